@@ -1,0 +1,147 @@
+/*
+ * svhip.h — C ABI of the MI355X-native speaker-embedding + scoring hot path (libsvhip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * checkout, hiimmuc/SpeakerVerification).  The reference is pure Python, so the "FFI" a maintainer
+ * adds is a ctypes binding — see INTEGRATION.md and speakerverification_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns an svhip_status (0 = ok, negative = error) and never throws;
+ *     svhip_last_error(h) returns the message of the last failing call on that handle.
+ *   - one handle = one HIP device + one HIP stream + one model's device weights + workspace.
+ *     Handles are thread-compatible, not thread-safe (one host thread per handle).
+ *   - the caller owns every buffer it passes.  `flags` says where they live:
+ *     SVHIP_IN_DEVICE / SVHIP_OUT_DEVICE mark device pointers; otherwise host pointers are
+ *     staged through the handle's own device buffers.  With SVHIP_ASYNC the call returns after
+ *     enqueueing on the handle's stream (device pointers only); otherwise it synchronises.
+ *   - activations inside the library are frame-major (B, T, C); the boundary keeps the
+ *     reference's layouts: waveforms (B, L) fp32, features (B, n_mels, T) fp32, embeddings
+ *     (B, nOut) fp32, all contiguous.
+ */
+#ifndef SVHIP_H
+#define SVHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVHIP_ABI_VERSION 1
+
+typedef struct svhip_handle svhip_handle;
+
+typedef enum svhip_status {
+    SVHIP_OK = 0,
+    SVHIP_ERR_INVALID = -1,     /* bad argument / shape */
+    SVHIP_ERR_HIP = -2,         /* a HIP runtime call failed */
+    SVHIP_ERR_STATE = -3,       /* call order violated (e.g. embed before finalize) */
+    SVHIP_ERR_NOMEM = -4,
+    SVHIP_ERR_UNSUPPORTED = -5,
+    SVHIP_ERR_MISSING = -6      /* a required weight tensor was never loaded */
+} svhip_status;
+
+enum { SVHIP_MODEL_ECAPA = 0, SVHIP_MODEL_RAWNET2 = 1, SVHIP_MODEL_NONE = 2 /* fbank + scoring only */ };
+enum { SVHIP_F32 = 0, SVHIP_BF16 = 1, SVHIP_I64 = 2 };
+enum { SVHIP_IN_DEVICE = 1, SVHIP_OUT_DEVICE = 2, SVHIP_ASYNC = 4 };
+
+typedef struct svhip_config {
+    int32_t struct_size;    /* = sizeof(svhip_config), for ABI evolution */
+    int32_t model;          /* SVHIP_MODEL_* */
+    int32_t compute;        /* SVHIP_F32: fp32 MFMA, 1e-4 parity path; SVHIP_BF16: bf16 MFMA, fp32 accumulate */
+    int32_t device;         /* HIP device ordinal */
+    int32_t channels;       /* ECAPA C (channels = [C,C,C,C,3C], ECAPA_TDNN.py:378) */
+    int32_t n_mels;         /* 80 */
+    int32_t embed_dim;      /* nOut: 192 (ECAPA) / 320 (RawNet2) */
+    int32_t max_batch;      /* workspace is sized for max_batch utterances per call */
+    int32_t samples;        /* L: samples per utterance (32000); fixes T = L/hop + 1 */
+    int32_t log_input;      /* ECAPA: 1 = features=='melspectrogram' -> log(x+1e-6) - mean_t (ECAPA_TDNN.py:473-476) */
+    int32_t input_norm;     /* ECAPA: InstanceNorm1d(n_mels, affine) (ECAPA_TDNN.py:406-409,477-478) */
+    /* mel front-end — defaults of models/FeatureExtraction/feature.py:66-71 */
+    int32_t fb_sr;          /* 8000 */
+    int32_t n_fft;          /* 512 */
+    int32_t win_length;     /* 200 */
+    int32_t hop_length;     /* 80 */
+    float   fmin;           /* 0 */
+    float   fmax;           /* <=0 -> sr/2 */
+    float   preemph;        /* 0.97; <0 disables pre-emphasis */
+    void*   stream;         /* optional hipStream_t to enqueue on (NULL: the handle creates its own) */
+} svhip_config;
+
+/* Fill *cfg with the reference defaults (ECAPA C=1024, fp32, 80 mels, nOut 192, L=32000). */
+void svhip_default_config(svhip_config* cfg);
+int  svhip_abi_version(void);
+
+/* Lifetime.  Replaces: SpeakerEncoder.__init__ building compute_features + __S__ on a device
+ * (src/model.py:61-73).  */
+int svhip_create(const svhip_config* cfg, svhip_handle** out);
+int svhip_destroy(svhip_handle* h);
+const char* svhip_last_error(const svhip_handle* h);   /* h may be NULL: last create() error */
+int svhip_synchronize(svhip_handle* h);
+
+/* Weights.  Replaces: ModelHandling.loadParameters' name-matched state_dict copy
+ * (src/model.py:718-746).  `name` is the reference state_dict key of the __S__ module (e.g.
+ * "blocks.1.tdnn1.conv.conv.weight"); data is host memory, dtype SVHIP_F32 or SVHIP_I64
+ * (num_batches_tracked, ignored).  Unknown names return SVHIP_ERR_INVALID, shape mismatches too —
+ * the Python shim decides whether to skip them as the reference does.  finalize folds BatchNorm
+ * into scale/shift, packs conv weights [N][tap][cin] (bf16 copy for the bf16 path), bakes the
+ * sinc filters (RawNet_baseline.py:339-357) and uploads everything. */
+int svhip_load_tensor(svhip_handle* h, const char* name, const void* data,
+                      const int64_t* shape, int32_t ndim, int32_t dtype);
+int svhip_finalize_weights(svhip_handle* h);
+
+/* Feature front-end.  Replaces: compute_features(inp) = Sequential(PreEmphasis, nnAudio
+ * MelSpectrogram) (models/FeatureExtraction/feature.py:66-94, src/utils.py:53-71;
+ * call site src/model.py:112-113).  wav (B, L) fp32 -> mel power (B, n_mels, T) fp32,
+ * T = L / hop + 1. */
+int svhip_fbank(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* mel_out, int32_t flags);
+
+/* Model forward.  Replaces: self.__S__.forward(inp) (src/model.py:119-121) ==
+ * ECAPA_TDNN.forward (models/ECAPA_TDNN.py:460-502) on features (B, n_mels, T), or
+ * RawNet2.forward (models/RawNet2_custom.py:161-227) on waveforms (B, L).  emb_out (B, nOut) fp32
+ * (the Python shim applies the reference's squeeze()). */
+int svhip_embed_features(svhip_handle* h, const float* feat, int32_t B, int32_t T, float* emb_out, int32_t flags);
+/* Fused waveform -> embedding: SpeakerEncoder.forward with label=None (src/model.py:104-125):
+ * compute_features then __S__.forward (ECAPA), or __S__.forward directly (RawNet2). */
+int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* emb_out, int32_t flags);
+
+/* Scoring.  Replaces the per-trial loop of ModelHandling.evaluateFromList / testFromList
+ * (src/model.py:415-448,526-553) and src/utils.py:126-169.
+ *   l2norm       : F.normalize(p=2, dim=1) in place (src/model.py:421-423), eps 1e-12.
+ *   score_pairs  : out[p] = | cos(E[ia[p]], E[ib[p]]) |, per-norm clamp 1e-5 (utils.py:163-164,
+ *                  one crop per row).
+ *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150) — fp32 MFMA.
+ *   asnorm_stats : per row of E: S = cohort @ e (utils.py:142), top-`top` largest, population
+ *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  Never materialises N x K.
+ *   asnorm_pairs : out[p] = 0.5*((s-mu[a])/sd[a] + (s-mu[b])/sd[b]), s = E[a].E[b] (utils.py:148-160).
+ * Pointers follow `flags` (indices are int32, device or host like the other inputs). */
+int svhip_l2norm(svhip_handle* h, float* E, int64_t N, int32_t D, int32_t flags);
+int svhip_score_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D,
+                      const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags);
+int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float* B, int64_t Nb,
+                       int32_t D, float* out, int32_t flags);
+int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* cohort,
+                       int32_t K, int32_t top, float* mu, float* sigma, int32_t flags);
+int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* mu,
+                       const float* sigma, const int32_t* ia, const int32_t* ib, int64_t P,
+                       float* out, int32_t flags);
+
+/* Introspection used by tests and bench.py (not part of the reference's surface).
+ *   get_stage    : copy an intermediate activation of the LAST forward to host as fp32, frame-major
+ *                  (B, T, C).  Names: "input","blocks.0".."blocks.3","mfa","asp","asp_bn" (ECAPA).
+ *                  Returns the element count through *count (out may be NULL to query).
+ *   profile_*    : when enabled every kernel launch is bracketed by HIP events on the handle's
+ *                  stream; profile_get returns accumulated milliseconds / launch count per kernel
+ *                  label since the last reset (enumerate idx = 0.. until SVHIP_ERR_INVALID).
+ *   workload_flops: algorithmic FLOPs (2 x MACs of conv/linear layers) of one utterance. */
+int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* count);
+int svhip_profile_enable(svhip_handle* h, int32_t on);
+int svhip_profile_reset(svhip_handle* h);
+int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops);
+double svhip_workload_flops(const svhip_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVHIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libsvhip.so (the C ABI declared in include/svhip.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load the import of any
+product module that needs it raises ``SvhipUnavailable`` — loudly — instead of silently running
+something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvhip.so")
+
+OK = 0
+MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
+F32, BF16, I64 = 0, 1, 2
+IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
+
+
+class SvhipUnavailable(RuntimeError):
+    pass
+
+
+class SvhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"svhip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("model", C.c_int32), ("compute", C.c_int32), ("device", C.c_int32),
+        ("channels", C.c_int32), ("n_mels", C.c_int32), ("embed_dim", C.c_int32), ("max_batch", C.c_int32),
+        ("samples", C.c_int32), ("log_input", C.c_int32), ("input_norm", C.c_int32),
+        ("fb_sr", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32), ("hop_length", C.c_int32),
+        ("fmin", C.c_float), ("fmax", C.c_float), ("preemph", C.c_float),
+        ("stream", C.c_void_p),
+    ]
+
+
+# every symbol include/svhip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = {
+    "svhip_default_config": (None, [C.POINTER(Config)]),
+    "svhip_abi_version": (C.c_int, []),
+    "svhip_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "svhip_destroy": (C.c_int, [_P]),
+    "svhip_last_error": (C.c_char_p, [_P]),
+    "svhip_synchronize": (C.c_int, [_P]),
+    "svhip_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
+    "svhip_finalize_weights": (C.c_int, [_P]),
+    "svhip_fbank": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "svhip_embed_features": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "svhip_embed_wave": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "svhip_l2norm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "svhip_score_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
+    "svhip_score_matrix": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
+    "svhip_asnorm_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
+    "svhip_asnorm_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
+    "svhip_get_stage": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64)]),
+    "svhip_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "svhip_profile_reset": (C.c_int, [_P]),
+    "svhip_profile_get": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "svhip_workload_flops": (C.c_double, [_P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load libsvhip.so (once).  Raises SvhipUnavailable if it is not built or cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvhipUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -m speakerverification_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback for the product path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SvhipUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SvhipUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def default_config() -> Config:
+    cfg = Config()
+    load().svhip_default_config(C.byref(cfg))
+    return cfg
+
+
+def check(handle, rc):
+    if rc != OK:
+        msg = load().svhip_last_error(handle)
+        raise SvhipError(rc, msg.decode() if msg else "?")

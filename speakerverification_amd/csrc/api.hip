@@ -1,0 +1,885 @@
+// api.hip — C ABI of libsvhip: handle, weight packing, forward orchestration (see include/svhip.h).
+#include "../../include/svhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace svhip;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct ConvLayer {            // one conv1d as a GEMM operand set (device pointers)
+    int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, dil = 1, cin = 0;
+    void* W = nullptr;        // packed [Np][Kp] in the compute dtype
+    float* bias = nullptr;    // [N] or null
+    float* scale = nullptr;   // folded BatchNorm (eval): y = x*scale + shift, or null
+    float* shift = nullptr;
+    double flops_per_row = 0;
+};
+
+struct LinearLayer {          // small-M fp32 linear (rowvec kernel)
+    int N = 0, K = 0;
+    float* W = nullptr;       // [N][K]
+    float* bias = nullptr;
+};
+
+struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
+
+}  // namespace
+
+struct svhip_handle {
+    svhip_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool bf16 = false;
+    bool finalized = false;
+    std::string err;
+    std::map<std::string, HostTensor> host_w;
+    std::vector<void*> allocs;               // everything hipMalloc'ed, freed in destroy
+
+    int T = 0;                                // frames per utterance
+    int esz = 4;                              // activation element size
+
+    // front-end tables
+    FbankTables fb;
+
+    // ECAPA layers
+    ConvLayer blocks0, mfa, asp_tdnn, asp_conv;
+    ConvLayer tdnn1[3], tdnn2[3], res2[3][7];
+    LinearLayer se1[3], se2[3], asp_ctx, fc;
+    float *aspbn_scale = nullptr, *aspbn_shift = nullptr;
+    float *in_w = nullptr, *in_b = nullptr;   // instance norm affine
+
+    // workspace (device)
+    float* d_wav = nullptr;       // (Bmax, L)
+    float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
+    float* d_pstats = nullptr;    // (Bmax*n_mels*2)
+    void* X_in = nullptr;         // (M, n_mels)
+    void* X0 = nullptr;           // (M, C)
+    void *H1 = nullptr, *H2 = nullptr, *H3 = nullptr;   // (M, C)
+    void* CAT = nullptr;          // (M, 3C)
+    void* MFA = nullptr;          // (M, 3C)
+    void* ATT = nullptr;          // (M, 128)
+    float* LOGITS = nullptr;      // (M, 3C) fp32
+    float *d_mean = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_gstats = nullptr, *d_ctx = nullptr;
+    float *d_pool_raw = nullptr, *d_pool_bn = nullptr, *d_emb = nullptr;
+    int lastB = 0;
+
+    // profiling
+    bool prof = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<ProfEntry> prof_entries;
+    double flops_per_utt = 0;
+};
+
+namespace {
+
+#define SV_FAIL(h, code, ...)                                   \
+    do {                                                        \
+        char _b[512];                                           \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+        (h)->err = _b;                                          \
+        return (code);                                          \
+    } while (0)
+
+#define SV_HIP(h, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(svhip_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return SVHIP_OK;
+}
+
+template <typename T>
+int dev_upload(svhip_handle* h, T** p, const std::vector<T>& v) {
+    int rc = dev_alloc(h, p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) SV_HIP(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SVHIP_OK;
+}
+
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---- profiling-aware launch wrapper --------------------------------------------------------------
+template <typename F>
+int run(svhip_handle* h, const char* label, double flops, F&& launch) {
+    if (h->prof) hipEventRecord(h->ev0, h->stream);
+    hipError_t e = launch();
+    if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "launch %s failed: %s", label, hipGetErrorString(e));
+    if (h->prof) {
+        hipEventRecord(h->ev1, h->stream);
+        hipEventSynchronize(h->ev1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        ProfEntry* pe = nullptr;
+        for (auto& x : h->prof_entries)
+            if (x.name == label) { pe = &x; break; }
+        if (!pe) { h->prof_entries.push_back(ProfEntry{label}); pe = &h->prof_entries.back(); }
+        pe->ms += ms;
+        pe->launches += 1;
+        pe->flops += flops;
+    }
+    return SVHIP_OK;
+}
+
+// ---- front-end tables (oracle/fbank.py restates the same constants) --------------------------------
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+int build_fbank_tables(svhip_handle* h) {
+    const svhip_config& c = h->cfg;
+    FbankTables& fb = h->fb;
+    fb.n_fft = c.n_fft; fb.win_length = c.win_length; fb.hop = c.hop_length; fb.n_mels = c.n_mels;
+    fb.n_bins = c.n_fft / 2 + 1;
+    fb.lpad = (c.n_fft - c.win_length) / 2;
+    fb.n_pairs = (fb.n_bins + 31) / 32;
+    fb.n_q = c.win_length / 8;
+    fb.preemph = c.preemph;
+    if (c.win_length % 8 != 0 || c.hop_length % 4 != 0 || fb.n_pairs > 9 || c.win_length > c.n_fft)
+        SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "fbank geometry n_fft=%d win=%d hop=%d not supported", c.n_fft, c.win_length, c.hop_length);
+    const double PI = 3.14159265358979323846;
+    // periodic Hamming (scipy get_window('hamming', win, fftbins=True)), cast to float32
+    std::vector<float> win(c.win_length);
+    for (int k = 0; k < c.win_length; ++k) win[k] = (float)(0.54 - 0.46 * std::cos(2.0 * PI * k / c.win_length));
+    // basis[q][pair][part][lane] float4: tap = 8q + 4h + j, bin = 32*pair + r (lane = 32h + r); part 0 = cos, 1 = sin
+    std::vector<float> basis((size_t)fb.n_q * fb.n_pairs * 2 * 64 * 4, 0.0f);
+    for (int q = 0; q < fb.n_q; ++q)
+        for (int pr = 0; pr < fb.n_pairs; ++pr)
+            for (int part = 0; part < 2; ++part)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = lane & 31, hh = lane >> 5;
+                        const int tap = 8 * q + 4 * hh + j, bin = 32 * pr + r;
+                        float v = 0.0f;
+                        if (bin < fb.n_bins) {
+                            const double ang = 2.0 * PI * (double)bin * (double)(fb.lpad + tap) / (double)c.n_fft;
+                            const float tr = (float)(part == 0 ? std::cos(ang) : std::sin(ang));
+                            v = tr * win[tap];                       // float32 product, as nnAudio's kernel * window mask
+                        }
+                        basis[((((size_t)q * fb.n_pairs + pr) * 2 + part) * 64 + lane) * 4 + j] = v;
+                    }
+    // Slaney mel bank (librosa 0.7 filters.mel(htk=False, norm=1)) in double, stored float32, sparse rows
+    const double sr = c.fb_sr;
+    const double fmax = c.fmax > 0 ? c.fmax : sr / 2;
+    const int nm = c.n_mels, nb = fb.n_bins;
+    std::vector<double> mel_f(nm + 2), fftf(nb);
+    for (int i = 0; i < nb; ++i) fftf[i] = (sr / 2) * i / (double)(nb - 1);
+    const double m0 = hz_to_mel(c.fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < nm + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (double)(nm + 1));
+    std::vector<float> mw;
+    std::vector<int> mstart(nm), mlen(nm), moff(nm);
+    for (int i = 0; i < nm; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        int first = -1, last = -1;
+        std::vector<float> row(nb);
+        for (int k = 0; k < nb; ++k) {
+            const double lower = -(mel_f[i] - fftf[k]) / fd0, upper = (mel_f[i + 2] - fftf[k]) / fd1;
+            const float w32 = (float)std::fmax(0.0, std::fmin(lower, upper));
+            row[k] = (float)((double)w32 * enorm);
+            if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
+        }
+        if (first < 0) { first = 0; last = -1; }
+        mstart[i] = first; mlen[i] = last - first + 1; moff[i] = (int)mw.size();
+        for (int k = first; k <= last; ++k) mw.push_back(row[k]);
+    }
+    if (mw.empty()) mw.push_back(0.0f);
+    float* d_basis; float* d_mw; int *d_ms, *d_ml, *d_mo;
+    int rc;
+    if ((rc = dev_upload(h, &d_basis, basis))) return rc;
+    if ((rc = dev_upload(h, &d_mw, mw))) return rc;
+    if ((rc = dev_upload(h, &d_ms, mstart))) return rc;
+    if ((rc = dev_upload(h, &d_ml, mlen))) return rc;
+    if ((rc = dev_upload(h, &d_mo, moff))) return rc;
+    fb.basis = d_basis; fb.mel_w = d_mw; fb.mel_start = d_ms; fb.mel_len = d_ml; fb.mel_off = d_mo;
+    return SVHIP_OK;
+}
+
+// ---- expected weight names / shapes ----------------------------------------------------------------
+const int ECAPA_K[5] = {5, 3, 3, 3, 1};
+const int ECAPA_D[5] = {1, 2, 3, 4, 1};
+
+void ecapa_spec(const svhip_config& c, std::map<std::string, std::vector<int64_t>>& spec) {
+    const int64_t C = c.channels, C3 = 3 * C, nm = c.n_mels;
+    auto bn = [&](const std::string& p, int64_t n) {
+        spec[p + ".weight"] = {n}; spec[p + ".bias"] = {n}; spec[p + ".running_mean"] = {n};
+        spec[p + ".running_var"] = {n}; spec[p + ".num_batches_tracked"] = {};
+    };
+    auto tdnn = [&](const std::string& p, int64_t cin, int64_t cout, int64_t k) {
+        spec[p + ".conv.conv.weight"] = {cout, cin, k}; spec[p + ".conv.conv.bias"] = {cout};
+        bn(p + ".norm.norm", cout);
+    };
+    if (c.input_norm) { spec["instance_norm.weight"] = {nm}; spec["instance_norm.bias"] = {nm}; }
+    tdnn("blocks.0", nm, C, ECAPA_K[0]);
+    for (int i = 1; i <= 3; ++i) {
+        const std::string p = "blocks." + std::to_string(i);
+        tdnn(p + ".tdnn1", C, C, 1);
+        for (int j = 0; j < 7; ++j) tdnn(p + ".res2net_block.blocks." + std::to_string(j), C / 8, C / 8, ECAPA_K[i]);
+        tdnn(p + ".tdnn2", C, C, 1);
+        spec[p + ".se_block.conv1.conv.weight"] = {128, C, 1}; spec[p + ".se_block.conv1.conv.bias"] = {128};
+        spec[p + ".se_block.conv2.conv.weight"] = {C, 128, 1}; spec[p + ".se_block.conv2.conv.bias"] = {C};
+    }
+    tdnn("mfa", C3, C3, 1);
+    tdnn("asp.tdnn", 3 * C3, 128, 1);
+    spec["asp.conv.conv.weight"] = {C3, 128, 1}; spec["asp.conv.conv.bias"] = {C3};
+    bn("asp_bn.norm", 2 * C3);
+    spec["fc.conv.weight"] = {(int64_t)c.embed_dim, 2 * C3, 1}; spec["fc.conv.bias"] = {(int64_t)c.embed_dim};
+}
+
+void model_spec(const svhip_config& c, std::map<std::string, std::vector<int64_t>>& spec) {
+    if (c.model == SVHIP_MODEL_ECAPA) ecapa_spec(c, spec);
+}
+
+const HostTensor* getw(svhip_handle* h, const std::string& name) {
+    auto it = h->host_w.find(name);
+    return it == h->host_w.end() ? nullptr : &it->second;
+}
+
+// fold BatchNorm1d(eval, eps=1e-5) into scale / shift (double arithmetic on the host)
+int make_bn(svhip_handle* h, const std::string& p, int n, float** scale, float** shift) {
+    const HostTensor *w = getw(h, p + ".weight"), *b = getw(h, p + ".bias"), *rm = getw(h, p + ".running_mean"),
+                     *rv = getw(h, p + ".running_var");
+    if (!w || !b || !rm || !rv) SV_FAIL(h, SVHIP_ERR_MISSING, "missing BatchNorm tensors for %s", p.c_str());
+    std::vector<float> sc(n), sh(n);
+    for (int i = 0; i < n; ++i) {
+        const double s = (double)w->data[i] / std::sqrt((double)rv->data[i] + 1e-5);
+        sc[i] = (float)s;
+        sh[i] = (float)((double)b->data[i] - (double)rm->data[i] * s);
+    }
+    int rc;
+    if ((rc = dev_upload(h, scale, sc))) return rc;
+    return dev_upload(h, shift, sh);
+}
+
+// pack conv weight (N, cin, taps) columns [c_lo, c_hi) -> [Np][Kp], k = tap*cin' + c
+int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std::string& bname, const std::string& bnname,
+              int dil, int c_lo = 0, int c_hi = -1) {
+    const HostTensor* w = getw(h, wname);
+    if (!w) SV_FAIL(h, SVHIP_ERR_MISSING, "missing tensor %s", wname.c_str());
+    const int N = (int)w->shape[0], cin_full = (int)w->shape[1], taps = (int)w->shape[2];
+    if (c_hi < 0) c_hi = cin_full;
+    const int cin = c_hi - c_lo;
+    const int bk = gemm_bk(h->bf16);
+    L.N = N; L.taps = taps; L.dil = dil; L.cin = cin; L.K = taps * cin;
+    L.Kp = round_up(L.K, bk); L.Np = round_up(N, GEMM_BN);
+    L.flops_per_row = 2.0 * N * L.K;
+    std::vector<float> packed((size_t)L.Np * L.Kp, 0.0f);
+    for (int n = 0; n < N; ++n)
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c)
+                packed[(size_t)n * L.Kp + t * cin + c] = w->data[((size_t)n * cin_full + (c_lo + c)) * taps + t];
+    int rc;
+    if (h->bf16) {
+        std::vector<uint16_t> pb(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) pb[i] = f32_to_bf16_rne(packed[i]);
+        uint16_t* d;
+        if ((rc = dev_upload(h, &d, pb))) return rc;
+        L.W = d;
+    } else {
+        float* d;
+        if ((rc = dev_upload(h, &d, packed))) return rc;
+        L.W = d;
+    }
+    if (!bname.empty()) {
+        const HostTensor* b = getw(h, bname);
+        if (!b) SV_FAIL(h, SVHIP_ERR_MISSING, "missing tensor %s", bname.c_str());
+        if ((rc = dev_upload(h, &L.bias, b->data))) return rc;
+    }
+    if (!bnname.empty()) return make_bn(h, bnname, N, &L.scale, &L.shift);
+    return SVHIP_OK;
+}
+
+int make_tdnn(svhip_handle* h, ConvLayer& L, const std::string& p, int dil) {
+    return make_conv(h, L, p + ".conv.conv.weight", p + ".conv.conv.bias", p + ".norm.norm", dil);
+}
+
+// fp32 linear from a (N, K, 1) or (N, K) tensor, optional column range
+int make_linear(svhip_handle* h, LinearLayer& L, const std::string& wname, const std::string& bname, int c_lo = 0, int c_hi = -1) {
+    const HostTensor* w = getw(h, wname);
+    if (!w) SV_FAIL(h, SVHIP_ERR_MISSING, "missing tensor %s", wname.c_str());
+    const int N = (int)w->shape[0], Kfull = (int)w->shape[1];
+    if (c_hi < 0) c_hi = Kfull;
+    L.N = N; L.K = c_hi - c_lo;
+    std::vector<float> m((size_t)N * L.K);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < L.K; ++k) m[(size_t)n * L.K + k] = w->data[(size_t)n * Kfull + c_lo + k];
+    int rc;
+    if ((rc = dev_upload(h, &L.W, m))) return rc;
+    if (!bname.empty()) {
+        const HostTensor* b = getw(h, bname);
+        if (!b) SV_FAIL(h, SVHIP_ERR_MISSING, "missing tensor %s", bname.c_str());
+        if ((rc = dev_upload(h, &L.bias, b->data))) return rc;
+    }
+    return SVHIP_OK;
+}
+
+int finalize_ecapa(svhip_handle* h) {
+    const int C = h->cfg.channels, C3 = 3 * C;
+    int rc;
+    if ((rc = make_tdnn(h, h->blocks0, "blocks.0", ECAPA_D[0]))) return rc;
+    for (int i = 1; i <= 3; ++i) {
+        const std::string p = "blocks." + std::to_string(i);
+        if ((rc = make_tdnn(h, h->tdnn1[i - 1], p + ".tdnn1", 1))) return rc;
+        for (int j = 0; j < 7; ++j)
+            if ((rc = make_tdnn(h, h->res2[i - 1][j], p + ".res2net_block.blocks." + std::to_string(j), ECAPA_D[i]))) return rc;
+        if ((rc = make_tdnn(h, h->tdnn2[i - 1], p + ".tdnn2", 1))) return rc;
+        if ((rc = make_linear(h, h->se1[i - 1], p + ".se_block.conv1.conv.weight", p + ".se_block.conv1.conv.bias"))) return rc;
+        if ((rc = make_linear(h, h->se2[i - 1], p + ".se_block.conv2.conv.weight", p + ".se_block.conv2.conv.bias"))) return rc;
+    }
+    if ((rc = make_tdnn(h, h->mfa, "mfa", 1))) return rc;
+    // asp.tdnn over cat[x, mean, std]: the x columns go through the GEMM, the time-constant columns
+    // become a per-utterance bias (ctx) computed by a small linear layer.
+    if ((rc = make_conv(h, h->asp_tdnn, "asp.tdnn.conv.conv.weight", "", "asp.tdnn.norm.norm", 1, 0, C3))) return rc;
+    if ((rc = make_linear(h, h->asp_ctx, "asp.tdnn.conv.conv.weight", "asp.tdnn.conv.conv.bias", C3, 3 * C3))) return rc;
+    if ((rc = make_conv(h, h->asp_conv, "asp.conv.conv.weight", "asp.conv.conv.bias", "", 1))) return rc;
+    if ((rc = make_bn(h, "asp_bn.norm", 2 * C3, &h->aspbn_scale, &h->aspbn_shift))) return rc;
+    if ((rc = make_linear(h, h->fc, "fc.conv.weight", "fc.conv.bias"))) return rc;
+    if (h->cfg.input_norm) {
+        const HostTensor *w = getw(h, "instance_norm.weight"), *b = getw(h, "instance_norm.bias");
+        if (!w || !b) SV_FAIL(h, SVHIP_ERR_MISSING, "missing instance_norm tensors");
+        if ((rc = dev_upload(h, &h->in_w, w->data))) return rc;
+        if ((rc = dev_upload(h, &h->in_b, b->data))) return rc;
+    }
+    // algorithmic FLOPs per utterance: 2 x MACs of every conv / linear (SURVEY §8d counts the same)
+    const double T = h->T;
+    double f = T * h->blocks0.flops_per_row + T * h->mfa.flops_per_row + T * h->asp_conv.flops_per_row;
+    f += T * 2.0 * 128 * (3.0 * C3);                                  // asp.tdnn over the full 9C input, as the reference computes it
+    for (int i = 0; i < 3; ++i) {
+        f += T * (h->tdnn1[i].flops_per_row + h->tdnn2[i].flops_per_row);
+        for (int j = 0; j < 7; ++j) f += T * h->res2[i][j].flops_per_row;
+        f += 2.0 * h->se1[i].N * h->se1[i].K + 2.0 * h->se2[i].N * h->se2[i].K;
+    }
+    f += 2.0 * h->fc.N * h->fc.K;
+    h->flops_per_utt = f;
+    return SVHIP_OK;
+}
+
+int alloc_workspace(svhip_handle* h) {
+    const svhip_config& c = h->cfg;
+    const size_t B = c.max_batch, T = h->T, M = B * T, C = c.channels, C3 = 3 * C, e = h->esz;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_wav, B * (size_t)c.samples))) return rc;
+    if ((rc = dev_alloc(h, &h->d_feat, B * c.n_mels * T))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pstats, B * c.n_mels * 2))) return rc;
+    if ((rc = dev_alloc(h, &h->d_emb, B * (size_t)c.embed_dim))) return rc;
+    if (c.model == SVHIP_MODEL_ECAPA) {
+        char* p;
+        auto actbuf = [&](void** dst, size_t elems) -> int {
+            int r = dev_alloc(h, &p, elems * e + 256);
+            *dst = p;
+            return r;
+        };
+        if ((rc = actbuf(&h->X_in, M * c.n_mels))) return rc;
+        if ((rc = actbuf(&h->X0, M * C))) return rc;
+        if ((rc = actbuf(&h->H1, M * C))) return rc;
+        if ((rc = actbuf(&h->H2, M * C))) return rc;
+        if ((rc = actbuf(&h->H3, M * C))) return rc;
+        if ((rc = actbuf(&h->CAT, M * C3))) return rc;
+        if ((rc = actbuf(&h->MFA, M * C3))) return rc;
+        if ((rc = actbuf(&h->ATT, M * 128))) return rc;
+        if ((rc = dev_alloc(h, &h->LOGITS, M * C3))) return rc;
+        if ((rc = dev_alloc(h, &h->d_mean, B * C))) return rc;
+        if ((rc = dev_alloc(h, &h->d_s1, B * 128))) return rc;
+        if ((rc = dev_alloc(h, &h->d_s2, B * C))) return rc;
+        if ((rc = dev_alloc(h, &h->d_gstats, B * 2 * C3))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ctx, B * 128))) return rc;
+        if ((rc = dev_alloc(h, &h->d_pool_raw, B * 2 * C3))) return rc;
+        if ((rc = dev_alloc(h, &h->d_pool_bn, B * 2 * C3))) return rc;
+    }
+    return SVHIP_OK;
+}
+
+// ---- GEMM call helper -------------------------------------------------------------------------------
+int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void* A, int lda, void* Y, int ldy, int M,
+              int act1, int act2 = ACT_NONE, const void* A2 = nullptr, int lda2 = 0, const float* bias_utt = nullptr,
+              int ld_bu = 0, bool out_f32 = false) {
+    GemmParams p;
+    p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
+    p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
+    p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np;
+    p.lda = lda; p.lda2 = lda2; p.ldy = ldy; p.ld_bu = ld_bu;
+    p.T = h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = PAD_REFLECT;
+    p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
+    const bool bf = h->bf16;
+    hipStream_t st = h->stream;
+    return run(h, label, (double)M * L.flops_per_row, [&]() { return launch_gemm(p, bf, st); });
+}
+
+inline void* off(void* base, size_t elems, int esz) { return reinterpret_cast<char*>(base) + elems * esz; }
+inline const void* off(const void* base, size_t elems, int esz) { return reinterpret_cast<const char*>(base) + elems * esz; }
+
+// ECAPA_TDNN.forward (models/ECAPA_TDNN.py:460-502) on device-resident features (B, n_mels, T)
+int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
+    const svhip_config& c = h->cfg;
+    const int T = h->T, M = B * T, C = c.channels, C3 = 3 * C, C8 = C / 8, e = h->esz;
+    const bool bf = h->bf16;
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = run(h, "prologue", 0, [&]() {
+             return launch_prologue(d_feat, h->X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, h->d_pstats, st);
+         }))) return rc;
+    if ((rc = conv_gemm(h, "gemm_blocks0", h->blocks0, h->X_in, c.n_mels, h->X0, C, M, ACT_GELU))) return rc;
+    const void* xin = h->X0;
+    int ldin = C;
+    for (int i = 0; i < 3; ++i) {
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, h->H1, C, M, ACT_GELU))) return rc;
+        if ((rc = run(h, "copy_cols", 0, [&]() { return launch_copy_cols(h->H1, C, h->H2, C, bf, M, C8, st); }))) return rc;
+        for (int j = 1; j < 8; ++j) {
+            const void* a = off(h->H1, (size_t)j * C8, e);
+            const void* a2 = j >= 2 ? off(h->H2, (size_t)(j - 1) * C8, e) : nullptr;
+            if ((rc = conv_gemm(h, "gemm_res2net", h->res2[i][j - 1], a, C, off(h->H2, (size_t)j * C8, e), C, M, ACT_RELU,
+                                ACT_NONE, a2, C)))
+                return rc;
+        }
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], h->H2, C, h->H3, C, M, ACT_GELU))) return rc;
+        if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(h->H3, bf, C, B, T, C, h->d_mean, st); }))) return rc;
+        if ((rc = run(h, "se_fc", 2.0 * B * 128 * C, [&]() {
+                 return launch_rowvec_linear(h->d_mean, C, h->se1[i].W, h->se1[i].bias, h->d_s1, 128, B, 128, C, ACT_RELU, st);
+             }))) return rc;
+        if ((rc = run(h, "se_fc", 2.0 * B * 128 * C, [&]() {
+                 return launch_rowvec_linear(h->d_s1, 128, h->se2[i].W, h->se2[i].bias, h->d_s2, C, B, C, 128, ACT_SIGMOID, st);
+             }))) return rc;
+        void* xout = off(h->CAT, (size_t)i * C, e);
+        if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(h->H3, C, h->d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))
+            return rc;
+        xin = xout;
+        ldin = C3;
+    }
+    if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, h->CAT, C3, h->MFA, C3, M, ACT_GELU))) return rc;
+    if ((rc = run(h, "asp_gstats", 0, [&]() { return launch_colstats(h->MFA, bf, C3, B, T, C3, h->d_gstats, 1e-12f, st); }))) return rc;
+    if ((rc = run(h, "asp_ctx", 2.0 * B * 128 * 2 * C3, [&]() {
+             return launch_rowvec_linear(h->d_gstats, 2 * C3, h->asp_ctx.W, h->asp_ctx.bias, h->d_ctx, 128, B, 128, 2 * C3, ACT_NONE, st);
+         }))) return rc;
+    if ((rc = conv_gemm(h, "gemm_asp_tdnn", h->asp_tdnn, h->MFA, C3, h->ATT, 128, M, ACT_RELU, ACT_TANH, nullptr, 0, h->d_ctx, 128)))
+        return rc;
+    if ((rc = conv_gemm(h, "gemm_asp_conv", h->asp_conv, h->ATT, 128, h->LOGITS, C3, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true)))
+        return rc;
+    if ((rc = run(h, "asp_pool", 0, [&]() {
+             return launch_asp_pool(h->LOGITS, h->MFA, bf, C3, B, T, C3, h->aspbn_scale, h->aspbn_shift, h->d_pool_raw, h->d_pool_bn, 1e-12f, st);
+         }))) return rc;
+    if ((rc = run(h, "fc", 2.0 * B * h->fc.N * h->fc.K, [&]() {
+             return launch_rowvec_linear(h->d_pool_bn, 2 * C3, h->fc.W, h->fc.bias, h->d_emb, c.embed_dim, B, c.embed_dim, 2 * C3, ACT_NONE, st);
+         }))) return rc;
+    h->lastB = B;
+    return SVHIP_OK;
+}
+
+int check_ready(svhip_handle* h, int B) {
+    if (!h) return SVHIP_ERR_INVALID;
+    if (!h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights not finalized (call svhip_finalize_weights first)");
+    if (B <= 0 || B > h->cfg.max_batch) SV_FAIL(h, SVHIP_ERR_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    return SVHIP_OK;
+}
+
+int finish(svhip_handle* h, int flags) {
+    if (!(flags & SVHIP_ASYNC)) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+void svhip_default_config(svhip_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(svhip_config);
+    c->model = SVHIP_MODEL_ECAPA;
+    c->compute = SVHIP_F32;
+    c->device = 0;
+    c->channels = 1024;
+    c->n_mels = 80;
+    c->embed_dim = 192;
+    c->max_batch = 8;
+    c->samples = 32000;
+    c->log_input = 1;
+    c->input_norm = 0;
+    c->fb_sr = 8000; c->n_fft = 512; c->win_length = 200; c->hop_length = 80;
+    c->fmin = 0.0f; c->fmax = -1.0f; c->preemph = 0.97f;
+    c->stream = nullptr;
+}
+
+int svhip_abi_version(void) { return SVHIP_ABI_VERSION; }
+
+const char* svhip_last_error(const svhip_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int svhip_create(const svhip_config* cfg, svhip_handle** out) {
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(svhip_config)) { g_create_error = "bad config / struct_size"; return SVHIP_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_error = std::string("no HIP device: ") + hipGetErrorString(e); return SVHIP_ERR_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return SVHIP_ERR_INVALID; }
+    if (cfg->model != SVHIP_MODEL_ECAPA && cfg->model != SVHIP_MODEL_RAWNET2 && cfg->model != SVHIP_MODEL_NONE) { g_create_error = "unknown model"; return SVHIP_ERR_INVALID; }
+    if (cfg->model == SVHIP_MODEL_ECAPA && (cfg->channels <= 0 || cfg->channels % 64 != 0)) { g_create_error = "ECAPA channels must be a positive multiple of 64"; return SVHIP_ERR_INVALID; }
+    if (cfg->n_mels <= 0 || cfg->n_mels % 8 != 0 || cfg->max_batch <= 0 || cfg->samples < cfg->n_fft || cfg->hop_length <= 0) { g_create_error = "bad n_mels / max_batch / samples"; return SVHIP_ERR_INVALID; }
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SVHIP_ERR_HIP; }
+    svhip_handle* h = new svhip_handle();
+    h->cfg = *cfg;
+    h->bf16 = cfg->compute == SVHIP_BF16;
+    h->esz = h->bf16 ? 2 : 4;
+    h->T = cfg->samples / cfg->hop_length + 1;
+    if (cfg->stream) { h->stream = reinterpret_cast<hipStream_t>(cfg->stream); h->own_stream = false; }
+    else {
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete h; return SVHIP_ERR_HIP; }
+        h->own_stream = true;
+    }
+    hipEventCreate(&h->ev0);
+    hipEventCreate(&h->ev1);
+    int rc = build_fbank_tables(h);
+    if (rc == SVHIP_OK) rc = alloc_workspace(h);
+    if (rc != SVHIP_OK) { g_create_error = h->err; svhip_destroy(h); return rc; }
+    if (cfg->model == SVHIP_MODEL_NONE) h->finalized = true;
+    *out = h;
+    return SVHIP_OK;
+}
+
+int svhip_destroy(svhip_handle* h) {
+    if (!h) return SVHIP_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SVHIP_OK;
+}
+
+int svhip_synchronize(svhip_handle* h) {
+    if (!h) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+int svhip_load_tensor(svhip_handle* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype) {
+    if (!h || !name || (!data && ndim > 0)) return SVHIP_ERR_INVALID;
+    if (h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights already finalized");
+    std::map<std::string, std::vector<int64_t>> spec;
+    model_spec(h->cfg, spec);
+    auto it = spec.find(name);
+    if (it == spec.end()) SV_FAIL(h, SVHIP_ERR_INVALID, "%s is not in the model.", name);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (shp != it->second) SV_FAIL(h, SVHIP_ERR_INVALID, "Wrong parameter shape: %s", name);
+    HostTensor t;
+    t.shape = shp;
+    const int64_t n = t.numel();
+    t.data.resize((size_t)n);
+    if (dtype == SVHIP_F32) memcpy(t.data.data(), data, (size_t)n * 4);
+    else if (dtype == SVHIP_I64) for (int64_t i = 0; i < n; ++i) t.data[i] = (float)reinterpret_cast<const int64_t*>(data)[i];
+    else SV_FAIL(h, SVHIP_ERR_INVALID, "unsupported dtype %d for %s", dtype, name);
+    h->host_w[name] = std::move(t);
+    return SVHIP_OK;
+}
+
+int svhip_finalize_weights(svhip_handle* h) {
+    if (!h) return SVHIP_ERR_INVALID;
+    if (h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights already finalized");
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    std::map<std::string, std::vector<int64_t>> spec;
+    model_spec(h->cfg, spec);
+    for (auto& kv : spec)
+        if (!h->host_w.count(kv.first) && kv.first.find("num_batches_tracked") == std::string::npos)
+            SV_FAIL(h, SVHIP_ERR_MISSING, "tensor %s was never loaded", kv.first.c_str());
+    int rc = SVHIP_ERR_UNSUPPORTED;
+    if (h->cfg.model == SVHIP_MODEL_ECAPA) rc = finalize_ecapa(h);
+    else SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "model %d has no forward path in this build", h->cfg.model);
+    if (rc) return rc;
+    SV_HIP(h, hipDeviceSynchronize());
+    h->host_w.clear();
+    h->finalized = true;
+    return SVHIP_OK;
+}
+
+int svhip_fbank(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* mel_out, int32_t flags) {
+    if (!h || !wav || !mel_out) return SVHIP_ERR_INVALID;
+    if (B <= 0 || B > h->cfg.max_batch) SV_FAIL(h, SVHIP_ERR_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+    if (L != h->cfg.samples) SV_FAIL(h, SVHIP_ERR_INVALID, "L=%d but the handle was created for %d samples", L, h->cfg.samples);
+    if ((flags & SVHIP_ASYNC) && (flags & (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE)) != (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE))
+        SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs device pointers");
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const float* d_in = wav;
+    if (!(flags & SVHIP_IN_DEVICE)) {
+        SV_HIP(h, hipMemcpyAsync(h->d_wav, wav, (size_t)B * L * 4, hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_wav;
+    }
+    float* d_out = (flags & SVHIP_OUT_DEVICE) ? mel_out : h->d_feat;
+    const int T = h->T;
+    int rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, d_out, h->stream); });
+    if (rc) return rc;
+    if (!(flags & SVHIP_OUT_DEVICE))
+        SV_HIP(h, hipMemcpyAsync(mel_out, d_out, (size_t)B * h->cfg.n_mels * T * 4, hipMemcpyDeviceToHost, h->stream));
+    return finish(h, flags);
+}
+
+int svhip_embed_features(svhip_handle* h, const float* feat, int32_t B, int32_t T, float* emb_out, int32_t flags) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!feat || !emb_out) SV_FAIL(h, SVHIP_ERR_INVALID, "null pointer");
+    if (h->cfg.model != SVHIP_MODEL_ECAPA) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embed_features needs a spectral model (ECAPA)");
+    if (T != h->T) SV_FAIL(h, SVHIP_ERR_INVALID, "T=%d but the handle was created for T=%d frames", T, h->T);
+    if ((flags & SVHIP_ASYNC) && (flags & (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE)) != (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE))
+        SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs device pointers");
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const float* d_in = feat;
+    if (!(flags & SVHIP_IN_DEVICE)) {
+        SV_HIP(h, hipMemcpyAsync(h->d_feat, feat, (size_t)B * h->cfg.n_mels * T * 4, hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_feat;
+    }
+    if ((rc = ecapa_forward(h, d_in, B))) return rc;
+    const size_t bytes = (size_t)B * h->cfg.embed_dim * 4;
+    SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, bytes, (flags & SVHIP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return finish(h, flags);
+}
+
+int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* emb_out, int32_t flags) {
+    int rc = check_ready(h, B);
+    if (rc) return rc;
+    if (!wav || !emb_out) SV_FAIL(h, SVHIP_ERR_INVALID, "null pointer");
+    if (L != h->cfg.samples) SV_FAIL(h, SVHIP_ERR_INVALID, "L=%d but the handle was created for %d samples", L, h->cfg.samples);
+    if ((flags & SVHIP_ASYNC) && (flags & (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE)) != (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE))
+        SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs device pointers");
+    if (h->cfg.model != SVHIP_MODEL_ECAPA) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "model %d has no forward path in this build", h->cfg.model);
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const float* d_in = wav;
+    if (!(flags & SVHIP_IN_DEVICE)) {
+        SV_HIP(h, hipMemcpyAsync(h->d_wav, wav, (size_t)B * L * 4, hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_wav;
+    }
+    const int T = h->T;
+    if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
+    if ((rc = ecapa_forward(h, h->d_feat, B))) return rc;
+    const size_t bytes = (size_t)B * h->cfg.embed_dim * 4;
+    SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, bytes, (flags & SVHIP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return finish(h, flags);
+}
+
+// ---- scoring ------------------------------------------------------------------------------------------
+namespace {
+struct TempBuf {      // device staging for host-pointer calls
+    svhip_handle* h; void* d = nullptr;
+    ~TempBuf() { if (d) hipFree(d); }
+    int in(const void* src, size_t bytes, bool is_dev, const void** out) {
+        if (is_dev) { *out = src; return SVHIP_OK; }
+        SV_HIP(h, hipMalloc(&d, bytes ? bytes : 16));
+        SV_HIP(h, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream));
+        *out = d;
+        return SVHIP_OK;
+    }
+    int out(void* dst, size_t bytes, bool is_dev, void** o) {
+        if (is_dev) { *o = dst; return SVHIP_OK; }
+        SV_HIP(h, hipMalloc(&d, bytes ? bytes : 16));
+        *o = d;
+        return SVHIP_OK;
+    }
+};
+}  // namespace
+
+int svhip_l2norm(svhip_handle* h, float* E, int64_t N, int32_t D, int32_t flags) {
+    if (!h || !E || N < 0 || D <= 0) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool dev = flags & SVHIP_IN_DEVICE;
+    TempBuf t{h};
+    const void* d;
+    int rc = t.in(E, (size_t)N * D * 4, dev, &d);
+    if (rc) return rc;
+    float* de = const_cast<float*>(reinterpret_cast<const float*>(d));
+    if ((rc = run(h, "l2norm", 0, [&]() { return launch_l2norm(de, N, D, h->stream); }))) return rc;
+    if (!dev) SV_HIP(h, hipMemcpyAsync(E, de, (size_t)N * D * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!dev || !(flags & SVHIP_ASYNC)) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+static int pairs_common(svhip_handle* h, int mode, const float* E, int64_t N, int32_t D, const float* mu, const float* sigma,
+                        const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags) {
+    if (!h || !E || !ia || !ib || !out || N <= 0 || D <= 0 || P < 0) return SVHIP_ERR_INVALID;
+    if (mode == 1 && (!mu || !sigma)) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    if (!din) {   // host indices are range-checked before they reach the GPU
+        for (int64_t p = 0; p < P; ++p)
+            if (ia[p] < 0 || ia[p] >= N || ib[p] < 0 || ib[p] >= N) SV_FAIL(h, SVHIP_ERR_INVALID, "pair %lld indexes outside [0, %lld)", (long long)p, (long long)N);
+    }
+    TempBuf tE{h}, tA{h}, tB{h}, tM{h}, tS{h}, tO{h};
+    const void *dE, *dA, *dB, *dM = nullptr, *dS = nullptr;
+    void* dO;
+    int rc;
+    if ((rc = tE.in(E, (size_t)N * D * 4, din, &dE))) return rc;
+    if ((rc = tA.in(ia, (size_t)P * 4, din, &dA))) return rc;
+    if ((rc = tB.in(ib, (size_t)P * 4, din, &dB))) return rc;
+    if (mode == 1) {
+        if ((rc = tM.in(mu, (size_t)N * 4, din, &dM))) return rc;
+        if ((rc = tS.in(sigma, (size_t)N * 4, din, &dS))) return rc;
+    }
+    if ((rc = tO.out(out, (size_t)P * 4, dout, &dO))) return rc;
+    if (mode == 0)
+        rc = run(h, "score_pairs", 2.0 * P * D, [&]() { return launch_score_pairs((const float*)dE, D, (const int32_t*)dA, (const int32_t*)dB, P, (float*)dO, h->stream); });
+    else
+        rc = run(h, "asnorm_pairs", 2.0 * P * D, [&]() { return launch_asnorm_pairs((const float*)dE, D, (const float*)dM, (const float*)dS, (const int32_t*)dA, (const int32_t*)dB, P, (float*)dO, h->stream); });
+    if (rc) return rc;
+    if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+int svhip_score_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, const int32_t* ia, const int32_t* ib, int64_t P,
+                      float* out, int32_t flags) {
+    return pairs_common(h, 0, E, N, D, nullptr, nullptr, ia, ib, P, out, flags);
+}
+
+int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* mu, const float* sigma,
+                       const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags) {
+    return pairs_common(h, 1, E, N, D, mu, sigma, ia, ib, P, out, flags);
+}
+
+// out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed)
+static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO) {
+    if (D % 32 != 0) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embedding dim %d must be a multiple of 32", D);
+    if (Na > (1 << 30) / 1 || Nb > (1 << 30)) SV_FAIL(h, SVHIP_ERR_INVALID, "matrix too large");
+    GemmParams p;
+    p.A = dA; p.W = dB; p.Y = dO;
+    p.M = (int)Na; p.N = (int)Nb; p.K = D; p.Kp = D; p.Wrows = (int)Nb;
+    p.lda = D; p.ldy = (int)Nb; p.T = 1;
+    hipStream_t st = h->stream;
+    return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
+}
+
+int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float* B, int64_t Nb, int32_t D, float* out, int32_t flags) {
+    if (!h || !A || !B || !out || Na <= 0 || Nb <= 0 || D <= 0) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    TempBuf tA{h}, tB{h}, tO{h};
+    const void *dA, *dB;
+    void* dO;
+    int rc;
+    if ((rc = tA.in(A, (size_t)Na * D * 4, din, &dA))) return rc;
+    if ((rc = tB.in(B, (size_t)Nb * D * 4, din, &dB))) return rc;
+    if ((rc = tO.out(out, (size_t)Na * Nb * 4, dout, &dO))) return rc;
+    if ((rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO))) return rc;
+    if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* cohort, int32_t K, int32_t top,
+                       float* mu, float* sigma, int32_t flags) {
+    if (!h || !E || !cohort || !mu || !sigma || N <= 0 || D <= 0 || K <= 0) return SVHIP_ERR_INVALID;
+    if (top < 0) top = K + top;             // python slice semantics of S[:top] (utils.py:143); top=-1 drops the smallest
+    if (top > K) top = K;
+    if (top <= 0) SV_FAIL(h, SVHIP_ERR_INVALID, "top must select at least one cohort score");
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    TempBuf tE{h}, tC{h}, tM{h}, tS{h};
+    const void *dE, *dC;
+    void *dM, *dS;
+    int rc;
+    if ((rc = tE.in(E, (size_t)N * D * 4, din, &dE))) return rc;
+    if ((rc = tC.in(cohort, (size_t)K * D * 4, din, &dC))) return rc;
+    if ((rc = tM.out(mu, (size_t)N * 4, dout, &dM))) return rc;
+    if ((rc = tS.out(sigma, (size_t)N * 4, dout, &dS))) return rc;
+    // cohort scores are produced slab by slab into an HBM scratch (rows x K fp32) and reduced per row
+    const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 30) / ((int64_t)K * 4)));
+    float* slab = nullptr;
+    SV_HIP(h, hipMalloc((void**)&slab, (size_t)slab_rows * K * 4));
+    for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
+        const int64_t rows = std::min(slab_rows, N - r0);
+        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab);
+        if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
+        if (rc) break;
+    }
+    hipStreamSynchronize(h->stream);
+    hipFree(slab);
+    if (rc) return rc;
+    if (!dout) {
+        SV_HIP(h, hipMemcpy(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost));
+        SV_HIP(h, hipMemcpy(sigma, dS, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+    return SVHIP_OK;
+}
+
+// ---- introspection ---------------------------------------------------------------------------------------
+int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* count) {
+    if (!h || !name || !count) return SVHIP_ERR_INVALID;
+    if (h->lastB <= 0) SV_FAIL(h, SVHIP_ERR_STATE, "no forward has run yet");
+    const int B = h->lastB, T = h->T, C = h->cfg.channels, C3 = 3 * C, e = h->esz;
+    const size_t M = (size_t)B * T;
+    const void* src = nullptr;
+    size_t rows = M, cols = 0, ld = 0;
+    bool f32 = !h->bf16;
+    const std::string n(name);
+    if (n == "input") { src = h->X_in; cols = ld = h->cfg.n_mels; }
+    else if (n == "blocks.0") { src = h->X0; cols = ld = C; }
+    else if (n == "blocks.1" || n == "blocks.2" || n == "blocks.3") { const int i = n.back() - '1'; src = off(h->CAT, (size_t)i * C, e); cols = C; ld = C3; }
+    else if (n == "mfa") { src = h->MFA; cols = ld = C3; }
+    else if (n == "asp") { src = h->d_pool_raw; rows = B; cols = ld = 2 * C3; f32 = true; }
+    else if (n == "asp_bn") { src = h->d_pool_bn; rows = B; cols = ld = 2 * C3; f32 = true; }
+    else if (n == "mel") { src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true; }
+    else SV_FAIL(h, SVHIP_ERR_INVALID, "unknown stage %s", name);
+    *count = (int64_t)(rows * cols);
+    if (!out) return SVHIP_OK;
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t es = f32 ? 4 : 2;
+    std::vector<char> tmp(rows * cols * es);
+    SV_HIP(h, hipMemcpy2D(tmp.data(), cols * es, src, ld * es, cols * es, rows, hipMemcpyDeviceToHost));
+    if (f32) memcpy(out, tmp.data(), tmp.size());
+    else {
+        const uint16_t* s = reinterpret_cast<const uint16_t*>(tmp.data());
+        for (size_t i = 0; i < rows * cols; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&out[i], &u, 4); }
+    }
+    return SVHIP_OK;
+}
+
+int svhip_profile_enable(svhip_handle* h, int32_t on) { if (!h) return SVHIP_ERR_INVALID; h->prof = on != 0; return SVHIP_OK; }
+int svhip_profile_reset(svhip_handle* h) { if (!h) return SVHIP_ERR_INVALID; h->prof_entries.clear(); return SVHIP_OK; }
+int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops) {
+    if (!h || idx < 0 || idx >= (int32_t)h->prof_entries.size()) return SVHIP_ERR_INVALID;
+    const ProfEntry& p = h->prof_entries[idx];
+    if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ms) *ms = p.ms;
+    if (launches) *launches = p.launches;
+    if (flops) *flops = p.flops;
+    return SVHIP_OK;
+}
+double svhip_workload_flops(const svhip_handle* h) { return h ? h->flops_per_utt : 0.0; }
+
+}  // extern "C"

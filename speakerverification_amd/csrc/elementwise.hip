@@ -1,0 +1,255 @@
+// elementwise.hip — frame-major reductions and elementwise kernels of the ECAPA / RawNet2 stacks.
+// All of these are HBM-bound: 16-byte vector accesses, lanes along the contiguous channel axis,
+// wavefront-parallel over T with a small LDS combine, fp32 statistics.
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+// ---- mean / std over the T rows of each utterance ---------------------------------------------
+// grid (ceil(C / (64*VEC)), B), block 256: wave w takes frames t = w, w+4, ...; lane owns VEC channels.
+template <typename T, bool STD>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ X, int ldx, int Tn, int C,
+                                                       float* __restrict__ out, int ld_out, float eps) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float red[4][64 * VEC];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * VEC;
+    const bool ok = c0 < C;
+    const T* __restrict__ base = X + (int64_t)b * Tn * ldx + c0;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.0f;
+    if (ok)
+        for (int t = wave; t < Tn; t += 4) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(base + (int64_t)t * ldx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += v.get(j);
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[wave][lane * VEC + j] = s[j];
+    __syncthreads();
+    float mean[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int e = lane * VEC + j;
+        mean[j] = (red[0][e] + red[1][e] + red[2][e] + red[3][e]) / (float)Tn;
+    }
+    if (!STD) {
+        if (wave == 0 && ok)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) out[(int64_t)b * ld_out + c0 + j] = mean[j];
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.0f;
+    if (ok)
+        for (int t = wave; t < Tn; t += 4) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(base + (int64_t)t * ldx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = v.get(j) - mean[j];
+                s[j] = fmaf(d, d, s[j]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[wave][lane * VEC + j] = s[j];
+    __syncthreads();
+    if (wave == 0 && ok)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int e = lane * VEC + j;
+            const float var = (red[0][e] + red[1][e] + red[2][e] + red[3][e]) / (float)Tn;
+            out[(int64_t)b * ld_out + c0 + j] = mean[j];
+            out[(int64_t)b * ld_out + C + c0 + j] = sqrtf(fmaxf(var, eps));
+        }
+}
+
+// ---- small-M linear: out[b, n] = act(bias[n] + W[n, :] . in[b, :]) -----------------------------
+// grid (ceil(N / 32), B), block 256: the input row is staged in LDS once, each wave produces 8 outputs.
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ in, int ld_in,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int ld_out, int N, int K, int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xin = reinterpret_cast<float*>(smem);
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < K; k += 256) xin[k] = in[(int64_t)b * ld_in + k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int o = 0; o < 8; ++o) {
+        const int n = blockIdx.x * 32 + wave * 8 + o;
+        if (n >= N) break;
+        const float* __restrict__ w = W + (int64_t)n * K;
+        float s = 0.0f;
+        for (int k = lane; k < K; k += 64) s = fmaf(w[k], xin[k], s);
+        s = wave_sum(s);
+        if (lane == 0) out[(int64_t)b * ld_out + n] = apply_act(s + (bias ? bias[n] : 0.0f), act);
+    }
+}
+
+// ---- SE gate + residual -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ s,
+                                                       const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
+                                                       int Tn, int C, int64_t total_chunks) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpr = C / VEC;   // chunks per row
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total_chunks; id += (int64_t)gridDim.x * 256) {
+        const int64_t m = id / cpr;
+        const int c = (int)(id - m * cpr) * VEC;
+        const int b = (int)(m / Tn);
+        Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
+        Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), s[(int64_t)b * C + c + j], xv.get(j)));
+        *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                                        int C, int64_t total_chunks) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpr = C / VEC;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total_chunks; id += (int64_t)gridDim.x * 256) {
+        const int64_t m = id / cpr;
+        const int c = (int)(id - m * cpr) * VEC;
+        *reinterpret_cast<Vec16<T>*>(dst + m * ldd + c) = *reinterpret_cast<const Vec16<T>*>(src + m * lds_ + c);
+    }
+}
+
+// ---- attentive statistics pooling (softmax over T, weighted mean / std, BatchNorm) --------------
+// grid (ceil(C / 64), B), block 256: lane = channel, wave w takes frames t = w, w+4, ...
+template <typename T>
+__global__ __launch_bounds__(256) void asp_pool_kernel(const float* __restrict__ logits, const T* __restrict__ X, int ldx,
+                                                       int Tn, int C, const float* __restrict__ bn_scale,
+                                                       const float* __restrict__ bn_shift, float* __restrict__ pooled_raw,
+                                                       float* __restrict__ pooled_bn, float eps) {
+    __shared__ float smx[4][64], sse[4][64], ssx[4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    const float* __restrict__ lg = logits + (int64_t)b * Tn * C + c;
+    const T* __restrict__ xp = X + (int64_t)b * Tn * ldx + c;
+    // pass 1: online softmax statistics
+    float mx = -INFINITY, se = 0.0f, sx = 0.0f;
+    if (ok)
+        for (int t = wave; t < Tn; t += 4) {
+            const float a = lg[(int64_t)t * C];
+            const float xv = to_f32<T>(xp[(int64_t)t * ldx]);
+            if (a > mx) {
+                const float f = expf(mx - a);     // exp(-inf) = 0 on the first frame
+                se *= f;
+                sx *= f;
+                mx = a;
+            }
+            const float e = expf(a - mx);
+            se += e;
+            sx = fmaf(e, xv, sx);
+        }
+    smx[wave][lane] = mx; sse[wave][lane] = se; ssx[wave][lane] = sx;
+    __syncthreads();
+    float M = fmaxf(fmaxf(smx[0][lane], smx[1][lane]), fmaxf(smx[2][lane], smx[3][lane]));
+    float SE = 0.0f, SX = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float f = (smx[w][lane] == -INFINITY) ? 0.0f : expf(smx[w][lane] - M);
+        SE = fmaf(sse[w][lane], f, SE);
+        SX = fmaf(ssx[w][lane], f, SX);
+    }
+    const float mean = SX / SE;
+    __syncthreads();
+    // pass 2: weighted variance around the weighted mean
+    float sv = 0.0f;
+    if (ok)
+        for (int t = wave; t < Tn; t += 4) {
+            const float a = lg[(int64_t)t * C];
+            const float d = to_f32<T>(xp[(int64_t)t * ldx]) - mean;
+            sv = fmaf(expf(a - M), d * d, sv);
+        }
+    sse[wave][lane] = sv;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        const float var = (sse[0][lane] + sse[1][lane] + sse[2][lane] + sse[3][lane]) / SE;
+        const float sd = sqrtf(fmaxf(var, eps));
+        if (pooled_raw) {
+            pooled_raw[(int64_t)b * 2 * C + c] = mean;
+            pooled_raw[(int64_t)b * 2 * C + C + c] = sd;
+        }
+        pooled_bn[(int64_t)b * 2 * C + c] = fmaf(mean, bn_scale[c], bn_shift[c]);
+        pooled_bn[(int64_t)b * 2 * C + C + c] = fmaf(sd, bn_scale[C + c], bn_shift[C + c]);
+    }
+}
+
+inline int grid_for(int64_t work_items) {
+    int64_t g = (work_items + 255) / 256;
+    const int64_t cap = 256 * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec != 0 || ldx % vec != 0) return hipErrorInvalidValue;
+    dim3 grid((C + 64 * vec - 1) / (64 * vec), B), block(256);
+    if (bf16) hipLaunchKernelGGL((colstats_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, mean, C, 0.f);
+    else hipLaunchKernelGGL((colstats_kernel<float, false>), grid, block, 0, stream, (const float*)X, ldx, T, C, mean, C, 0.f);
+    return hipGetLastError();
+}
+
+hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int C, float* stats, float eps, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec != 0 || ldx % vec != 0) return hipErrorInvalidValue;
+    dim3 grid((C + 64 * vec - 1) / (64 * vec), B), block(256);
+    if (bf16) hipLaunchKernelGGL((colstats_kernel<bf16_t, true>), grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, stats, 2 * C, eps);
+    else hipLaunchKernelGGL((colstats_kernel<float, true>), grid, block, 0, stream, (const float*)X, ldx, T, C, stats, 2 * C, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
+                                int B, int N, int K, int act, hipStream_t stream) {
+    if (K <= 0 || N <= 0 || (size_t)K * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+    dim3 grid((N + 31) / 32, B), block(256);
+    hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, (size_t)K * sizeof(float), stream, in, ld_in, W, bias, out, ld_out, N, K, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
+                           bool bf16, int B, int T, int C, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec || ldh % vec || ldx % vec || ldo % vec) return hipErrorInvalidValue;
+    const int64_t chunks = (int64_t)B * T * (C / vec);
+    dim3 grid(grid_for(chunks)), block(256);
+    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C, chunks);
+    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_cols(const void* src, int lds_, void* dst, int ldd, bool bf16, int M, int C, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec || lds_ % vec || ldd % vec) return hipErrorInvalidValue;
+    const int64_t chunks = (int64_t)M * (C / vec);
+    dim3 grid(grid_for(chunks)), block(256);
+    if (bf16) hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, C, chunks);
+    else hipLaunchKernelGGL(copy_cols_kernel<float>, grid, block, 0, stream, (const float*)src, lds_, (float*)dst, ldd, C, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_asp_pool(const float* logits, const void* X, bool bf16, int ldx, int B, int T, int C,
+                           const float* bn_scale, const float* bn_shift, float* pooled_raw, float* pooled_bn,
+                           float eps, hipStream_t stream) {
+    dim3 grid((C + 63) / 64, B), block(256);
+    if (bf16) hipLaunchKernelGGL(asp_pool_kernel<bf16_t>, grid, block, 0, stream, logits, (const bf16_t*)X, ldx, T, C, bn_scale, bn_shift, pooled_raw, pooled_bn, eps);
+    else hipLaunchKernelGGL(asp_pool_kernel<float>, grid, block, 0, stream, logits, (const float*)X, ldx, T, C, bn_scale, bn_shift, pooled_raw, pooled_bn, eps);
+    return hipGetLastError();
+}
+
+}  // namespace svhip

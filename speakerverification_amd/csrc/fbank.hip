@@ -1,0 +1,208 @@
+// fbank.hip — pre-emphasis + STFT power spectrum + Slaney mel bank on gfx950.
+//
+// Replaces Sequential(PreEmphasis, nnAudio MelSpectrogram) (reference
+// models/FeatureExtraction/feature.py:66-94, src/utils.py:53-71): wav (B, L) -> mel power (B, n_mels, T).
+//
+// One workgroup = 32 consecutive frames of one utterance, 3 waves.
+//   1. the pre-emphasised, reflect-padded samples the 32 frames touch (31*hop + win_length) are built
+//      once in LDS (coalesced HBM read of the waveform tile);
+//   2. the windowed DFT is a (32 frames x win_length taps) x (taps x 2*n_bins) product on the exact
+//      fp32 MFMA (v_mfma_f32_32x32x2_f32): the A fragments are ds_read_b128 of 4 consecutive taps
+//      straight out of the sample buffer (frames overlap, so no im2col copy exists anywhere), the B
+//      fragments (windowed cos / sin, laid out per lane as float4) stream from L2.  re and im of a bin
+//      land in the same lane, so |X|^2 is formed in registers;
+//   3. the 32 x n_bins power tile goes through LDS (stride 289: conflict-free both ways) and the
+//      sparse triangular mel filters are applied from there; frames are written coalesced along T.
+// Only the non-zero window taps (200 of 512) are multiplied.
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+constexpr int FB_FRAMES = 32;
+constexpr int FB_THREADS = 192;
+constexpr int FB_PT_STRIDE = 289;     // 9*32 + 1
+constexpr int FB_PAIRS_PER_WAVE = 3;
+
+__global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const float* __restrict__ wav,
+                                                           int L, int T, float* __restrict__ mel) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ns = (FB_FRAMES - 1) * tb.hop + tb.win_length;       // samples touched by the tile
+    const int ns_pad = (ns + 3) & ~3;
+    float* ys = reinterpret_cast<float*>(smem);
+    float* pt = ys + ns_pad;                                       // [32][289]
+
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * FB_FRAMES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ x = wav + (int64_t)b * L;
+
+    // ---- 1. pre-emphasised + reflect-padded samples -> LDS -------------------------------------
+    const int j0 = f0 * tb.hop + tb.lpad - tb.n_fft / 2;
+    const float coef = tb.preemph;
+    for (int i = tid; i < ns_pad; i += FB_THREADS) {
+        int jj = j0 + i;
+        jj = jj < 0 ? -jj : jj;
+        jj = jj >= L ? 2 * (L - 1) - jj : jj;
+        jj = max(0, min(jj, L - 1));
+        float v = x[jj];
+        if (coef >= 0.0f) {
+            const float prev = x[jj == 0 ? 1 : jj - 1];            // F.pad(reflect,(1,0)): x[-1] := x[1]
+            v = __fadd_rn(__fmul_rn(-coef, prev), v);              // conv1d with taps [-coef, 1]
+        }
+        ys[i] = v;
+    }
+    __syncthreads();
+
+    // ---- 2. windowed DFT on the fp32 MFMA --------------------------------------------------------
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[FB_PAIRS_PER_WAVE][2];
+#pragma unroll
+    for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
+
+    const f32x4* __restrict__ basis = reinterpret_cast<const f32x4*>(tb.basis);
+    const float* arow = ys + r * tb.hop + 4 * h;
+    for (int q = 0; q < tb.n_q; ++q) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+#pragma unroll
+        for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a) {
+            const int pair = wave * FB_PAIRS_PER_WAVE + a;
+            if (pair < tb.n_pairs) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 b4 = basis[((int64_t)(q * tb.n_pairs + pair) * 2 + c) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[a][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- 3. power -> LDS (frame-major), then sparse mel filters ----------------------------------
+#pragma unroll
+    for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a) {
+        const int pair = wave * FB_PAIRS_PER_WAVE + a;
+        if (pair < tb.n_pairs) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float re = acc[a][0][e], im = acc[a][1][e];
+                const float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));   // 'Magnitude'
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+                pt[i * FB_PT_STRIDE + pair * 32 + r] = __fmul_rn(mag, mag);                      // ** 2.0
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < FB_FRAMES * tb.n_mels; idx += FB_THREADS) {
+        const int i = idx & 31, m = idx >> 5;
+        const int f = f0 + i;
+        const int st = tb.mel_start[m], ln = tb.mel_len[m];
+        const float* __restrict__ w = tb.mel_w + tb.mel_off[m];
+        const float* prow = pt + i * FB_PT_STRIDE + st;
+        float s = 0.0f;
+        for (int k = 0; k < ln; ++k) s = fmaf(w[k], prow[k], s);
+        if (f < T) mel[((int64_t)b * tb.n_mels + m) * T + f] = s;
+    }
+}
+
+// per (b, mel): mean of log(x + 1e-6) over T (and biased variance of the normalised signal when
+// instance norm is on).  stats[(b*n_mels + m)*2 + {0,1}] = {shift, scale}: y = (v - shift) * scale.
+__global__ __launch_bounds__(256) void prologue_stats_kernel(const float* __restrict__ feat, float* __restrict__ stats,
+                                                             int rows, int T, int log_input, int inorm) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* __restrict__ x = feat + (int64_t)row * T;
+    float s = 0.0f;
+    for (int t = lane; t < T; t += 64) {
+        float v = x[t];
+        if (log_input) v = logf(v + 1e-6f);
+        s += v;
+    }
+    const float mean = wave_sum(s) / (float)T;
+    float shift = log_input ? mean : 0.0f, scale = 1.0f;
+    if (inorm) {
+        // InstanceNorm1d over t of u = (v - shift): mean_u = mean - shift, var biased
+        const float mu = mean - shift;
+        float q = 0.0f;
+        for (int t = lane; t < T; t += 64) {
+            float v = x[t];
+            if (log_input) v = logf(v + 1e-6f);
+            const float d = (v - shift) - mu;
+            q += d * d;
+        }
+        const float var = wave_sum(q) / (float)T;
+        shift = shift + mu;
+        scale = 1.0f / sqrtf(var + 1e-5f);
+    }
+    if (lane == 0) { stats[2 * row] = shift; stats[2 * row + 1] = scale; }
+}
+
+// (B, n_mels, T) -> (B, T, n_mels) with log / shift / scale / affine applied; 32-frame LDS transpose tile.
+template <typename T_>
+__global__ __launch_bounds__(256) void prologue_apply_kernel(const float* __restrict__ feat, const float* __restrict__ stats,
+                                                             T_* __restrict__ out, int n_mels, int T, int log_input,
+                                                             const float* __restrict__ in_w, const float* __restrict__ in_b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);      // [n_mels][33]
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    for (int idx = threadIdx.x; idx < n_mels * 32; idx += 256) {
+        const int i = idx & 31, m = idx >> 5;
+        const int t = t0 + i;
+        float v = 0.0f;
+        if (t < T) {
+            v = feat[((int64_t)b * n_mels + m) * T + t];
+            if (log_input) v = logf(v + 1e-6f);
+            const float sh = stats[2 * (b * n_mels + m)], sc = stats[2 * (b * n_mels + m) + 1];
+            v = (v - sh) * sc;
+            if (in_w) v = v * in_w[m] + in_b[m];
+        }
+        tile[m * 33 + i] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n_mels * 32; idx += 256) {
+        const int m = idx % n_mels, i = idx / n_mels;
+        const int t = t0 + i;
+        if (t < T) out[((int64_t)b * T + t) * n_mels + m] = from_f32<T_>(tile[m * 33 + i]);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, int T, float* mel, hipStream_t stream) {
+    if (tb.win_length % 8 != 0 || tb.hop % 4 != 0 || tb.n_pairs > 3 * FB_PAIRS_PER_WAVE ||
+        tb.n_bins > 32 * tb.n_pairs || tb.n_q * 8 != tb.win_length || L < tb.n_fft || B <= 0)
+        return hipErrorInvalidValue;
+    const int ns = (FB_FRAMES - 1) * tb.hop + tb.win_length;
+    const int ns_pad = (ns + 3) & ~3;
+    const size_t lds = (size_t)(ns_pad + FB_FRAMES * FB_PT_STRIDE) * sizeof(float);
+    dim3 grid((T + FB_FRAMES - 1) / FB_FRAMES, B), block(FB_THREADS);
+    hipLaunchKernelGGL(fbank_kernel, grid, block, lds, stream, tb, wav, L, T, mel);
+    return hipGetLastError();
+}
+
+hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, int n_mels, int T, int log_input,
+                           const float* in_w, const float* in_b, float* stats, hipStream_t stream) {
+    const int rows = B * n_mels;
+    hipLaunchKernelGGL(prologue_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, feat, stats, rows, T,
+                       log_input, in_w != nullptr ? 1 : 0);
+    dim3 grid((T + 31) / 32, B);
+    const size_t lds = (size_t)n_mels * 33 * sizeof(float);
+    if (out_bf16)
+        hipLaunchKernelGGL(prologue_apply_kernel<bf16_t>, grid, dim3(256), lds, stream, feat, stats,
+                           reinterpret_cast<bf16_t*>(out), n_mels, T, log_input, in_w, in_b);
+    else
+        hipLaunchKernelGGL(prologue_apply_kernel<float>, grid, dim3(256), lds, stream, feat, stats,
+                           reinterpret_cast<float*>(out), n_mels, T, log_input, in_w, in_b);
+    return hipGetLastError();
+}
+
+}  // namespace svhip

@@ -1,0 +1,266 @@
+// gemm.hip — LDS-tiled MFMA GEMM for the TDNN / Res2Net / MFA / ASP convolutions (gfx950).
+//
+// One kernel template covers both compute dtypes because the byte geometry is identical:
+// a K-step is 128 bytes per row (64 bf16 or 32 fp32), moved as 16-byte chunks.
+//   tile 128 x 128, 256 threads = 4 waves as 2 (M) x 2 (N), each wave 64 x 64 = 2 x 2 MFMA 32x32 tiles
+//   bf16: v_mfma_f32_32x32x16_bf16, fp32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, parity path)
+//   LDS: double-buffered A and B tiles (4 x 16 KiB), register-staged prefetch of tile k+1 under
+//        the MFMAs of tile k, one barrier per K-step; 16-byte chunk XOR swizzle
+//        chunk' = chunk ^ ((row >> 1) & 7) makes every ds_read_b128 fragment read conflict-free.
+//   A operand = activations (rows m, frame-major), B operand = packed weights [N][K]:
+//        the MFMA C layout then has n on the lane, so bias / BN scale / shift are per-lane scalars.
+//   grid: XCD-aware — each XCD owns a contiguous band of M tiles and walks it in groups of 8 M-tiles
+//        x all N-tiles (m fastest), so concurrently resident workgroups share A and W panels in that
+//        XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+constexpr int BM = GEMM_BM, BN = GEMM_BN;
+constexpr int ROWB = GEMM_BK_BYTES;            // bytes per tile row
+constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB
+constexpr int GROUP_M = 8;
+
+__device__ __forceinline__ int swz(int row, int chunk) {
+    return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<float> {
+    static constexpr int EPC = 4;              // elements per 16-byte chunk
+    static constexpr int BK = 32;
+    typedef f32x4 chunk_t;
+    static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, f32x16& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ chunk_t zero() { return chunk_t{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ chunk_t add(const chunk_t& a, const chunk_t& b) { return a + b; }
+};
+template <> struct MmaTraits<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int BK = 64;
+    typedef bf16x8 chunk_t;
+    static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ chunk_t zero() {
+        chunk_t z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = static_cast<bf16_t>(0.0f);
+        return z;
+    }
+    static __device__ __forceinline__ chunk_t add(const chunk_t& a, const chunk_t& b) {
+        chunk_t r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = static_cast<bf16_t>(static_cast<float>(a[j]) + static_cast<float>(b[j]));
+        return r;
+    }
+};
+
+template <typename T, bool CONV, bool HAS_A2>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    typedef MmaTraits<T> TR;
+    typedef typename TR::chunk_t chunk_t;
+    constexpr int EPC = TR::EPC;
+    constexpr int BK = TR::BK;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
+
+    // ---- XCD-aware tile mapping --------------------------------------------------------------
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nwg = ntm * ntn;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int grp = id / (GROUP_M * ntn);
+    const int within = id - grp * (GROUP_M * ntn);
+    const int gm = min(GROUP_M, ntm - grp * GROUP_M);
+    const int tile_m = grp * GROUP_M + within % gm;
+    const int tile_n = within / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- per-thread staging geometry: 4 A chunks + 4 B chunks per K-step ----------------------
+    const int lc = tid & 7;                  // chunk column 0..7
+    const int lr = tid >> 3;                 // row 0..31 (+32*i)
+    const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ A2p = reinterpret_cast<const T*>(p.A2);
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W);
+
+    int rowA[4];        // clamped global row
+    int uttA[4], tA[4]; // utterance base row and frame index (CONV only)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = min(m0 + lr + 32 * i, p.M - 1);
+        rowA[i] = m;
+        if (CONV) {
+            int b = m / p.T;
+            uttA[i] = b * p.T;
+            tA[i] = m - b * p.T;
+        }
+    }
+    int64_t wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = (int64_t)min(n0 + lr + 32 * i, p.Wrows - 1) * p.Kp;
+
+    chunk_t ra[4], rb[4];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + lc * EPC;
+        const bool kvalid = k < p.K;
+        int tap_off = 0, cc = k;
+        if (CONV) {
+            const int tap = k / p.cin;
+            cc = k - tap * p.cin;
+            tap_off = (tap - (p.taps >> 1)) * p.dil;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            chunk_t v = TR::zero();
+            if (kvalid) {
+                if (CONV) {
+                    int tt = tA[i] + tap_off;
+                    bool ok = true;
+                    if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
+                    else ok = (tt >= 0) && (tt < p.T);
+                    if (ok) {
+                        const int64_t src = (int64_t)(uttA[i] + tt);
+                        v = *reinterpret_cast<const chunk_t*>(Ap + src * p.lda + cc);
+                        if (HAS_A2) v = TR::add(v, *reinterpret_cast<const chunk_t*>(A2p + src * p.lda2 + cc));
+                    }
+                } else {
+                    v = *reinterpret_cast<const chunk_t*>(Ap + (int64_t)rowA[i] * p.lda + k);
+                    if (HAS_A2) v = TR::add(v, *reinterpret_cast<const chunk_t*>(A2p + (int64_t)rowA[i] * p.lda2 + k));
+                }
+            }
+            ra[i] = v;
+            rb[i] = *reinterpret_cast<const chunk_t*>(Wp + wrow[i] + kt * BK + lc * EPC);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* As = smem + buf * (2 * TILE_BYTES);
+        char* Bs = As + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 32 * i;
+            *reinterpret_cast<chunk_t*>(As + swz(r, lc)) = ra[i];
+            *reinterpret_cast<chunk_t*>(Bs + swz(r, lc)) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.Kp / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* As = smem + buf * (2 * TILE_BYTES);
+        const char* Bs = As + TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            chunk_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const chunk_t*>(As + swz(wm * 64 + i * 32 + fr, 2 * s + fh));
+                bfr[i] = *reinterpret_cast<const chunk_t*>(Bs + swz(wn * 64 + i * 32 + fr, 2 * s + fh));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) TR::mma(af[i], bfr[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> act1 -> BN affine -> act2 -> store --------------------------------
+    const bool out_f32 = (sizeof(T) == 4) || p.out_f32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        const bool nok = n < p.N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
+        const float sc = (p.scale && nok) ? p.scale[n] : 1.0f;
+        const float sh = (p.shift && nok) ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (nok && m < p.M) {
+                    float v = acc[i][j][r] + bias;
+                    if (p.bias_utt) v += p.bias_utt[(int64_t)(m / p.T) * p.ld_bu + n];
+                    v = apply_act(v, p.act1);
+                    v = v * sc + sh;
+                    v = apply_act(v, p.act2);
+                    if (out_f32) reinterpret_cast<float*>(p.Y)[(int64_t)m * p.ldy + n] = v;
+                    else reinterpret_cast<bf16_t*>(p.Y)[(int64_t)m * p.ldy + n] = static_cast<bf16_t>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    dim3 grid(ntm * ntn), block(256);
+    const size_t lds = 4 * TILE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {   // 64 KiB of dynamic LDS per workgroup
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const bool conv = p.taps > 1;
+    if (conv) {
+        if (p.A2) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, lds, stream, p);
+    } else {
+        if (p.A2) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, lds, stream, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
+    // host-side shape contract (checked before any launch: a bad shape must not reach the GPU)
+    const int epc = bf16 ? 8 : 4;
+    const int bk = gemm_bk(bf16);
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.Kp % bk != 0 || p.Kp < p.K || p.Wrows < p.N) return hipErrorInvalidValue;
+    if (p.lda % epc != 0 || (p.A2 && p.lda2 % epc != 0)) return hipErrorInvalidValue;
+    if (p.taps > 1) {
+        if (p.cin % epc != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return hipErrorInvalidValue;
+        if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return hipErrorInvalidValue;
+    } else if (p.K % epc != 0) {
+        return hipErrorInvalidValue;
+    }
+    if (p.bias_utt && (p.T <= 0)) return hipErrorInvalidValue;
+    return bf16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
+}
+
+}  // namespace svhip

@@ -1,0 +1,97 @@
+// kernels.h — internal launcher API of libsvhip (host side). All launchers enqueue on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svhip {
+
+// ---------------------------------------------------------------------------------------------
+// Tiled MFMA GEMM with fused conv-gather prologue and bias/activation/BN epilogue.
+//   Y[m, n] = act2( scale[n] * act1( sum_k A'[m, k] * W[n, k] + bias[n] (+ bias_utt[m / T, n]) ) + shift[n] )
+// A' is A (frame-major, row stride lda) or, with taps > 1, the im2col view of a dilated 1-D
+// convolution over the T rows of each utterance: k = tap*cin + c reads row t + (tap - taps/2)*dil
+// (reflect or zero padded).  With A2 != nullptr the operand is A + A2 (Res2Net chain).
+// W is packed [Np][Kp] (K contiguous; zero padded to the tile sizes) in the compute dtype.
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+    const void* A = nullptr;
+    const void* A2 = nullptr;
+    const void* W = nullptr;
+    void* Y = nullptr;
+    const float* bias = nullptr;
+    const float* bias_utt = nullptr;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int M = 0, N = 0, K = 0, Kp = 0;
+    int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
+    int T = 1;
+    int taps = 1, dil = 1, cin = 0, pad_mode = 0;
+    int act1 = 0, act2 = 0;
+    int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
+    int Wrows = 0;            // allocated rows of W (loads clamp to Wrows-1); packed weights: N rounded up to 128
+};
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK_BYTES = 128;   // K-step = 128 bytes per row: 32 fp32 or 64 bf16
+
+inline int gemm_bk(bool bf16) { return bf16 ? 64 : 32; }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Mel front-end
+// ---------------------------------------------------------------------------------------------
+struct FbankTables {           // device pointers, built once per handle
+    const float* basis = nullptr;      // [q][tile][lane] float4: windowed cos/sin taps laid out for MFMA B operands
+    const float* mel_w = nullptr;      // packed non-zero mel weights
+    const int* mel_start = nullptr;    // [n_mels] first bin
+    const int* mel_len = nullptr;      // [n_mels] number of bins
+    const int* mel_off = nullptr;      // [n_mels] offset into mel_w
+    int n_fft = 512, win_length = 200, hop = 80, n_mels = 80, n_bins = 257, lpad = 156;
+    int n_pairs = 9;                   // ceil(n_bins / 32) re/im tile pairs
+    int n_q = 25;                      // win_length / 8
+    float preemph = 0.97f;
+};
+// wav (B, L) fp32 -> mel power (B, n_mels, T) fp32
+hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, int T, float* mel, hipStream_t stream);
+
+// (B, n_mels, T) fp32 features -> frame-major (B, T, n_mels) activations in the compute dtype,
+// with optional log(x+1e-6) - mean_t and optional InstanceNorm1d(affine).
+// `stats` is a (B * n_mels * 2) fp32 scratch buffer.
+hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, int n_mels, int T,
+                           int log_input, const float* in_w, const float* in_b, float* stats, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Frame-major reductions / elementwise (activation dtype templated inside)
+// ---------------------------------------------------------------------------------------------
+// mean over the T rows of each utterance: X (B*T, ldx) cols [0,C) -> mean (B, C) fp32
+hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream);
+// mean and population std over T (two pass, clamp 1e-12 as ECAPA_TDNN.py:222-227): -> stats (B, 2C) = [mean | std]
+hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int C, float* stats, float eps, hipStream_t stream);
+// out[b, n] = act( bias[n] + sum_k W[n, k] * in[b, k] ), all fp32 (small-M linear layers)
+hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
+                                int B, int N, int K, int act, hipStream_t stream);
+// out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
+hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
+                           bool bf16, int B, int T, int C, hipStream_t stream);
+// strided 2-D copy of a column block: dst[m, 0:C) = src[m, 0:C)
+hipError_t launch_copy_cols(const void* src, int lds, void* dst, int ldd, bool bf16, int M, int C, hipStream_t stream);
+// attentive statistics: softmax over T of logits (fp32, ld = C), weighted mean / std of X, then
+// BatchNorm affine over the 2C pooled values -> pooled (B, 2C) fp32   (ECAPA_TDNN.py:252-259,496)
+hipError_t launch_asp_pool(const float* logits, const void* X, bool bf16, int ldx, int B, int T, int C,
+                           const float* bn_scale, const float* bn_shift, float* pooled_raw, float* pooled_bn,
+                           float eps, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Scoring
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_l2norm(float* E, int64_t N, int D, hipStream_t stream);
+hipError_t launch_score_pairs(const float* E, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out, hipStream_t stream);
+hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const float* sigma, const int32_t* ia,
+                               const int32_t* ib, int64_t P, float* out, hipStream_t stream);
+// S (rows x K) fp32 cohort scores -> mean / population std of the `top` largest per row
+hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int top, float* mu, float* sigma, hipStream_t stream);
+
+}  // namespace svhip

@@ -1,0 +1,257 @@
+"""Engine — thin Python owner of one svhip handle (one HIP device, one stream, one model).
+
+Host-side plumbing only: every array that crosses into the library is passed as a raw pointer
+(numpy -> host pointer, torch CUDA tensor -> device pointer).  No computation happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is plumbing (device memory / streams / torch.distributed); numpy-only use works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class _Buf:
+    """Pointer view of a numpy array (host) or a torch tensor (host or device)."""
+
+    def __init__(self, x, dtype, writable=False):
+        self.keep = x
+        if _is_torch(x):
+            tdt = {np.float32: torch.float32, np.int32: torch.int32}[dtype]
+            if x.dtype != tdt or not x.is_contiguous():
+                if writable:
+                    raise ValueError("output tensors must be contiguous and of the right dtype")
+                x = x.to(tdt).contiguous()
+                self.keep = x
+            self.device = x.is_cuda
+            self.ptr = x.data_ptr()
+        else:
+            a = np.asarray(x)
+            if a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+                if writable:
+                    raise ValueError("output arrays must be C-contiguous and of the right dtype")
+                a = np.ascontiguousarray(a, dtype=dtype)
+            self.keep = a
+            self.device = False
+            self.ptr = a.ctypes.data
+
+
+class Engine:
+    def __init__(self, model="ecapa", compute="f32", channels=1024, n_mels=80, embed_dim=192, max_batch=8,
+                 samples=32000, log_input=True, input_norm=False, device=0, stream=None,
+                 sr=8000, n_fft=512, win_length=200, hop_length=80, fmin=0.0, fmax=None, pre_emphasis=True):
+        self.lib = _lib.load()
+        cfg = _lib.default_config()
+        cfg.model = {"ecapa": _lib.MODEL_ECAPA, "rawnet2": _lib.MODEL_RAWNET2, "none": _lib.MODEL_NONE}[model]
+        cfg.compute = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16}[compute]
+        cfg.device = int(device)
+        cfg.channels = int(channels)
+        cfg.n_mels = int(n_mels)
+        cfg.embed_dim = int(embed_dim)
+        cfg.max_batch = int(max_batch)
+        cfg.samples = int(samples)
+        cfg.log_input = int(bool(log_input))
+        cfg.input_norm = int(bool(input_norm))
+        cfg.fb_sr, cfg.n_fft, cfg.win_length, cfg.hop_length = int(sr), int(n_fft), int(win_length), int(hop_length)
+        cfg.fmin = float(fmin)
+        cfg.fmax = -1.0 if fmax is None else float(fmax)
+        cfg.preemph = 0.97 if pre_emphasis is True else (-1.0 if pre_emphasis in (False, None) else float(pre_emphasis))
+        cfg.stream = C.c_void_p(int(stream)) if stream else None
+        self.cfg = cfg
+        self.model = model
+        self.compute = "bf16" if cfg.compute == _lib.BF16 else "f32"
+        self.max_batch = cfg.max_batch
+        self.samples = cfg.samples
+        self.frames = cfg.samples // cfg.hop_length + 1
+        self.n_mels = cfg.n_mels
+        self.embed_dim = cfg.embed_dim
+        self.device = cfg.device
+        h = C.c_void_p()
+        rc = self.lib.svhip_create(C.byref(cfg), C.byref(h))
+        if rc != _lib.OK:
+            msg = self.lib.svhip_last_error(None)
+            raise _lib.SvhipError(rc, msg.decode() if msg else "?")
+        self.h = h
+
+    # ---- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(self.h, rc)
+
+    def synchronize(self):
+        self._ck(self.lib.svhip_synchronize(self.h))
+
+    # ---- weights ---------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, object], strict=True, show_error=False):
+        """Name-matched copy of a reference ``__S__`` state dict (src/model.py:718-746 semantics:
+        with strict=False unknown / mis-shaped tensors are skipped, optionally printed)."""
+        skipped = []
+        for name, v in sd.items():
+            if _is_torch(v):
+                v = v.detach().cpu().numpy()
+            a = np.asarray(v)
+            shp = a.shape                       # (ascontiguousarray would promote 0-d to 1-d)
+            if a.dtype == np.int64:
+                dt = _lib.I64
+                a = np.ascontiguousarray(a)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                dt = _lib.F32
+            shape = (C.c_int64 * max(1, len(shp)))(*shp)
+            rc = self.lib.svhip_load_tensor(self.h, name.encode(), a.ctypes.data, shape, len(shp), dt)
+            if rc != _lib.OK:
+                if strict:
+                    self._ck(rc)
+                msg = self.lib.svhip_last_error(self.h).decode()
+                skipped.append(name)
+                if show_error:
+                    print(msg)
+        return skipped
+
+    def finalize(self):
+        self._ck(self.lib.svhip_finalize_weights(self.h))
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def _out(self, like, shape):
+        if _is_torch(like) and like.is_cuda:
+            return torch.empty(shape, dtype=torch.float32, device=like.device)
+        return np.empty(shape, dtype=np.float32)
+
+    @staticmethod
+    def _flags(i: _Buf, o: _Buf, async_=False):
+        f = (_lib.IN_DEVICE if i.device else 0) | (_lib.OUT_DEVICE if o.device else 0)
+        if async_:
+            f |= _lib.ASYNC
+        return f
+
+    def fbank(self, wav, out=None, async_=False):
+        """(B, L) fp32 waveforms -> (B, n_mels, T) mel power (numpy in -> numpy out, CUDA tensor in -> CUDA tensor out)."""
+        B, L = wav.shape
+        if out is None:
+            out = self._out(wav, (B, self.n_mels, self.frames))
+        i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
+        self._ck(self.lib.svhip_fbank(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
+        return out
+
+    def embed_features(self, feat, out=None, async_=False):
+        B, nm, T = feat.shape
+        if nm != self.n_mels:
+            raise ValueError(f"expected {self.n_mels} feature channels, got {nm}")
+        if out is None:
+            out = self._out(feat, (B, self.embed_dim))
+        i, o = _Buf(feat, np.float32), _Buf(out, np.float32, writable=True)
+        self._ck(self.lib.svhip_embed_features(self.h, i.ptr, B, T, o.ptr, self._flags(i, o, async_)))
+        return out
+
+    def embed_wave(self, wav, out=None, async_=False):
+        B, L = wav.shape
+        if out is None:
+            out = self._out(wav, (B, self.embed_dim))
+        i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
+        self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
+        return out
+
+    # ---- scoring ---------------------------------------------------------------------------------------------
+    def l2norm_(self, E):
+        N, D = E.shape
+        b = _Buf(E, np.float32, writable=True)
+        self._ck(self.lib.svhip_l2norm(self.h, b.ptr, N, D, _lib.IN_DEVICE | _lib.OUT_DEVICE if b.device else 0))
+        return E
+
+    def _same_space(self, *bufs):
+        dev = {b.device for b in bufs}
+        if len(dev) != 1:
+            raise ValueError("all arrays of one scoring call must live in the same memory space")
+        return dev.pop()
+
+    def score_pairs(self, E, ia, ib, out=None):
+        N, D = E.shape
+        P = int(ia.shape[0])
+        if out is None:
+            out = self._out(E, (P,))
+        e, a, b, o = _Buf(E, np.float32), _Buf(ia, np.int32), _Buf(ib, np.int32), _Buf(out, np.float32, writable=True)
+        dev = self._same_space(e, a, b, o)
+        self._ck(self.lib.svhip_score_pairs(self.h, e.ptr, N, D, a.ptr, b.ptr, P, o.ptr,
+                                            (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        return out
+
+    def score_matrix(self, A, B, out=None):
+        Na, D = A.shape
+        Nb = B.shape[0]
+        if out is None:
+            out = self._out(A, (Na, Nb))
+        a, b, o = _Buf(A, np.float32), _Buf(B, np.float32), _Buf(out, np.float32, writable=True)
+        dev = self._same_space(a, b, o)
+        self._ck(self.lib.svhip_score_matrix(self.h, a.ptr, Na, b.ptr, Nb, D, o.ptr,
+                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        return out
+
+    def asnorm_stats(self, E, cohort, top=200):
+        N, D = E.shape
+        K = cohort.shape[0]
+        mu, sd = self._out(E, (N,)), self._out(E, (N,))
+        e, c, m, s = _Buf(E, np.float32), _Buf(cohort, np.float32), _Buf(mu, np.float32, True), _Buf(sd, np.float32, True)
+        dev = self._same_space(e, c, m, s)
+        self._ck(self.lib.svhip_asnorm_stats(self.h, e.ptr, N, D, c.ptr, K, int(top), m.ptr, s.ptr,
+                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        return mu, sd
+
+    def asnorm_pairs(self, E, mu, sigma, ia, ib, out=None):
+        N, D = E.shape
+        P = int(ia.shape[0])
+        if out is None:
+            out = self._out(E, (P,))
+        e, m, s = _Buf(E, np.float32), _Buf(mu, np.float32), _Buf(sigma, np.float32)
+        a, b, o = _Buf(ia, np.int32), _Buf(ib, np.int32), _Buf(out, np.float32, writable=True)
+        dev = self._same_space(e, m, s, a, b, o)
+        self._ck(self.lib.svhip_asnorm_pairs(self.h, e.ptr, N, D, m.ptr, s.ptr, a.ptr, b.ptr, P, o.ptr,
+                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        return out
+
+    # ---- introspection ------------------------------------------------------------------------------------------
+    def get_stage(self, name: str) -> np.ndarray:
+        n = C.c_int64()
+        self._ck(self.lib.svhip_get_stage(self.h, name.encode(), None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._ck(self.lib.svhip_get_stage(self.h, name.encode(), out.ctypes.data, C.byref(n)))
+        return out
+
+    def profile(self, on=True):
+        self._ck(self.lib.svhip_profile_enable(self.h, int(on)))
+        if on:
+            self._ck(self.lib.svhip_profile_reset(self.h))
+
+    def profile_results(self):
+        res = {}
+        idx = 0
+        name = C.create_string_buffer(64)
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        while self.lib.svhip_profile_get(self.h, idx, name, 64, C.byref(ms), C.byref(n), C.byref(fl)) == _lib.OK:
+            res[name.value.decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
+            idx += 1
+        return res
+
+    @property
+    def flops_per_utterance(self) -> float:
+        return float(self.lib.svhip_workload_flops(self.h))

@@ -1,0 +1,103 @@
+"""GPU parity: ECAPA-TDNN forward through the C ABI vs the oracle / golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as o_ecapa
+from speakerverification_amd import synth
+from speakerverification_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ["blocks.0", "blocks.1", "blocks.2", "blocks.3", "mfa", "asp", "asp_bn"]
+
+
+def make_engine(C, T, B, compute, seed_w):
+    eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80 if T != 401 else 32000)
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=seed_w)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    return eng, sd
+
+
+def stage_cf(eng, name, B, T):
+    """library stages are frame-major (B, T, C); the reference's are (B, C, T)."""
+    a = eng.get_stage(name)
+    if name in ("asp", "asp_bn"):
+        return a.reshape(B, -1, 1)
+    return a.reshape(B, T, -1).transpose(0, 2, 1)
+
+
+def test_ecapa_c64_stages_fp32(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ecapa_C64_T50.npz"))
+    C, T, B = int(g["C"]), int(g["T"]), int(g["B"])
+    eng, _ = make_engine(C, T, B, "f32", int(g["seed_w"]))
+    mel = synth.synth_mel(B, 80, T, seed=int(g["seed_x"]))
+    out = eng.embed_features(mel)
+    for n in STAGES:
+        ref = g["st_" + n]
+        got = stage_cf(eng, n, B, T)
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        assert got.shape == ref.shape, n
+        assert float(np.abs(got - ref).max()) <= tol, (n, float(np.abs(got - ref).max()), tol)
+    ref = g["out"]
+    assert float(np.abs(out - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("C", [512, 1024])
+def test_ecapa_full_fp32_matches_reference(golden_dir, C):
+    g = np.load(os.path.join(golden_dir, f"ecapa_C{C}_T401.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    eng, _ = make_engine(C, T, B, "f32", int(g["seed_w"]))
+    mel = synth.synth_mel(B, 80, T, seed=int(g["seed_x"]))
+    out = eng.embed_features(mel)
+    ref = g["out"]
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(out - ref).max())
+    # tolerance: 1e-4 of the embedding scale (north_star: within 1e-4 fp32; embeddings here are O(100))
+    assert err <= 1e-4 * max(1.0, scale), (err, scale)
+    # stage checksums captured from the reference
+    for n in STAGES:
+        cs = g["cs_" + n]
+        got = stage_cf(eng, n, B, T).astype(np.float64)
+        assert abs(got.sum() - cs[0]) <= 2e-5 * cs[1] + 1e-3, n
+        assert abs(np.abs(got).sum() - cs[1]) <= 2e-5 * cs[1] + 1e-3, n
+
+
+def test_ecapa_bf16_close_to_fp32_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ecapa_C1024_T401.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    eng, _ = make_engine(1024, T, B, "bf16", int(g["seed_w"]))
+    mel = synth.synth_mel(B, 80, T, seed=int(g["seed_x"]))
+    out = eng.embed_features(mel)
+    ref = g["out"]
+    # bf16 activations/weights with fp32 accumulation: stated tolerance 3e-2 of the embedding scale,
+    # cosine to the fp32 reference embedding >= 0.999 (the reference's own bf16 autocast differs from
+    # its fp32 output by ~4e-3 relative)
+    rel = float(np.abs(out - ref).max()) / float(np.abs(ref).max())
+    cos = np.sum(out * ref, axis=1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+    print("bf16 rel err", rel, "cos", cos)
+    assert rel <= 3e-2
+    assert float(cos.min()) >= 0.999
+
+
+def test_batch_invariance_and_chunking():
+    """Embedding of an utterance must not depend on which batch it travels in."""
+    C, T = 512, 401
+    eng, _ = make_engine(C, T, 16, "f32", 1)
+    mel = synth.synth_mel(16, 80, T, seed=5)
+    full = eng.embed_features(mel)
+    part = np.concatenate([eng.embed_features(mel[:5]), eng.embed_features(mel[5:16])])
+    assert float(np.abs(full - part).max()) <= 1e-5 * float(np.abs(full).max())
+
+
+def test_device_pointers_roundtrip():
+    C, T = 512, 401
+    eng, _ = make_engine(C, T, 4, "f32", 1)
+    mel = synth.synth_mel(4, 80, T, seed=6)
+    host = eng.embed_features(mel)
+    dev = eng.embed_features(torch.from_numpy(mel).cuda())
+    assert dev.is_cuda
+    assert np.array_equal(dev.cpu().numpy(), host)
