@@ -82,6 +82,12 @@ def load():
         raise SvhipUnavailable(
             f"{LIB_PATH} is missing: build it with `python -m speakerverification_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback for the product path.")
+    # torch (plumbing: device memory, streams, torch.distributed) bundles its own HIP runtime; when it is
+    # installed it must be the one runtime of the process, so load it before libsvhip resolves libamdhip64.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - numpy-only use
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

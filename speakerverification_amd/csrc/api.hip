@@ -42,6 +42,7 @@ struct LinearLayer {          // small-M fp32 linear (rowvec kernel)
 };
 
 struct ProfEntry { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
+struct PendingEvent { hipEvent_t e0, e1; int entry; };
 
 }  // namespace
 
@@ -83,9 +84,11 @@ struct svhip_handle {
     float *d_pool_raw = nullptr, *d_pool_bn = nullptr, *d_emb = nullptr;
     int lastB = 0;
 
-    // profiling
+    // profiling: event pairs are recorded around every launch without blocking the host and
+    // resolved (hipEventElapsedTime) when results are read
     bool prof = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<PendingEvent> ev_pending;
     std::vector<ProfEntry> prof_entries;
     double flops_per_utt = 0;
 };
@@ -135,23 +138,44 @@ inline uint16_t f32_to_bf16_rne(float f) {
 }
 
 // ---- profiling-aware launch wrapper --------------------------------------------------------------
+hipEvent_t prof_event(svhip_handle* h) {
+    if (!h->ev_free.empty()) { hipEvent_t e = h->ev_free.back(); h->ev_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_collect(svhip_handle* h) {
+    if (h->ev_pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& pe : h->ev_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) h->prof_entries[pe.entry].ms += ms;
+        h->ev_free.push_back(pe.e0);
+        h->ev_free.push_back(pe.e1);
+    }
+    h->ev_pending.clear();
+}
+
 template <typename F>
 int run(svhip_handle* h, const char* label, double flops, F&& launch) {
-    if (h->prof) hipEventRecord(h->ev0, h->stream);
+    PendingEvent pe{nullptr, nullptr, -1};
+    if (h->prof) {
+        for (size_t i = 0; i < h->prof_entries.size(); ++i)
+            if (h->prof_entries[i].name == label) { pe.entry = (int)i; break; }
+        if (pe.entry < 0) { h->prof_entries.push_back(ProfEntry{label}); pe.entry = (int)h->prof_entries.size() - 1; }
+        pe.e0 = prof_event(h);
+        pe.e1 = prof_event(h);
+        (void)hipEventRecord(pe.e0, h->stream);
+    }
     hipError_t e = launch();
     if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "launch %s failed: %s", label, hipGetErrorString(e));
     if (h->prof) {
-        hipEventRecord(h->ev1, h->stream);
-        hipEventSynchronize(h->ev1);
-        float ms = 0;
-        hipEventElapsedTime(&ms, h->ev0, h->ev1);
-        ProfEntry* pe = nullptr;
-        for (auto& x : h->prof_entries)
-            if (x.name == label) { pe = &x; break; }
-        if (!pe) { h->prof_entries.push_back(ProfEntry{label}); pe = &h->prof_entries.back(); }
-        pe->ms += ms;
-        pe->launches += 1;
-        pe->flops += flops;
+        (void)hipEventRecord(pe.e1, h->stream);
+        h->prof_entries[pe.entry].launches += 1;
+        h->prof_entries[pe.entry].flops += flops;
+        h->ev_pending.push_back(pe);
+        if (h->ev_pending.size() >= 8192) prof_collect(h);
     }
     return SVHIP_OK;
 }
@@ -442,7 +466,10 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
     const bool bf = h->bf16;
     hipStream_t st = h->stream;
-    return run(h, label, (double)M * L.flops_per_row, [&]() { return launch_gemm(p, bf, st); });
+    (void)label;
+    // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
+    const char* klabel = L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : "gemm_pointwise";
+    return run(h, klabel, (double)M * L.flops_per_row, [&]() { return launch_gemm(p, bf, st); });
 }
 
 inline void* off(void* base, size_t elems, int esz) { return reinterpret_cast<char*>(base) + elems * esz; }
@@ -564,8 +591,6 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete h; return SVHIP_ERR_HIP; }
         h->own_stream = true;
     }
-    hipEventCreate(&h->ev0);
-    hipEventCreate(&h->ev1);
     int rc = build_fbank_tables(h);
     if (rc == SVHIP_OK) rc = alloc_workspace(h);
     if (rc != SVHIP_OK) { g_create_error = h->err; svhip_destroy(h); return rc; }
@@ -576,12 +601,12 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
 
 int svhip_destroy(svhip_handle* h) {
     if (!h) return SVHIP_OK;
-    hipSetDevice(h->cfg.device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (void* p : h->allocs) hipFree(p);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    prof_collect(h);
+    for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SVHIP_OK;
 }
@@ -698,7 +723,7 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
 namespace {
 struct TempBuf {      // device staging for host-pointer calls
     svhip_handle* h; void* d = nullptr;
-    ~TempBuf() { if (d) hipFree(d); }
+    ~TempBuf() { if (d) (void)hipFree(d); }
     int in(const void* src, size_t bytes, bool is_dev, const void** out) {
         if (is_dev) { *out = src; return SVHIP_OK; }
         SV_HIP(h, hipMalloc(&d, bytes ? bytes : 16));
@@ -827,8 +852,8 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
         if (rc) break;
     }
-    hipStreamSynchronize(h->stream);
-    hipFree(slab);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(slab);
     if (rc) return rc;
     if (!dout) {
         SV_HIP(h, hipMemcpy(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -870,9 +895,11 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
 }
 
 int svhip_profile_enable(svhip_handle* h, int32_t on) { if (!h) return SVHIP_ERR_INVALID; h->prof = on != 0; return SVHIP_OK; }
-int svhip_profile_reset(svhip_handle* h) { if (!h) return SVHIP_ERR_INVALID; h->prof_entries.clear(); return SVHIP_OK; }
+int svhip_profile_reset(svhip_handle* h) { if (!h) return SVHIP_ERR_INVALID; prof_collect(h); h->prof_entries.clear(); return SVHIP_OK; }
 int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops) {
-    if (!h || idx < 0 || idx >= (int32_t)h->prof_entries.size()) return SVHIP_ERR_INVALID;
+    if (!h) return SVHIP_ERR_INVALID;
+    prof_collect(h);
+    if (idx < 0 || idx >= (int32_t)h->prof_entries.size()) return SVHIP_ERR_INVALID;
     const ProfEntry& p = h->prof_entries[idx];
     if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
     if (ms) *ms = p.ms;

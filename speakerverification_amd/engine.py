@@ -83,6 +83,20 @@ class Engine:
             msg = self.lib.svhip_last_error(None)
             raise _lib.SvhipError(rc, msg.decode() if msg else "?")
         self.h = h
+        self._stream = int(stream) if stream else None
+
+    def _order_after_torch(self, *bufs, async_=False):
+        """Device tensors handed in by torch may still be in flight on torch's current stream.  When the
+        handle runs on that same stream the order is already right; otherwise wait for torch's stream
+        on the host before the library touches the data (and refuse async calls, which would race)."""
+        if torch is None or not any(b.device for b in bufs):
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if self._stream is not None and cur.cuda_stream == self._stream:
+            return
+        if async_:
+            raise ValueError("async_ calls need the Engine to be created on torch's current stream")
+        cur.synchronize()
 
     # ---- lifetime ------------------------------------------------------------------------------------
     def close(self):
@@ -151,6 +165,7 @@ class Engine:
         if out is None:
             out = self._out(wav, (B, self.n_mels, self.frames))
         i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
+        self._order_after_torch(i, o, async_=async_)
         self._ck(self.lib.svhip_fbank(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
@@ -161,6 +176,7 @@ class Engine:
         if out is None:
             out = self._out(feat, (B, self.embed_dim))
         i, o = _Buf(feat, np.float32), _Buf(out, np.float32, writable=True)
+        self._order_after_torch(i, o, async_=async_)
         self._ck(self.lib.svhip_embed_features(self.h, i.ptr, B, T, o.ptr, self._flags(i, o, async_)))
         return out
 
@@ -169,6 +185,7 @@ class Engine:
         if out is None:
             out = self._out(wav, (B, self.embed_dim))
         i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
+        self._order_after_torch(i, o, async_=async_)
         self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
@@ -176,6 +193,7 @@ class Engine:
     def l2norm_(self, E):
         N, D = E.shape
         b = _Buf(E, np.float32, writable=True)
+        self._order_after_torch(b)
         self._ck(self.lib.svhip_l2norm(self.h, b.ptr, N, D, _lib.IN_DEVICE | _lib.OUT_DEVICE if b.device else 0))
         return E
 
@@ -183,6 +201,7 @@ class Engine:
         dev = {b.device for b in bufs}
         if len(dev) != 1:
             raise ValueError("all arrays of one scoring call must live in the same memory space")
+        self._order_after_torch(*bufs)
         return dev.pop()
 
     def score_pairs(self, E, ia, ib, out=None):

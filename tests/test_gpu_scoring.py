@@ -1,0 +1,109 @@
+"""GPU parity: scoring kernels through the C ABI vs reference-pinned golden values and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring as o_scoring
+from speakerverification_amd import synth
+from speakerverification_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return Engine(model="none", max_batch=1)
+
+
+def test_l2norm_and_cosine_pairs(eng):
+    rng = np.random.Generator(np.random.PCG64(9))
+    E = rng.standard_normal((1000, 192)).astype(np.float32) * 3.0
+    E[7] = 0.0                                        # zero row: eps clamps, no NaN
+    ia = rng.integers(0, 1000, 5000).astype(np.int32)
+    ib = rng.integers(0, 1000, 5000).astype(np.int32)
+    got = eng.score_pairs(E, ia, ib)
+    want = o_scoring.cosine_pairs(E, ia, ib)
+    assert np.all(np.isfinite(got))
+    assert float(np.abs(got - want).max()) <= 1e-5
+    En = E.copy()
+    eng.l2norm_(En)
+    ref = torch.nn.functional.normalize(torch.from_numpy(E), p=2, dim=1).numpy()
+    assert float(np.abs(En - ref).max()) <= 1e-6
+    # empty pair list
+    assert eng.score_pairs(E, ia[:0], ib[:0]).shape == (0,)
+
+
+def test_golden_cosine_one_crop(eng, golden_dir):
+    """reference utils.cosine_similarity on single-crop inputs == |cos| of the pair kernel."""
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    R, Cm = g["R"][:, 0, :], g["C"][:, 0, :]
+    E = np.concatenate([R, Cm]).astype(np.float32)
+    n = R.shape[0]
+    ia, ib = np.arange(n, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32)
+    got = eng.score_pairs(E, ia, ib)
+    want = np.array([o_scoring.cosine_similarity(torch.from_numpy(R[i:i + 1]), torch.from_numpy(Cm[i:i + 1])) for i in range(n)])
+    assert float(np.abs(got - want).max()) <= 1e-5
+
+
+def test_golden_asnorm(eng, golden_dir):
+    """reference utils.ZT_norm_similarity (multi-crop) == GEMM form on crop means."""
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    top = int(g["top"])
+    cohort = g["cohort"]
+    Rn = torch.nn.functional.normalize(torch.from_numpy(g["R"]), p=2, dim=2).numpy()
+    Cn = torch.nn.functional.normalize(torch.from_numpy(g["C"]), p=2, dim=2).numpy()
+    n = Rn.shape[0]
+    E = np.concatenate([Rn.mean(axis=1), Cn.mean(axis=1)]).astype(np.float32)     # crop means
+    ia, ib = np.arange(n, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32)
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    got = eng.asnorm_pairs(E, mu, sd, ia, ib)
+    assert float(np.abs(got - g["zt_norm"]).max()) <= 1e-4, np.abs(got - g["zt_norm"]).max()
+    # default top=-1 of the reference (drops the smallest cohort score)
+    mu, sd = eng.asnorm_stats(E, cohort, -1)
+    got = eng.asnorm_pairs(E, mu, sd, ia, ib)
+    assert float(np.abs(got - g["zt_norm_default_top"]).max()) <= 1e-4
+
+
+@pytest.mark.parametrize("K,top", [(5994, 200), (257, 200), (64, 64), (1000, 1)])
+def test_asnorm_stats_vs_oracle(eng, K, top):
+    E = synth.synth_embeddings(300, seed=21)
+    cohort = synth.synth_embeddings(K, seed=22)
+    cohort[3] = cohort[5]                              # ties in the cohort scores
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    rmu, rsd = o_scoring.asnorm_stats(E, cohort, top)
+    assert float(np.abs(mu - rmu).max()) <= 1e-6
+    if top > 1:
+        assert float(np.abs(sd - rsd).max() / rsd.min()) <= 1e-4
+    else:
+        assert float(np.abs(sd).max()) <= 1e-6
+
+
+def test_score_matrix(eng):
+    A = synth.synth_embeddings(300, seed=31)
+    B = synth.synth_embeddings(517, seed=32)
+    got = eng.score_matrix(A, B)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    assert got.shape == (300, 517)
+    assert float(np.abs(got - want).max()) <= 1e-6
+
+
+def test_large_pair_list_properties():
+    """full-size (BASELINE config 4 scale) invariants: symmetry, self-pairs == 1, device pointers."""
+    eng = Engine(model="none", max_batch=1)
+    dev = torch.device("cuda", 0)
+    N = 1_200_000
+    g = torch.Generator(device=dev).manual_seed(2)
+    E = torch.randn((N, 192), generator=g, device=dev)
+    eng.l2norm_(E)
+    ia = torch.arange(N, device=dev, dtype=torch.int32)
+    ib = torch.randperm(N, generator=g, device=dev).to(torch.int32)
+    ab = eng.score_pairs(E, ia, ib)
+    ba = eng.score_pairs(E, ib, ia)
+    aa = eng.score_pairs(E, ia, ia)
+    assert torch.equal(ab, ba)
+    assert float((aa - 1).abs().max()) <= 1e-6
+    ref = (E[ia.long()[:4096]] * E[ib.long()[:4096]]).sum(1).abs()
+    assert float((ab[:4096] - ref).abs().max()) <= 1e-6
+    eng.close()

@@ -1,0 +1,154 @@
+"""CPU: the oracle restatement vs fixtures captured from the imported reference (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as o_ecapa
+from oracle import fbank as o_fbank
+from oracle import rawnet2 as o_rawnet2
+from oracle import scoring as o_scoring
+from speakerverification_amd import synth
+
+STAGES = ["blocks.0", "blocks.1", "blocks.2", "blocks.3", "mfa", "asp", "asp_bn"]
+
+
+def checksum(t):
+    t = t.detach().double()
+    return np.array([float(t.sum()), float(t.abs().sum())] + [float(v) for v in t.flatten()[:8]])
+
+
+def test_param_specs_match_reference_state_dicts(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "param_specs.json")))
+    for key, C in (("ecapa_C64", 64), ("ecapa_C512", 512), ("ecapa_C1024", 1024)):
+        mine = [[n, list(s)] for n, s in synth.ecapa_param_spec(C=C)]
+        assert mine == ref[key]
+        assert len(mine) == 231
+    mine = [[n, list(s)] for n, s in synth.rawnet2_param_spec(nOut=320)]
+    assert mine == ref["rawnet2"]
+    assert len(mine) == 147
+
+
+def test_synth_weights_are_deterministic():
+    a = synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=3)
+    b = synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert abs(float(a["blocks.0.conv.conv.weight"].std()) - (2.0 / 400) ** 0.5) < 0.01
+
+
+def test_ecapa_c64_full_stages(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ecapa_C64_T50.npz"))
+    sd = o_ecapa.to_torch_sd(synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=int(g["seed_w"])))
+    mel = torch.from_numpy(synth.synth_mel(int(g["B"]), 80, int(g["T"]), seed=int(g["seed_x"])))
+    st = {}
+    with torch.no_grad():
+        out = o_ecapa.ecapa_forward(mel, sd, stages=st)
+    for n in STAGES:
+        assert float((st[n] - torch.from_numpy(g["st_" + n])).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["st_" + n]).max())), n
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5 * float(np.abs(g["out"]).max())
+
+
+@pytest.mark.parametrize("C", [512, 1024])
+def test_ecapa_full_size(golden_dir, C):
+    g = np.load(os.path.join(golden_dir, f"ecapa_C{C}_T401.npz"))
+    sd = o_ecapa.to_torch_sd(synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=int(g["seed_w"])))
+    mel = torch.from_numpy(synth.synth_mel(int(g["B"]), 80, int(g["T"]), seed=int(g["seed_x"])))
+    st = {}
+    with torch.no_grad():
+        out = o_ecapa.ecapa_forward(mel, sd, stages=st)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5 * float(np.abs(g["out"]).max())
+    for n in STAGES:
+        cs, ref = checksum(st[n]), g["cs_" + n]
+        assert abs(cs[0] - ref[0]) <= 1e-6 * ref[1] + 1e-4, n
+        assert np.allclose(cs[2:], ref[2:], rtol=1e-4, atol=1e-5), n
+
+
+def test_ecapa_batch1_squeeze():
+    """ECAPA_TDNN.py:500: squeeze() turns a batch of one into a (nOut,) vector."""
+    sd = o_ecapa.to_torch_sd(synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=3))
+    with torch.no_grad():
+        out = o_ecapa.ecapa_forward(torch.from_numpy(synth.synth_mel(1, 80, 50)), sd)
+    assert out.shape == (192,)
+
+
+def test_rawnet2(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
+    sd = o_ecapa.to_torch_sd(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=int(g["seed_w"])))
+    x = torch.from_numpy(synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"])))
+    st = {}
+    with torch.no_grad():
+        out = o_rawnet2.rawnet2_forward(x, sd, stages=st)
+    assert out.shape == (2, 320)
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 1e-5 * float(np.abs(g["out"]).max())
+    assert float((st["sinc_filters"][[0, 1, 63, 127]] - torch.from_numpy(g["sinc_filters_rows"])).abs().max()) <= 1e-6
+    shapes = {"front": 10583, "layer1": 3527, "layer2": 1175, "layer3": 391, "layer4": 130, "layer5": 43, "layer6": 14}
+    for n, t in shapes.items():
+        assert st[n].shape[-1] == t, n          # SURVEY §2.3 R2-R3 time axis
+    for n in ("layer1", "layer6"):
+        cs, ref = checksum(st[n]), g["cs_" + n]
+        assert abs(cs[0] - ref[0]) <= 1e-5 * ref[1] + 1e-3
+
+
+def test_preemphasis(golden_dir):
+    g = np.load(os.path.join(golden_dir, "preemphasis.npz"))
+    assert np.array_equal(o_fbank.pre_emphasis(torch.from_numpy(g["a"])).numpy(), g["ya"])
+    assert np.allclose(g["ya"], [[-0.97, 1.0, 1.03, 1.06, 1.09, 1.12]])
+    assert np.array_equal(o_fbank.pre_emphasis(torch.from_numpy(g["b"])).numpy(), g["yb"])
+
+
+def test_scoring(golden_dir):
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    top = int(g["top"])
+    for i in range(g["R"].shape[0]):
+        r = torch.nn.functional.normalize(torch.from_numpy(g["R"][i]), p=2, dim=1)
+        c = torch.nn.functional.normalize(torch.from_numpy(g["C"][i]), p=2, dim=1)
+        assert abs(o_scoring.cosine_similarity(r, c) - g["cosine"][i]) < 1e-6
+        assert abs(o_scoring.cosine_similarity(torch.from_numpy(g["R"][i]), torch.from_numpy(g["C"][i])) - g["cosine_raw"][i]) < 1e-6
+        assert abs(o_scoring.zt_norm_similarity(r.numpy(), c.numpy(), g["cohort"], top) - g["zt_norm"][i]) < 1e-5
+        assert abs(o_scoring.zt_norm_similarity(r.numpy(), c.numpy(), g["cohort"]) - g["zt_norm_default_top"][i]) < 1e-5
+        assert abs(o_scoring.pnorm_similarity(r, c) - g["pnorm"][i]) < 1e-6
+    # batched GEMM statement on crop means == the reference's per-trial loop
+    Rn = torch.nn.functional.normalize(torch.from_numpy(g["R"]), p=2, dim=2).numpy()
+    Cn = torch.nn.functional.normalize(torch.from_numpy(g["C"]), p=2, dim=2).numpy()
+    n = Rn.shape[0]
+    E = np.concatenate([Rn.mean(axis=1), Cn.mean(axis=1)])
+    got = o_scoring.asnorm_pairs(E, np.arange(n), np.arange(n, 2 * n), g["cohort"], top)
+    assert np.abs(got - g["zt_norm"]).max() < 1e-5
+
+
+def test_crop(golden_dir):
+    g = np.load(os.path.join(golden_dir, "crop.npz"))
+    rng = np.random.Generator(np.random.PCG64(77))
+    for name in ("long", "short", "exact", "long10"):
+        n, ne = int(g[name + "_len"]), int(g[name + "_num_eval"])
+        a = (0.3 * rng.standard_normal(n)).astype(np.float32)
+        got = o_scoring.crop_eval(a, 32000, ne)
+        assert got.shape == (ne, 32000)
+        assert np.array_equal(got[:, :4], g[name + "_first"]) and np.array_equal(got[:, -4:], g[name + "_last"])
+        assert abs(float(got.astype(np.float64).sum()) - g[name + "_cs"][0]) < 1e-6 * g[name + "_cs"][1] + 1e-9
+
+
+def test_fbank_restatement_is_self_consistent():
+    """F2-F3 are parity-unpinned (nnAudio absent): check the restatement against an independent
+    float64 rFFT statement of the same definition, and its fp32 arithmetic against fp64."""
+    wav = synth.synth_waveforms(2)
+    r32 = o_fbank.melspectrogram(torch.from_numpy(wav)).numpy()
+    r64 = o_fbank.melspectrogram(torch.from_numpy(wav).double()).numpy()
+    assert r32.shape == (2, 80, 401)
+    y = o_fbank.pre_emphasis(torch.from_numpy(wav).double()).numpy()
+    w, lpad = o_fbank.window_taps()
+    assert lpad == 156 and np.count_nonzero(w) == 200
+    mb = o_fbank.mel_basis().astype(np.float64)
+    assert mb.shape == (80, 257) and int((mb > 0).sum(axis=1).max()) <= 17
+    for b in range(2):
+        yp = np.pad(y[b], (256, 256), mode="reflect")
+        frames = np.stack([yp[i * 80:i * 80 + 512] * w.astype(np.float64) for i in range(401)])
+        mel = mb @ (np.abs(np.fft.rfft(frames, axis=1)) ** 2).T
+        assert np.abs(mel - r64[b]).max() <= 1e-6 * np.abs(r64[b]).max()
+    peak = np.abs(r64).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(r32 - r64) / peak).max() <= 2e-6
+    l32 = o_fbank.log_mean_norm(torch.from_numpy(r32).double()).numpy()
+    l64 = o_fbank.log_mean_norm(torch.from_numpy(r64)).numpy()
+    assert np.abs(l32 - l64).max() <= 1e-4
