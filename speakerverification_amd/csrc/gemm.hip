@@ -61,7 +61,34 @@ template <> struct MmaTraits<bf16_t> {
     }
 };
 
-template <typename T, bool CONV, bool HAS_A2>
+// activation pairs used by the models, fixed at compile time (a runtime switch inlined 128 times
+// made the epilogue 30k instructions long and blew the instruction cache)
+enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_RELU_TANH = 3, EPI_LRELU03 = 4 };
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on the fast exp / rcp units: bf16 path only
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __expf(-z * z);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|x|/sqrt2)
+    const float ax = fabsf(x);
+    // 0.5*x*(1+erf(x/sqrt2)) = 0.5*(x + |x|*erf_abs)
+    return 0.5f * fmaf(ax, erf_abs, x);
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ float epilogue_act1(float v) {
+    if (EPI == EPI_RELU || EPI == EPI_RELU_TANH) return fmaxf(v, 0.0f);
+    if (EPI == EPI_GELU) return sizeof(T) == 2 ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (EPI == EPI_LRELU03) return v > 0.0f ? v : 0.3f * v;
+    return v;
+}
+
+template <typename T, bool CONV, bool HAS_A2, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     typedef MmaTraits<T> TR;
     typedef typename TR::chunk_t chunk_t;
@@ -210,9 +237,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 if (nok && m < p.M) {
                     float v = acc[i][j][r] + bias;
                     if (p.bias_utt) v += p.bias_utt[(int64_t)(m / p.T) * p.ld_bu + n];
-                    v = apply_act(v, p.act1);
-                    v = v * sc + sh;
-                    v = apply_act(v, p.act2);
+                    v = epilogue_act1<T, EPI>(v);
+                    v = fmaf(v, sc, sh);
+                    if (EPI == EPI_RELU_TANH) v = tanhf(v);
                     if (out_f32) reinterpret_cast<float*>(p.Y)[(int64_t)m * p.ldy + n] = v;
                     else reinterpret_cast<bf16_t*>(p.Y)[(int64_t)m * p.ldy + n] = static_cast<bf16_t>(v);
                 }
@@ -221,28 +248,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T>
-hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
+template <typename T, bool CONV, bool HAS_A2, int EPI>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     dim3 grid(ntm * ntn), block(256);
     const size_t lds = 4 * TILE_BYTES;
     static bool attr_done = false;
     if (!attr_done) {   // 64 KiB of dynamic LDS per workgroup
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, CONV, HAS_A2, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const bool conv = p.taps > 1;
-    if (conv) {
-        if (p.A2) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, lds, stream, p);
-    } else {
-        if (p.A2) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, lds, stream, p);
-    }
+    hipLaunchKernelGGL((gemm_kernel<T, CONV, HAS_A2, EPI>), grid, block, lds, stream, p);
     return hipGetLastError();
+}
+
+template <typename T, int EPI>
+hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
+    const bool conv = p.taps > 1;
+    if (conv) return p.A2 ? launch_inst<T, true, true, EPI>(p, stream) : launch_inst<T, true, false, EPI>(p, stream);
+    if (p.A2) return hipErrorInvalidValue;       // pointwise + A2 is not used by any model
+    return launch_inst<T, false, false, EPI>(p, stream);
+}
+
+template <typename T>
+hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
+    if (p.act1 == ACT_NONE && p.act2 == ACT_NONE) return launch_epi<T, EPI_NONE>(p, stream);
+    if (p.act1 == ACT_RELU && p.act2 == ACT_NONE) return launch_epi<T, EPI_RELU>(p, stream);
+    if (p.act1 == ACT_GELU && p.act2 == ACT_NONE) return launch_epi<T, EPI_GELU>(p, stream);
+    if (p.act1 == ACT_RELU && p.act2 == ACT_TANH) return launch_epi<T, EPI_RELU_TANH>(p, stream);
+    if (p.act1 == ACT_LRELU03 && p.act2 == ACT_NONE) return launch_epi<T, EPI_LRELU03>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -260,6 +297,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         return hipErrorInvalidValue;
     }
     if (p.bias_utt && (p.T <= 0)) return hipErrorInvalidValue;
+    if (gemm_pw_supported(p, bf16)) return launch_gemm_pw(p, bf16, stream);
     return bf16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }
 

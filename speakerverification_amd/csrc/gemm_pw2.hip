@@ -1,0 +1,247 @@
+// gemm_pw2.hip — bf16 pointwise-conv GEMM, 256 x 256 tile, role-staggered wave groups (gfx950).
+//
+// Same contract as gemm_pw.hip (Y = epi(A . W^T), bf16 in / fp32 accumulate / bf16 out), built for
+// the big layers (tdnn1/tdnn2, mfa).  What is different:
+//
+//   * K advances in HALF-steps of 32 (64 bytes per row).  The LDS holds a ring of 4 half-stages
+//     (A 16 KiB + W 16 KiB each, 128 KiB in all), filled by global_load_lds_dwordx4 three half-steps
+//     ahead of use.
+//   * the 8 waves form two groups (waves 0-3 = rows 0..127 of the tile, waves 4-7 = rows 128..255;
+//     one wave of each group per SIMD) that run the same program ONE PHASE APART:
+//         phase L(h): ds_read the 12 fragments of half-step h, issue this wave's 4 DMAs for h+3
+//         phase C(h): 16 MFMAs (32x32x16) on those fragments
+//     separated by raw s_barriers.  While one group is in L the other is in C, so on every SIMD the
+//     matrix pipe is fed by one wave while its partner pays the LDS-read / DMA-issue latency, instead
+//     of both waves stalling together (measured on the un-staggered kernel: MFMA, ds_read and DMA
+//     issue time added up instead of overlapping).
+//   * DMA completion is tracked with counted s_waitcnt vmcnt(8/4/0) placed BEFORE the barrier that
+//     precedes the first reader (LDS-DMA data is ordered for a ds_read only by the issuing wave's
+//     vmcnt followed by a barrier the reader has passed); a ring slot is refilled only after the
+//     barrier that follows its last reader.
+//   * conflict-free LDS: 64-byte rows, 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3);
+//     the DMA writes LDS lane-linear, so the XOR is applied to the per-lane SOURCE address.
+//   * epilogue identical to gemm_pw.hip: weights are the MFMA A operand, so each lane owns 4
+//     consecutive channels per register group; bias/act/BN, pack to bf16, swizzled LDS image of the
+//     256 x 256 tile, whole 512-byte rows out in 16-byte stores.
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+constexpr int QBM = 256, QBN = 256;
+constexpr int HROWB = 64;                       // bytes per row per half-step (32 bf16)
+constexpr int HA = QBM * HROWB;                 // 16 KiB
+constexpr int HSTAGE = HA + QBN * HROWB;        // 32 KiB
+constexpr int NRING = 4;
+constexpr int PW2_LDS = NRING * HSTAGE;         // 128 KiB (also holds the 256 x 256 bf16 output tile)
+constexpr int QGROUP_M = 4;
+
+enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
+
+__device__ __forceinline__ int hswz(int row, int chunk) { return row * HROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ float gelu_fast(float x) {      // erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __expf(-z * z);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);
+    return 0.5f * fmaf(fabsf(x), erf_abs, x);
+}
+
+template <int EPI>
+__device__ __forceinline__ float act1(float v) {
+    if (EPI == EPI_RELU) return fmaxf(v, 0.0f);
+    if (EPI == EPI_GELU) return gelu_fast(v);
+    if (EPI == EPI_LRELU03) return v > 0.0f ? v : 0.3f * v;
+    return v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- XCD-aware tile mapping --------------------------------------------------------------
+    const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
+    const int nwg = ntm * ntn;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int grp_t = id / (QGROUP_M * ntn);
+    const int within = id - grp_t * (QGROUP_M * ntn);
+    const int gm = min(QGROUP_M, ntm - grp_t * QGROUP_M);
+    const int tile_m = grp_t * QGROUP_M + within % gm;
+    const int tile_n = within / gm;
+    const int m0 = tile_m * QBM, n0 = tile_n * QBN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
+
+    // ---- DMA geometry: per half-step, wave w fills 16-row groups g = w, w + 8 of A and of W --------
+    const char* src[4];
+    int dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool isA = j < 2;
+        const int g = wave + 8 * (j & 1);
+        const int r = g * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((r >> 2) & 3);
+        if (isA) {
+            const int m = min(m0 + r, p.M - 1);
+            src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * 8) * 2;
+            dst[j] = g * 1024;
+        } else {
+            const int n = min(n0 + r, p.Wrows - 1);
+            src[j] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + lc * 8) * 2;
+            dst[j] = HA + g * 1024;
+        }
+    }
+    auto issue = [&](int h) {
+        char* base = smem + (h & (NRING - 1)) * HSTAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (int64_t)h * HROWB), (lds_void*)(base + dst[j]), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nh = p.Kp / 32;                       // half-steps (host guarantees Kp % 64 == 0, so nh >= 2)
+    issue(0);
+    issue(1);
+    if (nh > 2) issue(2);
+    if (nh > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // half-step 0 of every wave has landed
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind group 0
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int arow = wm * 128 + fr, wrow = wn * 64 + fr;
+    for (int h = 0; h < nh; ++h) {
+        // ---------------- phase L(h): fragments of half-step h -> registers; DMA for h+3 ----------------
+        const char* As = smem + (h & (NRING - 1)) * HSTAGE;
+        const char* Ws = As + HA;
+        bf16x8 xf[2][4], wf[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8*>(As + hswz(arow + i * 32, 2 * s + fh));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[s][j] = *reinterpret_cast<const bf16x8*>(Ws + hswz(wrow + j * 32, 2 * s + fh));
+        }
+        if (h + 3 < nh) {
+            issue(h + 3);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // retires this wave's DMAs of half-step h+1
+        } else if (h + 2 < nh) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase C(h): 16 MFMAs ------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count
+    __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: reuse the ring
+
+    // ---- epilogue: acc[i][j][4g+e] is (m = wm*128 + i*32 + fr, n = wn*64 + j*32 + 8g + 4fh + e) --------
+    constexpr int ORB = QBN * 2;                    // 512-byte output rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + j * 32 + 8 * g + 4 * fh;
+            const int n = n0 + nl;
+            const bool nok = n < p.N;
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+            if (nok) {
+                if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (p.scale) { sc4 = *reinterpret_cast<const f32x4*>(p.scale + n); sh4 = *reinterpret_cast<const f32x4*>(p.shift + n); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wm * 128 + i * 32 + fr;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(act1<EPI>(acc[i][j][4 * g + e] + b4[e]), sc4[e], sh4[e]);
+                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+                *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
+            }
+        }
+    }
+    __syncthreads();
+    char* Yb = reinterpret_cast<char*>(p.Y);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {               // 256 rows x 32 16-byte chunks / 512 threads
+        const int idx = it * 512 + tid;
+        const int row = idx >> 5, q = idx & 31;
+        const int rr = row & 15;
+        const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
+        const u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
+        const int m = m0 + row, n = n0 + q * 8;
+        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
+    }
+}
+
+template <int EPI>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
+    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE) return false;
+    if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
+    if (p.N < 256 || p.Kp % 64 != 0) return false;
+    return gemm_pw_supported(p, bf16);
+}
+
+hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
+    switch (p.act1) {
+        case ACT_NONE: return launch_inst<EPI_NONE>(p, stream);
+        case ACT_RELU: return launch_inst<EPI_RELU>(p, stream);
+        case ACT_GELU: return launch_inst<EPI_GELU>(p, stream);
+        case ACT_LRELU03: return launch_inst<EPI_LRELU03>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace svhip

@@ -28,6 +28,7 @@ struct GemmParams {
     int taps = 1, dil = 1, cin = 0, pad_mode = 0;
     int act1 = 0, act2 = 0;
     int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
+    int debug = 0;            // developer ablations (tools/gemm_bench): 1 no loads in the loop, 2 no MFMA, 4 no epilogue
     int Wrows = 0;            // allocated rows of W (loads clamp to Wrows-1); packed weights: N rounded up to 128
 };
 
@@ -39,6 +40,12 @@ inline int gemm_bk(bool bf16) { return bf16 ? 64 : 32; }
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
+// pointwise fast path (gemm_pw.hip): 256 x 128 tiles, LDS-DMA ring; launch_gemm routes to it when supported
+bool gemm_pw_supported(const GemmParams& p, bool bf16);
+hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream);
+// bf16 256 x 256 role-staggered variant for the big layers (gemm_pw2.hip); launch_gemm_pw routes to it
+bool gemm_pw2_supported(const GemmParams& p, bool bf16);
+hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Mel front-end

@@ -1,0 +1,10 @@
+#!/bin/bash
+# developer tool: build tools/gemm_bench with the GEMM sources compiled with -DSVHIP_GEMM_DEBUG (ablation flags)
+set -e
+cd "$(dirname "$0")/.."
+CS=speakerverification_amd/csrc
+FL="-O3 -std=c++17 --offload-arch=gfx950 -DSVHIP_GEMM_DEBUG -I $CS"
+for f in gemm gemm_pw gemm_pw2; do /opt/rocm/bin/hipcc $FL -c $CS/$f.hip -o tools/$f.dbg.o & done
+/opt/rocm/bin/hipcc $FL -c tools/gemm_bench.hip -o tools/gemm_bench.o
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 tools/gemm_bench.o tools/gemm.dbg.o tools/gemm_pw.dbg.o tools/gemm_pw2.dbg.o -o tools/gemm_bench

@@ -1,0 +1,71 @@
+// gemm_bench — microbenchmark of the library's GEMM launcher on the ECAPA layer shapes (developer tool).
+//   hipcc -O3 --offload-arch=gfx950 -I speakerverification_amd/csrc tools/gemm_bench.hip speakerverification_amd/csrc/gemm.o -o tools/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "kernels.h"
+#include "common.h"
+using namespace svhip;
+
+__global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed; x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+        float f = ((x & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
+        uint32_t u = __float_as_uint(f); p[i] = (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
+    }
+}
+__global__ void fill_f32(float* p, size_t n, uint32_t seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed; x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+        p[i] = ((x & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
+    }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; };
+
+int main(int argc, char** argv) {
+    const bool bf16 = !(argc > 1 && atoi(argv[1]) == 0);
+    const int B = argc > 2 ? atoi(argv[2]) : 256;
+    const int debug = argc > 3 ? atoi(argv[3]) : 0;
+    const float dscale = argc > 4 ? (float)atof(argv[4]) : 1.0f;
+    const int T = 401, M = B * T, C = 1024;
+    const int esz = bf16 ? 2 : 4;
+    std::vector<Shape> shapes = {
+        {"tdnn  N1024 K1024 gelu", M, C, C, 1, 1, 0, ACT_GELU, ACT_NONE, false, false},
+        {"mfa   N3072 K3072 gelu", M, 3 * C, 3 * C, 1, 1, 0, ACT_GELU, ACT_NONE, false, false},
+        {"asp_t N128  K3072 relu-tanh", M, 128, 3 * C, 1, 1, 0, ACT_RELU, ACT_TANH, false, false},
+        {"asp_c N3072 K128  f32out", M, 3 * C, 128, 1, 1, 0, ACT_NONE, ACT_NONE, false, true},
+        {"blk0  N1024 K400 conv5 gelu", M, C, 400, 5, 1, 80, ACT_GELU, ACT_NONE, false, false},
+        {"res2  N128  K384 conv3d2 relu +A2", M, 128, 384, 3, 2, 128, ACT_RELU, ACT_NONE, true, false},
+        {"tdnn  N1024 K1024 none", M, C, C, 1, 1, 0, ACT_NONE, ACT_NONE, false, false},
+    };
+    size_t maxA = (size_t)M * 3 * C, maxW = (size_t)3 * C * 3 * C + 128 * 3 * C, maxY = (size_t)M * 3 * C;
+    void *A, *A2, *W, *Y; float *bias, *scale, *shift;
+    CK(hipMalloc(&A, maxA * esz)); CK(hipMalloc(&A2, maxA * esz)); CK(hipMalloc(&W, maxW * esz)); CK(hipMalloc(&Y, maxY * 4));
+    CK(hipMalloc(&bias, 4096 * 4)); CK(hipMalloc(&scale, 4096 * 4)); CK(hipMalloc(&shift, 4096 * 4));
+    if (bf16) { fill_bf16<<<2048, 256>>>((uint16_t*)A, maxA, 1, dscale); fill_bf16<<<2048, 256>>>((uint16_t*)A2, maxA, 2, dscale); fill_bf16<<<2048, 256>>>((uint16_t*)W, maxW, 3, 0.05f * dscale); }
+    else { fill_f32<<<2048, 256>>>((float*)A, maxA, 1, 1.0f); fill_f32<<<2048, 256>>>((float*)A2, maxA, 2, 1.0f); fill_f32<<<2048, 256>>>((float*)W, maxW, 3, 0.05f); }
+    fill_f32<<<16, 256>>>(bias, 4096, 4, 0.1f); fill_f32<<<16, 256>>>(scale, 4096, 5, 1.0f); fill_f32<<<16, 256>>>(shift, 4096, 6, 0.1f);
+    CK(hipDeviceSynchronize());
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& s : shapes) {
+        GemmParams p;
+        p.A = A; p.A2 = s.a2 ? A2 : nullptr; p.W = W; p.Y = Y; p.bias = bias; p.scale = scale; p.shift = shift;
+        p.M = s.M; p.N = s.N; p.K = s.K; p.Kp = round_up(s.K, gemm_bk(bf16)); p.Wrows = round_up(s.N, 128);
+        p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = T;
+        p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = PAD_REFLECT; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = debug;
+        for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
+        CK(hipStreamSynchronize(st));
+        const int it = 5;
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < it; ++i) CK(launch_gemm(p, bf16, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+        printf("%-40s %8.3f ms  %8.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+    }
+    return 0;
+}
