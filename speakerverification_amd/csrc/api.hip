@@ -490,13 +490,25 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     int ldin = C;
     for (int i = 0; i < 3; ++i) {
         if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, h->H1, C, M, ACT_GELU))) return rc;
-        if ((rc = run(h, "copy_cols", 0, [&]() { return launch_copy_cols(h->H1, C, h->H2, C, bf, M, C8, st); }))) return rc;
-        for (int j = 1; j < 8; ++j) {
-            const void* a = off(h->H1, (size_t)j * C8, e);
-            const void* a2 = j >= 2 ? off(h->H2, (size_t)(j - 1) * C8, e) : nullptr;
-            if ((rc = conv_gemm(h, "gemm_res2net", h->res2[i][j - 1], a, C, off(h->H2, (size_t)j * C8, e), C, M, ACT_RELU,
-                                ACT_NONE, a2, C)))
-                return rc;
+        if (bf && res2net_chain_supported(C, T, h->res2[i][0].dil, h->res2[i][0].Kp)) {
+            Res2Params rp;
+            rp.H1 = h->H1; rp.H2 = h->H2; rp.ld = C; rp.T = T; rp.dil = h->res2[i][0].dil; rp.Kp = h->res2[i][0].Kp;
+            double fl = 0;
+            for (int j = 0; j < 7; ++j) {
+                rp.W[j] = h->res2[i][j].W; rp.bias[j] = h->res2[i][j].bias;
+                rp.scale[j] = h->res2[i][j].scale; rp.shift[j] = h->res2[i][j].shift;
+                fl += (double)M * h->res2[i][j].flops_per_row;
+            }
+            if ((rc = run(h, "res2net_chain", fl, [&]() { return launch_res2net_chain(rp, B, C, st); }))) return rc;
+        } else {
+            if ((rc = run(h, "copy_cols", 0, [&]() { return launch_copy_cols(h->H1, C, h->H2, C, bf, M, C8, st); }))) return rc;
+            for (int j = 1; j < 8; ++j) {
+                const void* a = off(h->H1, (size_t)j * C8, e);
+                const void* a2 = j >= 2 ? off(h->H2, (size_t)(j - 1) * C8, e) : nullptr;
+                if ((rc = conv_gemm(h, "gemm_res2net", h->res2[i][j - 1], a, C, off(h->H2, (size_t)j * C8, e), C, M, ACT_RELU,
+                                    ACT_NONE, a2, C)))
+                    return rc;
+            }
         }
         if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], h->H2, C, h->H3, C, M, ACT_GELU))) return rc;
         if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(h->H3, bf, C, B, T, C, h->d_mean, st); }))) return rc;
@@ -519,11 +531,20 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
          }))) return rc;
     if ((rc = conv_gemm(h, "gemm_asp_tdnn", h->asp_tdnn, h->MFA, C3, h->ATT, 128, M, ACT_RELU, ACT_TANH, nullptr, 0, h->d_ctx, 128)))
         return rc;
-    if ((rc = conv_gemm(h, "gemm_asp_conv", h->asp_conv, h->ATT, 128, h->LOGITS, C3, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true)))
-        return rc;
-    if ((rc = run(h, "asp_pool", 0, [&]() {
-             return launch_asp_pool(h->LOGITS, h->MFA, bf, C3, B, T, C3, h->aspbn_scale, h->aspbn_shift, h->d_pool_raw, h->d_pool_bn, 1e-12f, st);
-         }))) return rc;
+    if (bf && asp_fused_supported(T, C3, h->asp_tdnn.N, h->asp_conv.Kp)) {
+        AspFusedParams ap;
+        ap.att = h->ATT; ap.W = h->asp_conv.W; ap.Kp = h->asp_conv.Kp; ap.bias = h->asp_conv.bias;
+        ap.X = h->MFA; ap.ldx = C3; ap.T = T; ap.C = C3;
+        ap.bn_scale = h->aspbn_scale; ap.bn_shift = h->aspbn_shift;
+        ap.pooled_raw = h->d_pool_raw; ap.pooled_bn = h->d_pool_bn; ap.eps = 1e-12f;
+        if ((rc = run(h, "asp_fused", (double)M * h->asp_conv.flops_per_row, [&]() { return launch_asp_fused(ap, B, st); }))) return rc;
+    } else {
+        if ((rc = conv_gemm(h, "gemm_asp_conv", h->asp_conv, h->ATT, 128, h->LOGITS, C3, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true)))
+            return rc;
+        if ((rc = run(h, "asp_pool", 0, [&]() {
+                 return launch_asp_pool(h->LOGITS, h->MFA, bf, C3, B, T, C3, h->aspbn_scale, h->aspbn_shift, h->d_pool_raw, h->d_pool_bn, 1e-12f, st);
+             }))) return rc;
+    }
     if ((rc = run(h, "fc", 2.0 * B * h->fc.N * h->fc.K, [&]() {
              return launch_rowvec_linear(h->d_pool_bn, 2 * C3, h->fc.W, h->fc.bias, h->d_emb, c.embed_dim, B, c.embed_dim, 2 * C3, ACT_NONE, st);
          }))) return rc;

@@ -70,25 +70,57 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ X, 
 }
 
 // ---- small-M linear: out[b, n] = act(bias[n] + W[n, :] . in[b, :]) -----------------------------
-// grid (ceil(N / 32), B), block 256: the input row is staged in LDS once, each wave produces 8 outputs.
+// grid (ceil(N / 8), ceil(B / 8)), block 256: an 8 (n) x 8 (b) output block per workgroup, K split
+// over the 4 waves, float4 loads along K (both operands are read once per block instead of once per
+// output), 64 accumulators per lane, wavefront shuffle + LDS combine at the end.
 __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restrict__ in, int ld_in,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
-                                                            float* __restrict__ out, int ld_out, int N, int K, int act) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xin = reinterpret_cast<float*>(smem);
-    const int b = blockIdx.y;
-    for (int k = threadIdx.x; k < K; k += 256) xin[k] = in[(int64_t)b * ld_in + k];
-    __syncthreads();
+                                                            float* __restrict__ out, int ld_out, int B, int N, int K, int act) {
+    __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int o = 0; o < 8; ++o) {
-        const int n = blockIdx.x * 32 + wave * 8 + o;
-        if (n >= N) break;
-        const float* __restrict__ w = W + (int64_t)n * K;
-        float s = 0.0f;
-        for (int k = lane; k < K; k += 64) s = fmaf(w[k], xin[k], s);
-        s = wave_sum(s);
-        if (lane == 0) out[(int64_t)b * ld_out + n] = apply_act(s + (bias ? bias[n] : 0.0f), act);
+    const int n0 = blockIdx.x * 8, b0 = blockIdx.y * 8;
+    const float* __restrict__ wrow[8];
+    const float* __restrict__ xrow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wrow[i] = W + (int64_t)min(n0 + i, N - 1) * K;
+        xrow[i] = in + (int64_t)min(b0 + i, B - 1) * ld_in;
+    }
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0f;
+    const int K4 = K >> 2;                                   // float4 chunks along K
+    for (int c = wave * 64 + lane; c < K4; c += 256) {
+        f32x4 wv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wv[i] = *reinterpret_cast<const f32x4*>(wrow[i] + 4 * c);
+            xv[i] = *reinterpret_cast<const f32x4*>(xrow[i] + 4 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j] = fmaf(wv[i][e], xv[j][e], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = wave_sum(acc[i][j]);
+            if (lane == 0) red[wave][i * 8 + j] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x >> 3, j = threadIdx.x & 7;     // n = n0 + i, b = b0 + j
+        const int n = n0 + i, b = b0 + j;
+        if (n < N && b < B) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            out[(int64_t)b * ld_out + n] = apply_act(s + (bias ? bias[n] : 0.0f), act);
+        }
     }
 }
 
@@ -216,9 +248,10 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
 
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
                                 int B, int N, int K, int act, hipStream_t stream) {
-    if (K <= 0 || N <= 0 || (size_t)K * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
-    dim3 grid((N + 31) / 32, B), block(256);
-    hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, (size_t)K * sizeof(float), stream, in, ld_in, W, bias, out, ld_out, N, K, act);
+    if (K <= 0 || N <= 0 || B <= 0 || K % 4 != 0 || ld_in % 4 != 0) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
+    dim3 grid((N + 7) / 8, (B + 7) / 8), block(256);
+    hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, 0, stream, in, ld_in, W, bias, out, ld_out, B, N, K, act);
     return hipGetLastError();
 }
 

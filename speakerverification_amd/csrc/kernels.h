@@ -48,6 +48,23 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
+// Fused Res2Net chain (bf16 path): one workgroup per utterance runs the 7 dependent dilated convs
+// of one SE-Res2Net block with the conv input resident in LDS (res2net.hip).
+// H1 = tdnn1 output (M, ld), H2 = chain output (M, ld): y_0 = c_0, y_j = BN(ReLU(conv(c_j + y_{j-1}))).
+// ---------------------------------------------------------------------------------------------
+struct Res2Params {
+    const void* H1 = nullptr;
+    void* H2 = nullptr;
+    int ld = 0, T = 0, dil = 1, Kp = 0;
+    const void* W[7] = {};       // packed [>= C/8 rows][Kp] bf16, k = tap * C/8 + c
+    const float* bias[7] = {};
+    const float* scale[7] = {};
+    const float* shift[7] = {};
+};
+bool res2net_chain_supported(int C, int T, int dil, int Kp);
+hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
 // Mel front-end
 // ---------------------------------------------------------------------------------------------
 struct FbankTables {           // device pointers, built once per handle
@@ -90,6 +107,23 @@ hipError_t launch_copy_cols(const void* src, int lds, void* dst, int ldd, bool b
 hipError_t launch_asp_pool(const float* logits, const void* X, bool bf16, int ldx, int B, int T, int C,
                            const float* bn_scale, const float* bn_shift, float* pooled_raw, float* pooled_bn,
                            float eps, hipStream_t stream);
+
+// Fused attention tail (bf16 path, asp_fused.hip): logits = conv1x1(att) + b, softmax over T, weighted
+// mean / std of X, BatchNorm affine -> pooled (B, 2C).  The logits never reach memory.
+struct AspFusedParams {
+    const void* att = nullptr;      // (B*T, 128) bf16
+    const void* W = nullptr;        // asp.conv packed [>= C rows][Kp = 128] bf16
+    const float* bias = nullptr;    // [C]
+    const void* X = nullptr;        // (B*T, ldx) bf16, the mfa output
+    const float* bn_scale = nullptr;
+    const float* bn_shift = nullptr;
+    float* pooled_raw = nullptr;    // optional (B, 2C)
+    float* pooled_bn = nullptr;     // (B, 2C)
+    int ldx = 0, T = 0, C = 0, Kp = 0;
+    float eps = 1e-12f;
+};
+bool asp_fused_supported(int T, int C, int att_channels, int Kp);
+hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Scoring

@@ -1,0 +1,191 @@
+// res2net.hip — the whole Res2Net chain of one SE-Res2Net block in ONE launch (bf16 path).
+//
+// Reference: Res2NetBlock.forward, models/ECAPA_TDNN.py:118-129:  chunks c_0..c_7 of the tdnn1 output,
+//   y_0 = c_0,  y_1 = B_0(c_1),  y_j = B_{j-1}(c_j + y_{j-1}),  B = BN(ReLU(conv_k3_dilated(.)))
+// Seven dependent convolutions with only C/8 channels each: as separate GEMM launches they are 21
+// latency-bound kernels per forward.  Here one workgroup owns one utterance:
+//   * U = the current conv input (T x C/8, bf16) lives in LDS for the whole chain; the dilated taps
+//     with reflect padding are just row-address arithmetic on it (no halo, no im2col);
+//   * the weights of one tap (C/8 x C/8) are staged in LDS, the next tap's slab is prefetched into
+//     registers under the MFMAs (global -> VGPR -> LDS, written after the barrier);
+//   * 8 waves: n-tiles of 32 channels x interleaved 32-frame m-tiles, v_mfma_f32_32x32x16_bf16 with
+//     the weights as the A operand, so a lane owns 4 consecutive output channels of one frame and
+//     the epilogue (bias, ReLU, BatchNorm affine) writes packed bf16x4 straight back into U;
+//   * a cooperative pass then streams y_j to HBM as whole rows and adds the next chunk c_{j+1}
+//     in place (fp32 add, one bf16 rounding — same as the unfused path).
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+constexpr int R2_TMAX = 416;         // 13 MFMA m-tiles; T = 401 for 2 s @ 16 kHz
+
+template <int CW> struct R2Cfg {
+    static constexpr int ROWB = CW * 2;                 // bytes per LDS row (256 / 128)
+    static constexpr int NCH = ROWB / 16;               // 16-byte chunks per row (16 / 8)
+    static constexpr int U_BYTES = R2_TMAX * ROWB;
+    static constexpr int W_BYTES = CW * ROWB;           // one tap: CW rows x CW k
+    static constexpr int LDS = U_BYTES + W_BYTES;       // 136 KiB / 60 KiB
+    static constexpr int NT = CW / 32;                  // n-tiles (4 / 2)
+    static constexpr int MW = 8 / NT;                   // wave groups along M (2 / 4)
+    static constexpr int MI = (13 + MW - 1) / MW;       // m-tiles per wave (7 / 4)
+    static constexpr int WCH = CW * NCH / 512;          // weight chunks per thread per tap (4 / 1)
+    static __device__ __forceinline__ int swz(int row) { return CW == 128 ? (row & 15) : ((row >> 1) & 7); }
+};
+
+template <int CW>
+__global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
+    typedef R2Cfg<CW> CF;
+    constexpr int ROWB = CF::ROWB, NCH = CF::NCH, MI = CF::MI, WCH = CF::WCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* U = smem;
+    char* Wt = smem + CF::U_BYTES;
+
+    const int b = blockIdx.x;
+    const int T = p.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % CF::NT, wq = wave / CF::NT;
+    const int fr = lane & 31, fh = lane >> 5;
+    const bf16_t* __restrict__ H1 = reinterpret_cast<const bf16_t*>(p.H1) + (int64_t)b * T * p.ld;
+    bf16_t* __restrict__ H2 = reinterpret_cast<bf16_t*>(p.H2) + (int64_t)b * T * p.ld;
+
+    // ---- weight slab prefetch (global -> registers), write (registers -> LDS) ----------------------
+    u32x4 wregs[WCH];
+    auto wload = [&](int layer, int tap) {
+        const char* wsrc = reinterpret_cast<const char*>(p.W[layer]);
+#pragma unroll
+        for (int e = 0; e < WCH; ++e) {
+            const int c = tid + 512 * e;
+            const int n = c / NCH, ch = c % NCH;
+            wregs[e] = *reinterpret_cast<const u32x4*>(wsrc + ((int64_t)n * p.Kp + tap * CW) * 2 + ch * 16);
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < WCH; ++e) {
+            const int c = tid + 512 * e;
+            const int n = c / NCH, ch = c % NCH;
+            *reinterpret_cast<u32x4*>(Wt + n * ROWB + ((ch ^ CF::swz(n)) << 4)) = wregs[e];
+        }
+    };
+
+    // ---- init: U = c_1, y_0 = c_0 straight to H2, first weight slab ---------------------------------
+    wload(0, 0);
+    for (int c = tid; c < T * NCH; c += 512) {
+        const int row = c / NCH, ch = c % NCH;
+        const u32x4 c0 = *reinterpret_cast<const u32x4*>(H1 + (int64_t)row * p.ld + ch * 8);
+        const u32x4 c1 = *reinterpret_cast<const u32x4*>(H1 + (int64_t)row * p.ld + CW + ch * 8);
+        *reinterpret_cast<u32x4*>(H2 + (int64_t)row * p.ld + ch * 8) = c0;
+        *reinterpret_cast<u32x4*>(U + row * ROWB + ((ch ^ CF::swz(row)) << 4)) = c1;
+    }
+    wstore();
+    __syncthreads();
+
+    for (int s = 1; s < 8; ++s) {
+        const int layer = s - 1;
+        f32x16 acc[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+        for (int tap = 0; tap < 3; ++tap) {
+            const bool more = !(s == 7 && tap == 2);
+            if (more) { if (tap < 2) wload(layer, tap + 1); else wload(layer + 1, 0); }
+            const int delta = (tap - 1) * p.dil;
+            int rbase[MI], rsw[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int t = (wq + CF::MW * i) * 32 + fr + delta;
+                const int row = min(reflect_idx(t, T), T - 1);
+                rbase[i] = row * ROWB;
+                rsw[i] = CF::swz(row);
+            }
+            const int wrow = (wn * 32 + fr);
+            const int wbase = wrow * ROWB, wsw = CF::swz(wrow);
+#pragma unroll
+            for (int kk = 0; kk < CW / 16; ++kk) {
+                const int ch = 2 * kk + fh;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wt + wbase + ((ch ^ wsw) << 4));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if ((wq + CF::MW * i) * 32 < T) {          // wave-uniform: skip m-tiles beyond T
+                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(U + rbase[i] + ((ch ^ rsw[i]) << 4));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                                    // Wt (and, after tap 2, U) are free
+            if (tap < 2) { wstore(); __syncthreads(); }
+        }
+
+        // ---- epilogue: acc[i][4g+e] = (t = (wq + MW*i)*32 + fr, n = wn*32 + 8g + 4fh + e) -> U ------
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = wn * 32 + 8 * g + 4 * fh;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias[layer] + n);
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale[layer] + n);
+            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(p.shift[layer] + n);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int t = (wq + CF::MW * i) * 32 + fr;
+                if (t < T) {
+                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = static_cast<bf16_t>(fmaf(fmaxf(acc[i][4 * g + e] + b4[e], 0.0f), sc4[e], sh4[e]));
+                    const int c8 = n >> 2;                      // 8-byte chunk index inside the row
+                    *reinterpret_cast<bf16x4*>(U + t * ROWB + ((((c8 >> 1) ^ CF::swz(t)) << 4) | ((c8 & 1) << 3))) = o;
+                }
+            }
+        }
+        if (s < 7) wstore();                                    // next layer's tap-0 slab (loaded during tap 2)
+        __syncthreads();
+
+        // ---- y_s -> H2 (whole rows), U <- y_s + c_{s+1} -------------------------------------------------
+        for (int c = tid; c < T * NCH; c += 512) {
+            const int row = c / NCH, ch = c % NCH;
+            char* up = U + row * ROWB + ((ch ^ CF::swz(row)) << 4);
+            const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
+            *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
+            if (s < 7) {
+                const bf16x8 cn = *reinterpret_cast<const bf16x8*>(H1 + (int64_t)row * p.ld + (s + 1) * CW + ch * 8);
+                bf16x8 u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cn[e]));
+                *reinterpret_cast<bf16x8*>(up) = u;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int CW>
+hipError_t launch_cw(const Res2Params& p, int B, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(res2net_chain_kernel<CW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, R2Cfg<CW>::LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(res2net_chain_kernel<CW>, dim3(B), dim3(512), R2Cfg<CW>::LDS, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool res2net_chain_supported(int C, int T, int dil, int Kp) {
+    const int cw = C / 8;
+    return (cw == 64 || cw == 128) && T <= R2_TMAX && T > 2 * dil && Kp == 3 * cw;
+}
+
+hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t stream) {
+    if (!res2net_chain_supported(C, p.T, p.dil, p.Kp) || B <= 0 || p.ld % 8 != 0) return hipErrorInvalidValue;
+    return C / 8 == 128 ? launch_cw<128>(p, B, stream) : launch_cw<64>(p, B, stream);
+}
+
+}  // namespace svhip

@@ -66,10 +66,11 @@ def test_ecapa_full_fp32_matches_reference(golden_dir, C):
         assert abs(np.abs(got).sum() - cs[1]) <= 2e-5 * cs[1] + 1e-3, n
 
 
-def test_ecapa_bf16_close_to_fp32_reference(golden_dir):
-    g = np.load(os.path.join(golden_dir, "ecapa_C1024_T401.npz"))
+@pytest.mark.parametrize("C", [512, 1024])
+def test_ecapa_bf16_close_to_fp32_reference(golden_dir, C):
+    g = np.load(os.path.join(golden_dir, f"ecapa_C{C}_T401.npz"))
     B, T = int(g["B"]), int(g["T"])
-    eng, _ = make_engine(1024, T, B, "bf16", int(g["seed_w"]))
+    eng, _ = make_engine(C, T, B, "bf16", int(g["seed_w"]))
     mel = synth.synth_mel(B, 80, T, seed=int(g["seed_x"]))
     out = eng.embed_features(mel)
     ref = g["out"]
@@ -81,6 +82,12 @@ def test_ecapa_bf16_close_to_fp32_reference(golden_dir):
     print("bf16 rel err", rel, "cos", cos)
     assert rel <= 3e-2
     assert float(cos.min()) >= 0.999
+    # per-stage: the fused kernels (Res2Net chain, LDS-DMA GEMMs) against the reference's stage checksums
+    for n in STAGES:
+        cs = g["cs_" + n]
+        got = stage_cf(eng, n, B, T).astype(np.float64)
+        assert abs(np.abs(got).sum() - cs[1]) <= 1e-2 * cs[1], n
+        assert abs(got.sum() - cs[0]) <= 1e-2 * cs[1], n
 
 
 def test_batch_invariance_and_chunking():
