@@ -179,6 +179,72 @@ def golden_crop():
     np.savez_compressed(os.path.join(GOLD, "crop.npz"), **cases)
 
 
+def golden_e2e(ref):
+    """BASELINE config 1 plumbing oracle: the reference's OWN WrappedModel(SpeakerEncoder) ->
+    ModelHandling.evaluateFromList / embed_utterance on CPU over synthetic 16 kHz WAV files, with the
+    oracle's fbank standing in for the absent nnAudio front-end.  Inputs are regenerated
+    from seeds by the tests (tests/e2e_data.py); only the reference's outputs are stored."""
+    import tempfile
+    import types
+
+    import scipy.io.wavfile as wavfile
+    from tests.e2e_data import make_e2e_files, E2E_SEED_W
+
+    class OracleMel(torch.nn.Module):            # what nnAudio.features.mel.MelSpectrogram would compute
+        def __init__(self, **kw):
+            super().__init__()
+            self.kw = kw
+
+        def forward(self, x):
+            return o_fbank.melspectrogram(x, pre_emph=False, **self.kw)
+
+    sys.modules["nnAudio.features.mel"].MelSpectrogram = OracleMel
+    sys.modules["nnAudio.features"].mel = sys.modules["nnAudio.features.mel"]
+
+    def sf_read(path, **k):
+        sr, a = wavfile.read(path)
+        return a.astype(np.float32) / 32768.0, sr
+    sys.modules["soundfile"].read = sf_read
+
+    import model as ref_model                     # reference src/model.py
+    import processing.audio_loader as ref_loader
+    ref_loader.sf = sys.modules["soundfile"]
+
+    tmp = tempfile.mkdtemp(prefix="svhip_e2e_")
+    files, trial_path, lines = make_e2e_files(tmp)
+    C = 512
+    args = dict(
+        device="cpu", gpu=0, model={"name": "ECAPA_TDNN", "nOut": 192},
+        criterion={"name": "AAmSoftmaxAP", "margin": 0.25, "scale": 30},
+        classifier={"input_size": 192, "out_neurons": 10},
+        optimizer={"name": "adam", "weight_decay": 2e-5, "lr_decay": 0.95},
+        callbacks={"name": "steplr"}, features="melspectrogram", include_top=False, n_mels=80, nClasses=10,
+        lr=0.001, step_size=10, channels=[C] * 4 + [3 * C],
+        dataloader_options={"nPerSpeaker": 2, "num_workers": 0, "batch_size": 2},
+        audio_spec={"sample_rate": 16000, "channels": 1, "sentence_len": 2.0, "win_len": 0.025, "hop_len": 0.01},
+        augment=False, augment_options={"augment_chain": []}, save_folder=tmp,
+    )
+    enc = ref_model.SpeakerEncoder(**args)
+    net = ref_model.WrappedModel(enc)
+    mh = ref_model.ModelHandling(net, **args)
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=E2E_SEED_W)
+    enc.__S__.load_state_dict(torch_sd(sd), strict=True)
+    out = {}
+    for ne in (2, 3):   # num_eval=1 cannot run in the reference: squeeze() yields (192,) and F.normalize(dim=1) raises
+        sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False,
+                                          dataloader_options=args["dataloader_options"], cohorts_path="unused",
+                                          num_eval=ne, scoring_mode="cosine")
+        out[f"scores_ne{ne}"] = np.array(sc, np.float64)
+        out[f"labels_ne{ne}"] = np.array(lab, np.int64)
+        assert tr == [ln.split()[1] + " " + ln.split()[2] for ln in lines]
+    emb = mh.embed_utterance(files[0], num_eval=3, normalize=True)
+    out["embed_utt0_ne3"] = emb.numpy()
+    emb_arr = mh.embed_utterance((0.25 * np.sin(np.arange(40000) / 7.0)).astype(np.float32), num_eval=2, normalize=False)
+    out["embed_array_ne2"] = emb_arr.numpy()
+    np.savez_compressed(os.path.join(GOLD, "e2e_config1.npz"), **out)
+    print("e2e fixture: scores", out["scores_ne2"][:4], "...")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -195,6 +261,12 @@ def main():
     specs["ecapa_C512"] = golden_ecapa(ref, C=512, T=401, B=2, seed_w=1, seed_x=11, full=False)
     specs["ecapa_C1024"] = golden_ecapa(ref, C=1024, T=401, B=2, seed_w=1, seed_x=11, full=False)
     specs["rawnet2"] = golden_rawnet2(ref, B=2, seed_w=1, seed_x=20220829)
+    try:
+        golden_e2e(ref)
+    except Exception as e:  # pragma: no cover - reported, not fatal
+        import traceback
+        traceback.print_exc()
+        print("e2e fixture skipped:", repr(e))
     with open(os.path.join(GOLD, "param_specs.json"), "w") as f:
         json.dump({k: [[n, list(s)] for n, s in v] for k, v in specs.items()}, f)
     print("golden fixtures written to", GOLD)

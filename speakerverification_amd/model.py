@@ -1,0 +1,399 @@
+"""Counterparts of the reference's ``src/model.py`` for the inference hot path.
+
+Same class / method names, arguments and return shapes as the reference so that
+``inference.py``-style drivers keep working:
+
+    net = WrappedModel(SpeakerEncoder(**vars(args)))
+    speaker_model = ModelHandling(net, **vars(args))
+    speaker_model.loadParameters(path)
+    scores, labels, trials = speaker_model.evaluateFromList(listfilename=..., distributed=False,
+                                                           dataloader_options=..., cohorts_path=...,
+                                                           num_eval=10, scoring_mode='cosine')
+
+What changed underneath: crops of MANY files are batched into one device call
+(reference: batch = one file), embeddings stay in one dense matrix, and the whole trial list is
+scored by one kernel launch per mode (reference: three host<->device crossings per trial).
+Training (``fit``), ONNX export and report writing are out of scope and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import csv
+import importlib
+import itertools
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import distributed as sv_dist
+from . import scoring
+from .audio import loadWAV
+from .engine import _is_torch
+
+try:
+    import torch
+    import torch.nn.functional as F
+except Exception:  # pragma: no cover
+    torch = None
+
+# losses whose test_normalize is False in the reference (src/losses/Prototypical.py:21); every other
+# loss sets it True (src/losses/*.py), which is what reaches the hot path (src/model.py:90-94,421-423)
+_NO_TEST_NORMALIZE = {"Prototypical"}
+
+
+class WrappedModel:
+    """src/model.py:24-33 — the DataParallel-compatibility wrapper: forward delegates to .module"""
+
+    def __init__(self, model):
+        self.module = model
+
+    def forward(self, x, label=None):
+        return self.module(x, label)
+
+    __call__ = forward
+
+    def eval(self):
+        self.module.eval()
+        return self
+
+    def train(self, mode=True):
+        self.module.train(mode)
+        return self
+
+    def state_dict(self):
+        return self.module.state_dict()
+
+    def parameters(self):
+        return self.module.parameters()
+
+
+class SpeakerEncoder:
+    """src/model.py:36-135: feature extractor + __S__ (+ the loss's test_normalize flag)."""
+
+    def __init__(self, model, criterion=None, classifier=None, optimizer=None, features="melspectrogram",
+                 device="cuda", gpu=0, include_top=False, **kwargs):
+        self.model = model
+        self.criterion = criterion or {"name": "AAmSoftmaxAP"}
+        self.classifier = classifier
+        self.optimizer = optimizer
+        self.gpu = gpu
+        self.device = f"{device}:{gpu}"
+        self.n_mels = kwargs.get("n_mels", 80)
+        self.features = features.lower()
+        if include_top:
+            raise NotImplementedError("include_top (classification head) is outside the inference hot path")
+        kw = dict(kwargs)
+        kw.setdefault("n_mels", self.n_mels)
+        kw.setdefault("augment", False)
+        kw.setdefault("augment_options", {"augment_chain": []})
+        if self.features in ("mfcc", "melspectrogram"):
+            fx = importlib.import_module("speakerverification_amd.models.FeatureExtraction.feature")
+            self.compute_features = getattr(fx, self.features)(**kw).to(self.device)
+        else:
+            self.compute_features = None
+        if not isinstance(self.model["name"], str):
+            raise NotImplementedError("Mixed_model lists are outside the hot path")
+        mod = importlib.import_module("speakerverification_amd.models." + self.model["name"])
+        self.__S__ = mod.MainModel(nOut=self.model["nOut"], features=self.features, device=self.device, **kw).to(self.device)
+        self.test_normalize = self.criterion.get("name") not in _NO_TEST_NORMALIZE
+        self.training = False
+
+    # nn.Module look-alikes ------------------------------------------------------------------------------
+    def eval(self):
+        self.__S__.eval()
+        return self
+
+    def train(self, mode=True):
+        self.__S__.train(mode)
+        return self
+
+    def parameters(self):
+        return self.__S__.parameters()
+
+    def state_dict(self):
+        """reference checkpoint layout: keys prefixed with __S__. (src/model.py:710-716)"""
+        return {"__S__." + k: v for k, v in self.__S__.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        sub = {k[len("__S__."):]: v for k, v in sd.items() if k.startswith("__S__.")}
+        return self.__S__.load_state_dict(sub, strict=strict)
+
+    def forward(self, data, label=None):
+        """src/model.py:104-125 with label=None: (..., L) waveforms -> (N, nOut) embeddings
+        ((nOut,) for a single row, as the reference's stack(dim=1).squeeze())."""
+        if label is not None:
+            raise NotImplementedError("loss evaluation (training) is outside the inference hot path")
+        L = data.shape[-1]
+        data = data.reshape(-1, L)
+        if self.features != "raw" and hasattr(self.__S__, "embed_wave") and self._fusable():
+            out = self.__S__.embed_wave(data)                   # fbank + forward in one library call
+        else:
+            inp = self.compute_features(data) if self.features != "raw" else data
+            out = self.__S__.forward(inp)
+        return out
+
+    __call__ = forward
+
+    def _fusable(self):
+        """the fused path bakes the front-end defaults into the model handle; only use it when the
+        feature extractor has exactly those defaults"""
+        p = getattr(self.compute_features, "p", None)
+        return p == dict(sr=8000, n_fft=512, win_length=200, n_mels=self.n_mels, hop_length=80,
+                         fmin=0.0, fmax=None, pre_emphasis=True)
+
+
+class ModelHandling:
+    """src/model.py:138-792, inference methods only."""
+
+    def __init__(self, encoder_model, optimizer=None, callbacks=None, device="cuda", gpu=0, mixedprec=False, **kwargs):
+        self.kwargs = kwargs
+        self.save_path = kwargs.get("save_folder", ".")
+        self.audio_spec = kwargs["audio_spec"]
+        self.__model__ = encoder_model
+        self.model_name = self.__model__.module.model["name"]
+        self.criterion = self.__model__.module.criterion["name"]
+        self.gpu = gpu
+        self.device = f"{device}:{gpu}"
+        self.embed_batch = int(kwargs.get("embed_batch", 64))      # crops per device call
+
+    # ---- training-only surface ---------------------------------------------------------------------------
+    def fit(self, *a, **k):
+        raise NotImplementedError("training is outside the scope of the MI355X inference path")
+
+    def export_onnx(self, *a, **k):
+        raise NotImplementedError("ONNX export is outside the scope of the MI355X inference path")
+
+    # ---- embedding -------------------------------------------------------------------------------------------
+    def _embed_crops(self, crops: np.ndarray) -> np.ndarray:
+        """(n, L) float32 crops -> (n, nOut) float32, in device batches of embed_batch rows."""
+        outs = []
+        for i in range(0, crops.shape[0], self.embed_batch):
+            o = self.__model__.forward(np.ascontiguousarray(crops[i:i + self.embed_batch], dtype=np.float32))
+            o = o.detach().cpu().numpy() if _is_torch(o) else np.asarray(o)
+            outs.append(o.reshape(-1, o.shape[-1]))
+        return np.concatenate(outs, 0)
+
+    def _embed_files(self, files, num_eval):
+        """crops of several files travel in one batch (the reference runs one file per forward,
+        src/model.py:386-394).  Returns {file: (num_eval, nOut)} via a dense (n_files, num_eval, nOut) block."""
+        feats = None
+        pending, owners = [], []
+
+        def flush():
+            nonlocal feats
+            if not pending:
+                return
+            emb = self._embed_crops(np.concatenate(pending, 0))
+            if feats is None:
+                feats = np.zeros((len(files), max(1, num_eval), emb.shape[-1]), np.float32)
+            pos = 0
+            for idx, n in owners:
+                feats[idx, :n] = emb[pos:pos + n]
+                pos += n
+            pending.clear()
+            owners.clear()
+
+        for idx, f in enumerate(files):
+            audio = loadWAV(f, self.audio_spec, evalmode=True, augment=False, augment_options=[], num_eval=num_eval,
+                            random_chunk=False)
+            if num_eval == 0:                       # whole file: variable length, one forward per file
+                flush()
+                emb = self._embed_crops(audio)
+                if feats is None:
+                    feats = np.zeros((len(files), 1, emb.shape[-1]), np.float32)
+                feats[idx, :1] = emb
+                continue
+            pending.append(audio)
+            owners.append((idx, audio.shape[0]))
+            if sum(n for _, n in owners) >= self.embed_batch:
+                flush()
+        flush()
+        return feats
+
+    def embed_utterance(self, source, num_eval=20, normalize=False):
+        """src/model.py:675-704: path or ndarray -> (num_eval, nOut) CPU tensor (L2-normalised on request)."""
+        audio = loadWAV(source, self.audio_spec, evalmode=True, augment=False, augment_options=[], num_eval=num_eval,
+                        random_chunk=False)
+        emb = self._embed_crops(audio)
+        if normalize:
+            eng = scoring.scoring_engine(self.gpu)
+            emb = np.ascontiguousarray(emb)
+            eng.l2norm_(emb)
+        return torch.from_numpy(emb) if torch is not None else emb
+
+    # ---- evaluation ----------------------------------------------------------------------------------------------
+    def _score(self, feats, ia, ib, scoring_mode, cohorts, cohorts_path):
+        if self.__model__.module.test_normalize:
+            flat = np.ascontiguousarray(feats.reshape(-1, feats.shape[-1]))
+            scoring.scoring_engine(self.gpu).l2norm_(flat)                  # F.normalize(p=2, dim=1), model.py:421-423
+            feats = flat.reshape(feats.shape)
+        if cohorts_path is None:
+            # model.py:425-431: F.pairwise_distance(ref (n,D,1), com (1,D,n)) takes the 2-norm over the LAST
+            # axis of the broadcast (n, D, n) difference, i.e. over the crops of `com`; score = -mean(dist)
+            r, c = feats[ia].astype(np.float64), feats[ib].astype(np.float64)          # (P, n, D)
+            d = r[:, :, :, None] - np.transpose(c, (0, 2, 1))[:, None, :, :] + 1e-6   # (P, n, D, n)
+            return (-np.sqrt((d * d).sum(-1)).mean(axis=(1, 2))).astype(np.float32)
+        if scoring_mode == "norm":
+            return scoring.score_trials(feats, ia, ib, "norm", cohorts=cohorts, top=200, device=self.gpu)
+        if scoring_mode == "cosine":
+            return scoring.score_trials(feats, ia, ib, "cosine", device=self.gpu)
+        if scoring_mode == "pnorm":
+            return scoring.score_trials(feats, ia, ib, "pnorm", device=self.gpu)
+        raise ValueError(f"unknown scoring_mode {scoring_mode}")
+
+    def evaluateFromList(self, listfilename, distributed=False, dataloader_options=None,
+                         cohorts_path="checkpoint/dump_cohorts.npy", num_eval=10, scoring_mode="cosine", **kwargs):
+        """src/model.py:306-450.  Trial lines ``label file1 file2`` (or CSV with a header line).
+        Returns (all_scores, all_labels, all_trials); empty lists on ranks != 0 when distributed."""
+        self.__model__.eval()
+        cohorts = np.load(cohorts_path) if (cohorts_path is not None and scoring_mode == "norm") else None
+        with open(listfilename) as fh:
+            lines = fh.readlines()
+        determinator = "," if len(lines[0].split(",")) > 1 else " "
+        start_index = 1 if determinator == "," else 0
+        files = list(itertools.chain(*[x.strip().split(determinator)[-2:] for x in lines[start_index:]]))
+        setfiles = sorted(set(files))
+        rank, world = sv_dist.rank_world() if distributed else (0, 1)
+        lo, hi, _ = sv_dist.shard_bounds(len(setfiles), rank, world)
+        local = self._embed_files(setfiles[lo:hi], num_eval)
+        if world > 1:
+            nOut = self.__model__.module.model["nOut"]
+            if local is None:
+                local = np.zeros((0, max(1, num_eval), nOut), np.float32)
+            t = torch.from_numpy(local)
+            if torch.distributed.get_backend() == "nccl":
+                t = t.cuda(self.gpu)
+            feats = sv_dist.all_gather_rows(t, len(setfiles)).cpu().numpy()      # ONE collective (reference: all_gather_object)
+        else:
+            feats = local
+        all_scores, all_labels, all_trials = [], [], []
+        if rank == 0:
+            index = {str(Path(f)): i for i, f in enumerate(setfiles)}
+            index.update({f: i for i, f in enumerate(setfiles)})
+            ia, ib = [], []
+            for line in lines[start_index:]:
+                data = line.strip().split(determinator) if determinator == "," else line.split()
+                if len(data) < 3:
+                    continue
+                data = data[-3:]
+                ia.append(index[data[1]])
+                ib.append(index[data[2]])
+                all_labels.append(int(data[0]))
+                all_trials.append(data[1] + " " + data[2])
+            s = self._score(feats, np.asarray(ia, np.int32), np.asarray(ib, np.int32), scoring_mode, cohorts, cohorts_path)
+            all_scores = [float(v) for v in s]
+        return all_scores, all_labels, all_trials
+
+    def testFromList(self, test_list="evaluation_test.txt", thresh_score=0.5, distributed=False, dataloader_options=None,
+                     cohorts_path=None, num_eval=10, scoring_mode="norm", output_file=None):
+        """src/model.py:455-554: CSV ``audio_1,audio_2`` -> writes audio_1,audio_2,pred_label,score."""
+        self.__model__.eval()
+        cohorts = np.load(cohorts_path) if (cohorts_path is not None and scoring_mode == "norm") else None
+        save_root = os.path.join(self.save_path, f"{self.model_name}/{self.criterion}/result")
+        if output_file is None:
+            output_file = test_list.replace(".txt", "_result.txt")
+        write_file = Path(save_root, output_file) if os.path.split(output_file)[0] == "" else output_file
+        files, lines = [], []
+        with open(Path(test_list), newline="") as rf:
+            reader = csv.reader(rf, delimiter=",")
+            next(reader, None)
+            for row in reader:
+                files += [row[0], row[1]]
+                lines.append(row)
+        setfiles = sorted(set(files))
+        feats = self._embed_files(setfiles, num_eval)
+        index = {f: i for i, f in enumerate(setfiles)}
+        ia = np.asarray([index[r[0]] for r in lines], np.int32)
+        ib = np.asarray([index[r[1]] for r in lines], np.int32)
+        # the reference routes every mode through similarity_measure here (cohorts_path may be None for cosine)
+        s = self._score(feats, ia, ib, scoring_mode, cohorts, cohorts_path if scoring_mode == "norm" else "")
+        results = []
+        os.makedirs(os.path.dirname(str(write_file)) or ".", exist_ok=True)
+        with open(write_file, "w", newline="") as wf:
+            w = csv.writer(wf, delimiter=",")
+            w.writerow(["audio_1", "audio_2", "pred_label", "score"])
+            for row, score in zip(lines, s):
+                score = float(score)
+                w.writerow([row[0], row[1], "1" if score >= thresh_score else "0", score])
+                results.append(f"{Path(row[0]).name},{Path(row[1]).name},{score}")
+        return results
+
+    # ---- cohort / enrolment preparation ------------------------------------------------------------------------------
+    def prepare(self, save_path=None, prepare_type="cohorts", num_eval=10, source=None, **kwargs):
+        """src/model.py:559-670."""
+        self.__model__.eval()
+        if not source:
+            raise ValueError("Please provide appropriate source!")
+        if prepare_type == "cohorts":
+            n_emb_per_spk = 3
+            assert isinstance(source, str), "Please provide path to train metadata files"
+            spk_files = {}
+            with open(Path(source)) as fh:
+                for line in fh.read().splitlines():
+                    data = line.split()
+                    if len(data) >= 2:
+                        spk_files.setdefault(data[0], []).append(data[1])
+            files, owner = [], []
+            for si, (spk, paths) in enumerate(spk_files.items()):
+                for pth in paths[:n_emb_per_spk]:
+                    files.append(pth)
+                    owner.append(si)
+            feats = self._embed_files(files, num_eval)                              # (n_files, n_crops, D)
+            flat = np.ascontiguousarray(feats.reshape(-1, feats.shape[-1]))
+            scoring.scoring_engine(self.gpu).l2norm_(flat)                          # embed_utterance(normalize=True)
+            feats = flat.reshape(feats.shape)
+            owner = np.asarray(owner)
+            cohort = np.vstack([feats[owner == si].reshape(-1, feats.shape[-1]).mean(axis=0, keepdims=True)
+                                for si in range(len(spk_files))])
+            if save_path:
+                np.save(save_path, np.array(cohort))
+            return True
+        if prepare_type == "embed":
+            norm = self.__model__.module.test_normalize
+            if isinstance(source, str):
+                speaker_dirs = [x for x in Path(source).iterdir() if x.is_dir()]
+                embeds, classes = [], {}
+                for idx, d in enumerate(speaker_dirs):
+                    classes[idx] = d.stem
+                    fl = [str(f) for f in d.glob("*.wav")]
+                    e = np.stack([self.embed_utterance(f, num_eval=num_eval, normalize=norm).numpy() for f in fl], 0)
+                    embeds.append(e.mean(axis=0))
+                embeds = torch.from_numpy(np.stack(embeds, -1))                     # (num_eval, nOut, n_class)
+                if save_path:
+                    torch.save(embeds, Path(save_path, "embeds.pt"))
+                    np.save(str(Path(save_path, "classes.npy")), classes)
+                return True
+            if isinstance(source, list):
+                e = np.stack([self.embed_utterance(a, num_eval=num_eval, normalize=norm).numpy() for a in source], 0)
+                mean_embed = torch.from_numpy(e.mean(axis=0))
+                if save_path:
+                    torch.save(mean_embed, Path(save_path, "embeds.pt"))
+                return mean_embed
+        raise NotImplementedError
+
+    # ---- checkpoints ------------------------------------------------------------------------------------------------------
+    def saveParameters(self, path):
+        torch.save(self.__model__.module.state_dict(), path)
+
+    def loadParameters(self, path, show_error=True):
+        """src/model.py:718-746: name-matched copy; 'module.' prefixes stripped; unknown or mis-shaped
+        tensors are reported and skipped.  (map_location is 'cpu': weights are repacked for the device.)"""
+        if not os.path.exists(path):
+            raise FileNotFoundError("Model's path is not exists")
+        loaded = torch.load(path, map_location="cpu")
+        own = self.__model__.module.state_dict()
+        keep = {}
+        for name, param in loaded.items():
+            orig = name
+            if name not in own:
+                name = name.replace("module.", "")
+                if name not in own:
+                    if show_error and name.startswith("__S__."):
+                        print("{} is not in the model.".format(orig))
+                    continue
+            if tuple(own[name].shape) != tuple(param.shape):
+                if show_error:
+                    print("Wrong parameter length: {}, model: {}, loaded: {}".format(orig, tuple(own[name].shape), tuple(param.shape)))
+                continue
+            keep[name] = param
+        self.__model__.module.load_state_dict(keep, strict=False)

@@ -1,0 +1,119 @@
+"""Scoring counterparts of the reference's ``src/utils.py:126-169``.
+
+``similarity_measure(method, ref, com, **kw)`` keeps the per-trial signature for compatibility; the
+batched entry points (``score_pairs``, ``score_matrix``, ``asnorm_stats``, ``asnorm_pairs``,
+``score_trials``) are what ``ModelHandling.evaluateFromList`` uses: one kernel launch per trial LIST
+instead of three host<->device crossings per trial.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import Engine, _is_torch
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_engines = {}
+
+
+def scoring_engine(device=0) -> Engine:
+    """one fbank/scoring-only handle per device, created on first use"""
+    if device not in _engines:
+        _engines[device] = Engine(model="none", max_batch=1, device=device)
+    return _engines[device]
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
+
+
+# ---- batched API ---------------------------------------------------------------------------------------
+def score_pairs(E, ia, ib, device=0):
+    """|cos(E[ia], E[ib])| (utils.py:163-164 with one crop per row)."""
+    return scoring_engine(device).score_pairs(E, ia, ib)
+
+
+def score_matrix(A, B, device=0):
+    return scoring_engine(device).score_matrix(A, B)
+
+
+def asnorm_stats(E, cohort, top=200, device=0):
+    return scoring_engine(device).asnorm_stats(E, cohort, top)
+
+
+def asnorm_pairs(E, mu, sigma, ia, ib, device=0):
+    return scoring_engine(device).asnorm_pairs(E, mu, sigma, ia, ib)
+
+
+def score_trials(feats, ia, ib, mode="cosine", cohorts=None, top=200, device=0):
+    """Score a whole trial list.  ``feats``: (n_files, n_crops, D) float32 (already L2-normalised when
+    the loss sets test_normalize); ``ia``/``ib``: file indices per trial.
+      cosine: mean_i |cos(R_i, C_i)| over aligned crops                          (utils.py:163-164)
+      norm  : adaptive S-norm on crop means with the top-`top` cohort scores     (utils.py:135-160)
+      pnorm : mean_i ||R_i - C_i + 1e-6||_2                                      (utils.py:167-169)
+    Returns float32 numpy scores (one per trial)."""
+    feats = np.ascontiguousarray(_np(feats), dtype=np.float32)
+    if feats.ndim == 2:
+        feats = feats[:, None, :]
+    n_files, n_crops, D = feats.shape
+    ia = np.ascontiguousarray(ia, dtype=np.int32)
+    ib = np.ascontiguousarray(ib, dtype=np.int32)
+    eng = scoring_engine(device)
+    if len(ia) == 0:
+        return np.zeros((0,), np.float32)
+    if mode == "cosine":
+        E = feats.reshape(n_files * n_crops, D)
+        crops = np.arange(n_crops, dtype=np.int32)[None, :]
+        pa = (ia[:, None] * n_crops + crops).reshape(-1)
+        pb = (ib[:, None] * n_crops + crops).reshape(-1)
+        s = eng.score_pairs(E, pa, pb).reshape(len(ia), n_crops)
+        return s.mean(axis=1).astype(np.float32)
+    if mode in ("norm", "zt_norm"):
+        if cohorts is None:
+            raise ValueError("scoring_mode 'norm' needs a cohort matrix")
+        Em = np.ascontiguousarray(feats.mean(axis=1), dtype=np.float32)          # crop means
+        mu, sd = eng.asnorm_stats(Em, np.ascontiguousarray(_np(cohorts), dtype=np.float32), top)
+        return eng.asnorm_pairs(Em, mu, sd, ia, ib)
+    if mode == "pnorm":
+        d = feats[ia] - feats[ib] + 1e-6
+        return np.sqrt((d * d).sum(-1)).mean(axis=1).astype(np.float32)
+    raise ValueError(f"unknown scoring mode {mode}")
+
+
+# ---- per-trial compatibility API (same names / arguments as the reference) ---------------------------------
+def cosine_similarity(ref, com, **kwargs):
+    r, c = np.ascontiguousarray(_np(ref), np.float32), np.ascontiguousarray(_np(com), np.float32)
+    if r.ndim == 1:
+        r, c = r[None], c[None]
+    n = r.shape[0]
+    E = np.concatenate([r, c])
+    s = scoring_engine(kwargs.get("device", 0)).score_pairs(E, np.arange(n, dtype=np.int32), np.arange(n, 2 * n, dtype=np.int32))
+    return np.mean(s)
+
+
+def ZT_norm_similarity(ref, com, cohorts, top=-1, **kwargs):
+    r, c = _np(ref).astype(np.float32), _np(com).astype(np.float32)
+    if r.ndim == 1:
+        r, c = r[None], c[None]
+    E = np.ascontiguousarray(np.stack([r.mean(axis=0), c.mean(axis=0)]), dtype=np.float32)
+    eng = scoring_engine(kwargs.get("device", 0))
+    mu, sd = eng.asnorm_stats(E, np.ascontiguousarray(_np(cohorts), np.float32), top)
+    return float(eng.asnorm_pairs(E, mu, sd, np.array([0], np.int32), np.array([1], np.int32))[0])
+
+
+def pnorm_similarity(ref, com, p=2, **kwargs):
+    d = _np(ref).astype(np.float32) - _np(com).astype(np.float32) + 1e-6
+    return np.mean(np.power(np.power(np.abs(d), p).sum(-1), 1.0 / p))
+
+
+def similarity_measure(method="cosine", ref=None, com=None, **kwargs):
+    """src/utils.py:126-132"""
+    if method == "cosine":
+        return cosine_similarity(ref, com, **kwargs)
+    elif method == "pnorm":
+        return pnorm_similarity(ref, com, **kwargs)
+    elif method == "zt_norm":
+        return ZT_norm_similarity(ref, com, **kwargs)

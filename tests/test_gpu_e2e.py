@@ -1,0 +1,75 @@
+"""GPU: BASELINE config 1 — the drop-in SpeakerEncoder / ModelHandling on the HIP path reproduce the
+(scores, labels, trials) triple and embed_utterance outputs captured from the REFERENCE'S OWN
+ModelHandling on CPU (tests/golden/e2e_config1.npz, oracle/make_golden.py::golden_e2e)."""
+import os
+
+import numpy as np
+import pytest
+
+from speakerverification_amd import synth
+from speakerverification_amd.model import ModelHandling, SpeakerEncoder, WrappedModel
+from tests.e2e_data import E2E_SEED_W, make_e2e_files
+
+pytestmark = pytest.mark.gpu
+
+ARGS = dict(
+    device="cuda", gpu=0, model={"name": "ECAPA_TDNN", "nOut": 192},
+    criterion={"name": "AAmSoftmaxAP", "margin": 0.25, "scale": 30},
+    classifier={"input_size": 192, "out_neurons": 10},
+    optimizer={"name": "adam", "weight_decay": 2e-5, "lr_decay": 0.95},
+    callbacks={"name": "steplr"}, features="melspectrogram", include_top=False, n_mels=80, nClasses=10,
+    lr=0.001, step_size=10, channels=[512] * 4 + [1536],
+    dataloader_options={"nPerSpeaker": 2, "num_workers": 0, "batch_size": 2},
+    audio_spec={"sample_rate": 16000, "channels": 1, "sentence_len": 2.0, "win_len": 0.025, "hop_len": 0.01},
+    augment=False, augment_options={"augment_chain": []},
+)
+
+
+@pytest.fixture(scope="module")
+def handler(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("e2e"))
+    net = WrappedModel(SpeakerEncoder(**ARGS))
+    mh = ModelHandling(net, **dict(ARGS, save_folder=tmp))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E_SEED_W)
+    # checkpoint round trip through the reference's layout (keys '__S__.*', torch.save / loadParameters)
+    import torch
+    ck = os.path.join(tmp, "best_state.pt")
+    torch.save({"__S__." + k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()} | {"__L__.w": torch.zeros(1)}, ck)
+    mh.loadParameters(ck, show_error=False)
+    return mh, tmp
+
+
+def test_evaluate_from_list_matches_reference(handler, golden_dir):
+    mh, tmp = handler
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    files, trial_path, lines = make_e2e_files(tmp)
+    for ne in (2, 3):
+        sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False,
+                                          dataloader_options=ARGS["dataloader_options"], cohorts_path="unused",
+                                          num_eval=ne, scoring_mode="cosine")
+        assert lab == list(g[f"labels_ne{ne}"])
+        assert tr == [ln.split()[1] + " " + ln.split()[2] for ln in lines]
+        err = float(np.abs(np.array(sc) - g[f"scores_ne{ne}"]).max())
+        assert err <= 1e-4, err            # north_star: cosine scores within 1e-4 of the reference CPU path
+
+
+def test_embed_utterance_matches_reference(handler, golden_dir):
+    mh, tmp = handler
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    files, _, _ = make_e2e_files(tmp)
+    e = mh.embed_utterance(files[0], num_eval=3, normalize=True).numpy()
+    assert e.shape == g["embed_utt0_ne3"].shape == (3, 192)
+    assert float(np.abs(e - g["embed_utt0_ne3"]).max()) <= 1e-4
+    a = (0.25 * np.sin(np.arange(40000) / 7.0)).astype(np.float32)
+    e2 = mh.embed_utterance(a, num_eval=2, normalize=False).numpy()
+    ref = g["embed_array_ne2"]
+    assert float(np.abs(e2 - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_single_crop_returns_vector_like_the_reference():
+    """SpeakerEncoder.forward on one row -> (nOut,) (stack(dim=1).squeeze(), src/model.py:125)."""
+    enc = SpeakerEncoder(**ARGS)
+    out = enc.forward(synth.synth_waveforms(1))
+    assert tuple(out.shape) == (192,)
+    out = enc.forward(synth.synth_waveforms(3))
+    assert tuple(out.shape) == (3, 192)

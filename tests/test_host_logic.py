@@ -1,0 +1,187 @@
+"""CPU: host-side logic of the drop-in layer (audio cropping, trial-list plumbing, batched scoring
+statements, multi-process sharding over gloo) — no GPU, the Engine is replaced by tests/fakes.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring as o_scoring
+from speakerverification_amd import audio, distributed as sv_dist, scoring
+from speakerverification_amd import model as sv_model
+from tests import fakes
+from tests.e2e_data import make_e2e_files
+
+
+def test_loadwav_matches_reference_cropping(golden_dir):
+    g = np.load(os.path.join(golden_dir, "crop.npz"))
+    spec = {"sample_rate": 16000, "channels": 1, "sentence_len": 2.0, "win_len": 0.025, "hop_len": 0.01}
+    rng = np.random.Generator(np.random.PCG64(77))
+    for name in ("long", "short", "exact", "long10"):
+        n, ne = int(g[name + "_len"]), int(g[name + "_num_eval"])
+        a = (0.3 * rng.standard_normal(n)).astype(np.float32)
+        got = audio.loadWAV(a, spec, evalmode=True, num_eval=ne)
+        assert got.shape == (ne, 32000) and got.dtype == np.float32
+        assert np.array_equal(got[:, :4], g[name + "_first"]) and np.array_equal(got[:, -4:], g[name + "_last"])
+    whole = audio.loadWAV((0.3 * rng.standard_normal(40000)).astype(np.float32), spec, num_eval=0)
+    assert whole.shape == (1, 40000)
+    with pytest.raises(NotImplementedError):
+        audio.loadWAV(np.zeros(10, np.float32), spec, evalmode=False)
+
+
+def test_wav_reader_scaling(tmp_path):
+    files, _, _ = make_e2e_files(str(tmp_path))
+    a, sr = audio.read_wav(files[0])
+    assert sr == 16000 and a.dtype == np.float32 and a.shape == (32000,) and np.abs(a).max() <= 1.0
+
+
+@pytest.fixture
+def fake_engine(monkeypatch):
+    eng = fakes.FakeScoringEngine()
+    monkeypatch.setattr(scoring, "scoring_engine", lambda device=0: eng)
+    return eng
+
+
+def test_score_trials_equals_reference_per_trial_loop(fake_engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "scoring.npz"))
+    Rn = torch.nn.functional.normalize(torch.from_numpy(g["R"]), p=2, dim=2).numpy()
+    Cn = torch.nn.functional.normalize(torch.from_numpy(g["C"]), p=2, dim=2).numpy()
+    n = Rn.shape[0]
+    feats = np.concatenate([Rn, Cn])                     # (2n files, 3 crops, D)
+    ia, ib = np.arange(n), np.arange(n, 2 * n)
+    assert np.abs(scoring.score_trials(feats, ia, ib, "cosine") - g["cosine"]).max() < 1e-5
+    assert np.abs(scoring.score_trials(feats, ia, ib, "norm", cohorts=g["cohort"], top=int(g["top"])) - g["zt_norm"]).max() < 1e-4
+    assert np.abs(scoring.score_trials(feats, ia, ib, "pnorm") - g["pnorm"]).max() < 1e-5
+    assert scoring.score_trials(feats, ia[:0], ib[:0], "cosine").shape == (0,)
+    # per-trial compatibility signature (utils.py:126-132)
+    assert abs(scoring.similarity_measure("cosine", torch.from_numpy(Rn[0]), torch.from_numpy(Cn[0])) - g["cosine"][0]) < 1e-5
+    assert abs(scoring.similarity_measure("zt_norm", Rn[0], Cn[0], cohorts=g["cohort"], top=int(g["top"])) - g["zt_norm"][0]) < 1e-4
+
+
+class _FakeS:
+    def eval(self): return self
+    def state_dict(self): return {}
+
+
+def _make_handler(tmp_path, dim=16):
+    enc = sv_model.SpeakerEncoder.__new__(sv_model.SpeakerEncoder)
+    enc.model = {"name": "ECAPA_TDNN", "nOut": dim}
+    enc.criterion = {"name": "AAmSoftmaxAP"}
+    enc.test_normalize = True
+    enc.features = "melspectrogram"
+    enc.__S__ = _FakeS()
+    emb = fakes.fake_embedder(dim)
+    enc.forward = lambda data, label=None: emb(data.reshape(-1, data.shape[-1]))
+    net = sv_model.WrappedModel(enc)
+    net.forward = lambda x, label=None: enc.forward(x)
+    spec = {"sample_rate": 16000, "channels": 1, "sentence_len": 2.0, "win_len": 0.025, "hop_len": 0.01}
+    mh = sv_model.ModelHandling(net, audio_spec=spec, save_folder=str(tmp_path), embed_batch=5)
+    return mh, emb, spec
+
+
+def _expected_scores(files, lines, emb, spec, num_eval):
+    feats = {}
+    for f in files:
+        a, _ = audio.read_wav(f)
+        feats[f] = torch.nn.functional.normalize(torch.from_numpy(emb(o_scoring.crop_eval(a, 32000, num_eval, peak_normalize=False))), p=2, dim=1)
+    return [o_scoring.cosine_similarity(feats[l.split()[1]], feats[l.split()[2]]) for l in lines]
+
+
+def test_evaluate_from_list_plumbing(fake_engine, tmp_path):
+    files, trial_path, lines = make_e2e_files(str(tmp_path))
+    mh, emb, spec = _make_handler(tmp_path)
+    for ne in (1, 3):
+        sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={"num_workers": 0},
+                                          cohorts_path="unused", num_eval=ne, scoring_mode="cosine")
+        assert len(sc) == len(lab) == len(tr) == 28 and all(isinstance(s, float) for s in sc)
+        assert lab == [int(l.split()[0]) for l in lines]
+        assert tr == [l.split()[1] + " " + l.split()[2] for l in lines]
+        assert np.abs(np.array(sc) - np.array(_expected_scores(files, lines, emb, spec, ne))).max() < 1e-5
+    e = mh.embed_utterance(files[1], num_eval=4, normalize=True)
+    assert tuple(e.shape) == (4, 16) and np.allclose(np.linalg.norm(e.numpy(), axis=1), 1.0, atol=1e-5)
+
+
+def test_test_from_list_and_prepare(fake_engine, tmp_path):
+    files, _, _ = make_e2e_files(str(tmp_path))
+    mh, emb, spec = _make_handler(tmp_path)
+    csv_path = tmp_path / "pairs.txt"
+    csv_path.write_text("audio_1,audio_2\n" + "".join(f"{files[i]},{files[i + 1]}\n" for i in range(4)))
+    res = mh.testFromList(test_list=str(csv_path), thresh_score=0.5, cohorts_path=None, num_eval=2, scoring_mode="cosine",
+                          output_file=str(tmp_path / "out.txt"))
+    assert len(res) == 4 and res[0].startswith("utt0.wav,utt1.wav,")
+    rows = (tmp_path / "out.txt").read_text().splitlines()
+    assert rows[0] == "audio_1,audio_2,pred_label,score" and len(rows) == 5
+    meta = tmp_path / "train.txt"
+    meta.write_text("".join(f"spk{i // 4} {f}\n" for i, f in enumerate(files)))
+    out = tmp_path / "cohort.npy"
+    assert mh.prepare(save_path=str(out), prepare_type="cohorts", num_eval=2, source=str(meta)) is True
+    cohort = np.load(out)
+    assert cohort.shape == (2, 16)           # 2 speakers, first 3 files each, mean of L2-normalised crop embeddings
+    exp0 = np.concatenate([torch.nn.functional.normalize(torch.from_numpy(emb(o_scoring.crop_eval(audio.read_wav(f)[0], 32000, 2, peak_normalize=False))), dim=1).numpy()
+                           for f in files[:3]]).mean(0)
+    assert np.abs(cohort[0] - exp0).max() < 1e-5
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 9, 1000):
+        for w in (1, 2, 3, 8):
+            got = []
+            for r in range(w):
+                lo, hi, per = sv_dist.shard_bounds(n, r, w)
+                assert 0 <= hi - lo <= per
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+
+
+def _gloo_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from speakerverification_amd import scoring as sc_mod
+        eng = fakes.FakeScoringEngine()
+        sc_mod.scoring_engine = lambda device=0: eng
+        # 1. dense all-gather of ragged shards
+        n = 7
+        lo, hi, _ = sv_dist.shard_bounds(n, rank, world)
+        local = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.ones(1, 3)
+        full = sv_dist.all_gather_rows(local, n)
+        ok1 = bool(torch.equal(full, torch.arange(n, dtype=torch.float32)[:, None] * torch.ones(1, 3)))
+        # 2. evaluateFromList shards files over ranks and scores on rank 0
+        files, trial_path, lines = make_e2e_files(os.path.join(tmp, f"r{rank}"))
+        mh, emb, spec = _make_handler(tmp)
+        sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=True, dataloader_options={}, cohorts_path="x",
+                                          num_eval=2, scoring_mode="cosine")
+        q.put((rank, ok1, sc, lab))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_evaluation(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    for r in range(2):
+        os.makedirs(tmp_path / f"r{r}", exist_ok=True)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, ok1, sc, lab = q.get(timeout=120)
+        res[rank] = (ok1, sc, lab)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] and res[1][0]
+    assert len(res[0][1]) == 28 and res[1][1] == []             # rank 0 scores, other ranks return empty lists
+    # single-process answer must match
+    files, trial_path, lines = make_e2e_files(str(tmp_path / "single"))  if os.makedirs(tmp_path / "single", exist_ok=True) is None else None
+    eng = fakes.FakeScoringEngine()
+    scoring.scoring_engine = lambda device=0: eng
+    mh, emb, spec = _make_handler(tmp_path)
+    sc, _, _ = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path="x",
+                                   num_eval=2, scoring_mode="cosine")
+    assert np.abs(np.array(sc) - np.array(res[0][1])).max() < 1e-6
