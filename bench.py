@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--model", default="ecapa", choices=["ecapa", "rawnet2"], help="ecapa = headline (configs[1]); rawnet2 = configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true")
     return ap.parse_args()
@@ -167,9 +168,16 @@ def main():
 
 def run(args, rank, world, local, dev, dist):
     B, K, W = args.batch, args.steps, args.warmup
-    eng = Engine(model="ecapa", compute=args.compute, channels=CHANNELS, embed_dim=EMBED, max_batch=B,
-                 samples=SAMPLES, device=local, stream=torch.cuda.current_stream().cuda_stream)
-    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=CHANNELS), seed=1))
+    global EMBED, DOMINANT
+    if args.model == "rawnet2":
+        EMBED, DOMINANT = 320, "gemm_conv"
+        eng = Engine(model="rawnet2", compute=args.compute, embed_dim=EMBED, max_batch=B, samples=SAMPLES, device=local,
+                     stream=torch.cuda.current_stream().cuda_stream)
+        eng.load_state_dict(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=EMBED), seed=1))
+    else:
+        eng = Engine(model="ecapa", compute=args.compute, channels=CHANNELS, embed_dim=EMBED, max_batch=B,
+                     samples=SAMPLES, device=local, stream=torch.cuda.current_stream().cuda_stream)
+        eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=CHANNELS), seed=1))
     eng.finalize()
 
     # synthetic waveforms, resident in HBM before the timed region (rank-dependent seed)
@@ -229,8 +237,10 @@ def run(args, rank, world, local, dev, dist):
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
-            "config": {"workload": "ECAPA-TDNN C=1024 fbank+conv+ASP, batch=256 x 2 s @ 16 kHz per GPU per step "
-                                   "(BASELINE configs[1]), HBM-resident waveforms -> 192-d embeddings",
+            "config": {"workload": ("ECAPA-TDNN C=1024 fbank+conv+ASP, batch=256 x 2 s @ 16 kHz per GPU per step "
+                                    "(BASELINE configs[1]), HBM-resident waveforms -> 192-d embeddings") if args.model == "ecapa" else
+                                   ("RawNet2 sinc front-end + 8 residual blocks + ASP, batch=256 x 2 s @ 16 kHz per GPU per step "
+                                    "(BASELINE configs[2]), HBM-resident waveforms -> 320-d embeddings"),
                        "batch_per_gpu": B, "samples": SAMPLES, "frames": eng.frames, "embed_dim": EMBED,
                        "collective": "one all_gather_into_tensor of the shard embeddings" if world > 1 else "none"},
             "finite": ok,
@@ -241,11 +251,11 @@ def run(args, rank, world, local, dev, dist):
                          "launches": dom["launches"]},
             "kernels": kern,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "ecapa":
             line["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None
-        if world == 1 and not args.no_scoring:
+        if world == 1 and not args.no_scoring and args.model == "ecapa":
             try:
                 line["scoring"] = scoring_bench(dev)
             except Exception as e:  # scoring is reported next to, not inside, the headline

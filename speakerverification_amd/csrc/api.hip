@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,6 +69,26 @@ struct svhip_handle {
     LinearLayer se1[3], se2[3], asp_ctx, fc;
     float *aspbn_scale = nullptr, *aspbn_shift = nullptr;
     float *in_w = nullptr, *in_b = nullptr;   // instance norm affine
+
+    // RawNet2 layers (front_proc='sinc', aggregate='asp'; RawNet2_custom.py:230-243)
+    struct RnBlock {
+        int cin = 0, cout = 0;
+        bool downsample = false, has_shortcut = false;
+        float *bn1_scale = nullptr, *bn1_shift = nullptr;
+        ConvLayer conv1, conv2, shortcut;       // conv1 carries bn2 as its epilogue
+        float* alpha = nullptr;
+        LinearLayer afms_fc;
+    };
+    RnBlock rn_blocks[8];
+    float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
+    void* rn_filt = nullptr;
+    float *rn_agg_scale = nullptr, *rn_agg_shift = nullptr;
+    ConvLayer rn_att0, rn_att3;
+    LinearLayer rn_fc;
+    void* rn_buf[6] = {};                 // activation ping-pong buffers
+    float *rn_stats = nullptr, *rn_mean = nullptr, *rn_s = nullptr, *rn_logits = nullptr, *rn_pooled = nullptr;
+    int rn_T1 = 0;
+    const void* rn_dbg_x = nullptr; int rn_dbg_T = 0, rn_dbg_C = 0;   // SVHIP_RN_STOP developer hook (tests)
 
     // workspace (device)
     float* d_wav = nullptr;       // (Bmax, L)
@@ -290,8 +311,41 @@ void ecapa_spec(const svhip_config& c, std::map<std::string, std::vector<int64_t
     spec["fc.conv.weight"] = {(int64_t)c.embed_dim, 2 * C3, 1}; spec["fc.conv.bias"] = {(int64_t)c.embed_dim};
 }
 
+const int RN_LAYERS[6] = {1, 1, 1, 2, 1, 2};                   // RawNet2_custom.py:231
+const int RN_FILTERS[6] = {128, 128, 256, 256, 512, 512};      // RawNet2_custom.py:232
+
+void rawnet2_spec(const svhip_config& c, std::map<std::string, std::vector<int64_t>>& spec) {
+    auto bn = [&](const std::string& p, int64_t n) {
+        spec[p + ".weight"] = {n}; spec[p + ".bias"] = {n}; spec[p + ".running_mean"] = {n};
+        spec[p + ".running_var"] = {n}; spec[p + ".num_batches_tracked"] = {};
+    };
+    spec["ln.gamma"] = {(int64_t)c.samples}; spec["ln.beta"] = {(int64_t)c.samples};
+    spec["first_conv.low_hz_"] = {128, 1}; spec["first_conv.band_hz_"] = {128, 1};
+    bn("first_bn", 128);
+    int64_t inpl = 128;
+    for (int li = 0; li < 6; ++li)
+        for (int b = 0; b < RN_LAYERS[li]; ++b) {
+            const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int64_t planes = RN_FILTERS[li];
+            bn(p + ".bn1", inpl);
+            spec[p + ".conv1.weight"] = {planes, inpl, 3};
+            bn(p + ".bn2", planes);
+            spec[p + ".conv2.weight"] = {planes, planes, 3};
+            spec[p + ".afms.alpha"] = {planes, 1};
+            spec[p + ".afms.fc.weight"] = {planes, planes}; spec[p + ".afms.fc.bias"] = {planes};
+            if (inpl != planes) spec[p + ".shortcut.0.weight"] = {planes, inpl, 1};
+            inpl = planes;
+        }
+    bn("bn_before_agg", 512);
+    spec["attention.0.weight"] = {128, 512, 1}; spec["attention.0.bias"] = {128};
+    bn("attention.2", 128);
+    spec["attention.3.weight"] = {512, 128, 1}; spec["attention.3.bias"] = {512};
+    spec["fc.weight"] = {(int64_t)c.embed_dim, 1024}; spec["fc.bias"] = {(int64_t)c.embed_dim};
+}
+
 void model_spec(const svhip_config& c, std::map<std::string, std::vector<int64_t>>& spec) {
     if (c.model == SVHIP_MODEL_ECAPA) ecapa_spec(c, spec);
+    else if (c.model == SVHIP_MODEL_RAWNET2) rawnet2_spec(c, spec);
 }
 
 const HostTensor* getw(svhip_handle* h, const std::string& name) {
@@ -418,6 +472,92 @@ int finalize_ecapa(svhip_handle* h) {
     return SVHIP_OK;
 }
 
+int upload_f32(svhip_handle* h, const std::string& name, float** dst) {
+    const HostTensor* t = getw(h, name);
+    if (!t) SV_FAIL(h, SVHIP_ERR_MISSING, "missing tensor %s", name.c_str());
+    return dev_upload(h, dst, t->data);
+}
+
+// sinc band-pass filters baked once per weight load (RawNet_baseline.py:313-318,339-357), float32 arithmetic
+int bake_sinc(svhip_handle* h) {
+    const HostTensor *lo = getw(h, "first_conv.low_hz_"), *bd = getw(h, "first_conv.band_hz_");
+    if (!lo || !bd) SV_FAIL(h, SVHIP_ERR_MISSING, "missing sinc parameters");
+    const int NF = 128, KS = 251, HALF = 125;
+    const float sr = 16000.0f, min_low = 50.0f, min_band = 50.0f;
+    const float PI = 3.14159265358979323846f;
+    std::vector<float> win(HALF), n_(HALF);
+    for (int i = 0; i < HALF; ++i) {
+        const float n_lin = (float)(124.5 * i / 124.0);                         // torch.linspace(0, 124.5, 125)
+        win[i] = 0.54f - 0.46f * std::cos(2.0f * PI * n_lin / (float)KS);
+        n_[i] = 2.0f * PI * (float)(-125 + i) / sr;                             // 2*pi*arange(-125, 0)/16000
+    }
+    std::vector<float> filt((size_t)NF * KS);
+    for (int f = 0; f < NF; ++f) {
+        const float low = min_low + std::fabs(lo->data[f]);
+        float high = low + min_band + std::fabs(bd->data[f]);
+        high = std::fmin(std::fmax(high, min_low), sr / 2);
+        const float band = high - low;
+        for (int i = 0; i < HALF; ++i) {
+            const float left = ((std::sin(high * n_[i]) - std::sin(low * n_[i])) / (n_[i] / 2.0f)) * win[i];
+            filt[(size_t)f * KS + i] = left / (2.0f * band);
+            filt[(size_t)f * KS + (KS - 1 - i)] = left / (2.0f * band);
+        }
+        filt[(size_t)f * KS + HALF] = (2.0f * band) / (2.0f * band);
+    }
+    int rc;
+    if (h->bf16) {
+        std::vector<uint16_t> pk((size_t)NF * 256, 0);
+        for (int f = 0; f < NF; ++f)
+            for (int k = 0; k < KS; ++k) pk[(size_t)f * 256 + k] = f32_to_bf16_rne(filt[(size_t)f * KS + k]);
+        uint16_t* d;
+        if ((rc = dev_upload(h, &d, pk))) return rc;
+        h->rn_filt = d;
+    } else {
+        std::vector<float> pk((size_t)NF * 252, 0.0f);
+        for (int f = 0; f < NF; ++f)
+            for (int k = 0; k < KS; ++k) pk[(size_t)f * 252 + k] = filt[(size_t)f * KS + k];
+        float* d;
+        if ((rc = dev_upload(h, &d, pk))) return rc;
+        h->rn_filt = d;
+    }
+    return SVHIP_OK;
+}
+
+int finalize_rawnet2(svhip_handle* h) {
+    int rc;
+    if ((rc = upload_f32(h, "ln.gamma", &h->rn_gamma))) return rc;
+    if ((rc = upload_f32(h, "ln.beta", &h->rn_beta))) return rc;
+    if ((rc = bake_sinc(h))) return rc;
+    if ((rc = make_bn(h, "first_bn", 128, &h->rn_fbn_scale, &h->rn_fbn_shift))) return rc;
+    int inpl = 128, bi = 0;
+    int T = h->rn_T1;
+    double fl = 2.0 * 128 * 251 * (double)(h->cfg.samples - 250);
+    for (int li = 0; li < 6; ++li)
+        for (int b = 0; b < RN_LAYERS[li]; ++b, ++bi) {
+            svhip_handle::RnBlock& B = h->rn_blocks[bi];
+            const std::string p = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int planes = RN_FILTERS[li];
+            B.cin = inpl; B.cout = planes; B.downsample = (b == RN_LAYERS[li] - 1); B.has_shortcut = inpl != planes;
+            if ((rc = make_bn(h, p + ".bn1", inpl, &B.bn1_scale, &B.bn1_shift))) return rc;
+            if ((rc = make_conv(h, B.conv1, p + ".conv1.weight", "", p + ".bn2", 1))) return rc;
+            if ((rc = make_conv(h, B.conv2, p + ".conv2.weight", "", "", 1))) return rc;
+            if (B.has_shortcut && (rc = make_conv(h, B.shortcut, p + ".shortcut.0.weight", "", "", 1))) return rc;
+            if ((rc = upload_f32(h, p + ".afms.alpha", &B.alpha))) return rc;
+            if ((rc = make_linear(h, B.afms_fc, p + ".afms.fc.weight", p + ".afms.fc.bias"))) return rc;
+            fl += (double)T * (B.conv1.flops_per_row + B.conv2.flops_per_row + (B.has_shortcut ? B.shortcut.flops_per_row : 0.0));
+            fl += 2.0 * planes * planes;
+            if (B.downsample) T /= 3;
+            inpl = planes;
+        }
+    if ((rc = make_bn(h, "bn_before_agg", 512, &h->rn_agg_scale, &h->rn_agg_shift))) return rc;
+    if ((rc = make_conv(h, h->rn_att0, "attention.0.weight", "attention.0.bias", "attention.2", 1))) return rc;
+    if ((rc = make_conv(h, h->rn_att3, "attention.3.weight", "attention.3.bias", "", 1))) return rc;
+    if ((rc = make_linear(h, h->rn_fc, "fc.weight", "fc.bias"))) return rc;
+    fl += (double)T * (h->rn_att0.flops_per_row + h->rn_att3.flops_per_row) + 2.0 * h->rn_fc.N * h->rn_fc.K;
+    h->flops_per_utt = fl;
+    return SVHIP_OK;
+}
+
 int alloc_workspace(svhip_handle* h) {
     const svhip_config& c = h->cfg;
     const size_t B = c.max_batch, T = h->T, M = B * T, C = c.channels, C3 = 3 * C, e = h->esz;
@@ -426,6 +566,23 @@ int alloc_workspace(svhip_handle* h) {
     if ((rc = dev_alloc(h, &h->d_feat, B * c.n_mels * T))) return rc;
     if ((rc = dev_alloc(h, &h->d_pstats, B * c.n_mels * 2))) return rc;
     if ((rc = dev_alloc(h, &h->d_emb, B * (size_t)c.embed_dim))) return rc;
+    if (c.model == SVHIP_MODEL_RAWNET2) {
+        h->rn_T1 = (c.samples - 250) / 3;
+        const size_t per_utt = (size_t)h->rn_T1 * 128;           // largest activation: (T1, 128); later stages shrink 3x per doubling
+        for (int i = 0; i < 6; ++i) {
+            char* q;
+            if ((rc = dev_alloc(h, &q, B * per_utt * e + 256))) return rc;
+            h->rn_buf[i] = q;
+        }
+        if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_mean, B * 512))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_s, B * 512))) return rc;
+        int tf = h->rn_T1;
+        for (int i = 0; i < 6; ++i) tf /= 3;                      // six max_pool1d(3) stages follow the front-end
+        if (tf < 1) SV_FAIL(h, SVHIP_ERR_INVALID, "utterance too short for RawNet2 (%d samples)", c.samples);
+        if ((rc = dev_alloc(h, &h->rn_logits, B * (size_t)tf * 512))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_pooled, B * 1024))) return rc;
+    }
     if (c.model == SVHIP_MODEL_ECAPA) {
         char* p;
         auto actbuf = [&](void** dst, size_t elems) -> int {
@@ -456,13 +613,14 @@ int alloc_workspace(svhip_handle* h) {
 // ---- GEMM call helper -------------------------------------------------------------------------------
 int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void* A, int lda, void* Y, int ldy, int M,
               int act1, int act2 = ACT_NONE, const void* A2 = nullptr, int lda2 = 0, const float* bias_utt = nullptr,
-              int ld_bu = 0, bool out_f32 = false) {
+              int ld_bu = 0, bool out_f32 = false, int T = 0, int pad_mode = PAD_REFLECT, const void* R = nullptr, int ldr = 0) {
     GemmParams p;
+    p.R = R; p.ldr = ldr;
     p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
     p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
     p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np;
     p.lda = lda; p.lda2 = lda2; p.ldy = ldy; p.ld_bu = ld_bu;
-    p.T = h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = PAD_REFLECT;
+    p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
     const bool bf = h->bf16;
     hipStream_t st = h->stream;
@@ -552,6 +710,64 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     return SVHIP_OK;
 }
 
+// RawNet2.forward (models/RawNet2_custom.py:161-227) on device-resident waveforms (B, L)
+int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
+    const svhip_config& c = h->cfg;
+    const bool bf = h->bf16;
+    hipStream_t st = h->stream;
+    const int L = c.samples;
+    int rc;
+    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, h->rn_stats, st); }))) return rc;
+    int T = h->rn_T1;
+    void *x = h->rn_buf[0], *pre = h->rn_buf[1], *hb = h->rn_buf[2], *o = h->rn_buf[3], *sc = h->rn_buf[4], *xn = h->rn_buf[5];
+    if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
+             return launch_rn_sinc(d_wav, h->rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
+         }))) return rc;
+    const char* stop_env = getenv("SVHIP_RN_STOP");          // developer hook: stop after N blocks, expose x as stage "rn_x"
+    const int stop_after = stop_env ? atoi(stop_env) : -1;
+    h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
+    for (int bi = 0; bi < 8; ++bi) {
+        if (stop_after >= 0 && bi >= stop_after) { h->lastB = B; return SVHIP_OK; }
+        svhip_handle::RnBlock& K = h->rn_blocks[bi];
+        const int M = B * T;
+        // out = lrelu(bn1(x))                                                         RawNet_baseline.py:222
+        if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
+        const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
+        if (K.has_shortcut) {
+            if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
+            resid = sc;
+        }
+        // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
+        if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
+        if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, K.cout))) return rc;
+        void* y = o;
+        if (K.downsample) {                                                          // :228-229
+            if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, bf, B, T, K.cout, st); }))) return rc;
+            T /= 3;
+            y = hb;
+        }
+        // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
+        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, h->rn_mean, st); }))) return rc;
+        if ((rc = run(h, "rn_afms_fc", 2.0 * B * K.cout * K.cout, [&]() {
+                 return launch_rowvec_linear(h->rn_mean, K.cout, K.afms_fc.W, K.afms_fc.bias, h->rn_s, K.cout, B, K.cout, K.cout, ACT_SIGMOID, st);
+             }))) return rc;
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, h->rn_s, B, T, K.cout, st); }))) return rc;
+        std::swap(x, xn);
+        h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
+    }
+    // aggregation: attentive statistics pooling                                          RawNet2_custom.py:215-224
+    const int M = B * T;
+    if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, h->rn_agg_scale, h->rn_agg_shift, M, 512, 0.3f, st); }))) return rc;
+    if ((rc = conv_gemm(h, "rn_gemm", h->rn_att0, pre, 512, hb, 128, M, ACT_LRELU001))) return rc;
+    if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, h->rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
+    if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(h->rn_logits, pre, bf, B, T, 512, h->rn_pooled, st); }))) return rc;
+    if ((rc = run(h, "rn_fc", 2.0 * B * h->rn_fc.N * h->rn_fc.K, [&]() {
+             return launch_rowvec_linear(h->rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, h->d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st);
+         }))) return rc;
+    h->lastB = B;
+    return SVHIP_OK;
+}
+
 int check_ready(svhip_handle* h, int B) {
     if (!h) return SVHIP_ERR_INVALID;
     if (!h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights not finalized (call svhip_finalize_weights first)");
@@ -600,6 +816,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return SVHIP_ERR_INVALID; }
     if (cfg->model != SVHIP_MODEL_ECAPA && cfg->model != SVHIP_MODEL_RAWNET2 && cfg->model != SVHIP_MODEL_NONE) { g_create_error = "unknown model"; return SVHIP_ERR_INVALID; }
     if (cfg->model == SVHIP_MODEL_ECAPA && (cfg->channels <= 0 || cfg->channels % 64 != 0)) { g_create_error = "ECAPA channels must be a positive multiple of 64"; return SVHIP_ERR_INVALID; }
+    if (cfg->model == SVHIP_MODEL_RAWNET2 && cfg->samples < 251 + 3 * 3 * 3 * 3 * 3 * 3 * 3) { g_create_error = "RawNet2 needs at least 2438 samples"; return SVHIP_ERR_INVALID; }
     if (cfg->n_mels <= 0 || cfg->n_mels % 8 != 0 || cfg->max_batch <= 0 || cfg->samples < cfg->n_fft || cfg->hop_length <= 0) { g_create_error = "bad n_mels / max_batch / samples"; return SVHIP_ERR_INVALID; }
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SVHIP_ERR_HIP; }
     svhip_handle* h = new svhip_handle();
@@ -669,6 +886,7 @@ int svhip_finalize_weights(svhip_handle* h) {
             SV_FAIL(h, SVHIP_ERR_MISSING, "tensor %s was never loaded", kv.first.c_str());
     int rc = SVHIP_ERR_UNSUPPORTED;
     if (h->cfg.model == SVHIP_MODEL_ECAPA) rc = finalize_ecapa(h);
+    else if (h->cfg.model == SVHIP_MODEL_RAWNET2) rc = finalize_rawnet2(h);
     else SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "model %d has no forward path in this build", h->cfg.model);
     if (rc) return rc;
     SV_HIP(h, hipDeviceSynchronize());
@@ -725,16 +943,21 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
     if (L != h->cfg.samples) SV_FAIL(h, SVHIP_ERR_INVALID, "L=%d but the handle was created for %d samples", L, h->cfg.samples);
     if ((flags & SVHIP_ASYNC) && (flags & (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE)) != (SVHIP_IN_DEVICE | SVHIP_OUT_DEVICE))
         SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs device pointers");
-    if (h->cfg.model != SVHIP_MODEL_ECAPA) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "model %d has no forward path in this build", h->cfg.model);
+    if (h->cfg.model != SVHIP_MODEL_ECAPA && h->cfg.model != SVHIP_MODEL_RAWNET2)
+        SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "model %d has no forward path in this build", h->cfg.model);
     SV_HIP(h, hipSetDevice(h->cfg.device));
     const float* d_in = wav;
     if (!(flags & SVHIP_IN_DEVICE)) {
         SV_HIP(h, hipMemcpyAsync(h->d_wav, wav, (size_t)B * L * 4, hipMemcpyHostToDevice, h->stream));
         d_in = h->d_wav;
     }
-    const int T = h->T;
-    if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
-    if ((rc = ecapa_forward(h, h->d_feat, B))) return rc;
+    if (h->cfg.model == SVHIP_MODEL_RAWNET2) {
+        if ((rc = rawnet2_forward(h, d_in, B))) return rc;
+    } else {
+        const int T = h->T;
+        if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
+        if ((rc = ecapa_forward(h, h->d_feat, B))) return rc;
+    }
     const size_t bytes = (size_t)B * h->cfg.embed_dim * 4;
     SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, bytes, (flags & SVHIP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
     return finish(h, flags);
@@ -899,6 +1122,7 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     else if (n == "mfa") { src = h->MFA; cols = ld = C3; }
     else if (n == "asp") { src = h->d_pool_raw; rows = B; cols = ld = 2 * C3; f32 = true; }
     else if (n == "asp_bn") { src = h->d_pool_bn; rows = B; cols = ld = 2 * C3; f32 = true; }
+    else if (n == "rn_x") { src = h->rn_dbg_x; rows = (size_t)B * h->rn_dbg_T; cols = ld = h->rn_dbg_C; }
     else if (n == "mel") { src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true; }
     else SV_FAIL(h, SVHIP_ERR_INVALID, "unknown stage %s", name);
     *count = (int64_t)(rows * cols);

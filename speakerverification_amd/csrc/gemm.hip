@@ -63,7 +63,7 @@ template <> struct MmaTraits<bf16_t> {
 
 // activation pairs used by the models, fixed at compile time (a runtime switch inlined 128 times
 // made the epilogue 30k instructions long and blew the instruction cache)
-enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_RELU_TANH = 3, EPI_LRELU03 = 4 };
+enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_RELU_TANH = 3, EPI_LRELU03 = 4, EPI_BN_LRELU03 = 5, EPI_LRELU001 = 6 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on the fast exp / rcp units: bf16 path only
 __device__ __forceinline__ float gelu_fast(float x) {
@@ -85,6 +85,7 @@ __device__ __forceinline__ float epilogue_act1(float v) {
     if (EPI == EPI_RELU || EPI == EPI_RELU_TANH) return fmaxf(v, 0.0f);
     if (EPI == EPI_GELU) return sizeof(T) == 2 ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (EPI == EPI_LRELU03) return v > 0.0f ? v : 0.3f * v;
+    if (EPI == EPI_LRELU001) return v > 0.0f ? v : 0.01f * v;
     return v;
 }
 
@@ -240,6 +241,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                     v = epilogue_act1<T, EPI>(v);
                     v = fmaf(v, sc, sh);
                     if (EPI == EPI_RELU_TANH) v = tanhf(v);
+                    if (EPI == EPI_BN_LRELU03) v = v > 0.0f ? v : 0.3f * v;
+                    if (p.R) v += to_f32<T>(reinterpret_cast<const T*>(p.R)[(int64_t)m * p.ldr + n]);
                     if (out_f32) reinterpret_cast<float*>(p.Y)[(int64_t)m * p.ldy + n] = v;
                     else reinterpret_cast<bf16_t*>(p.Y)[(int64_t)m * p.ldy + n] = static_cast<bf16_t>(v);
                 }
@@ -279,6 +282,8 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
     if (p.act1 == ACT_GELU && p.act2 == ACT_NONE) return launch_epi<T, EPI_GELU>(p, stream);
     if (p.act1 == ACT_RELU && p.act2 == ACT_TANH) return launch_epi<T, EPI_RELU_TANH>(p, stream);
     if (p.act1 == ACT_LRELU03 && p.act2 == ACT_NONE) return launch_epi<T, EPI_LRELU03>(p, stream);
+    if (p.act1 == ACT_NONE && p.act2 == ACT_LRELU03) return launch_epi<T, EPI_BN_LRELU03>(p, stream);
+    if (p.act1 == ACT_LRELU001 && p.act2 == ACT_NONE) return launch_epi<T, EPI_LRELU001>(p, stream);
     return hipErrorInvalidValue;
 }
 

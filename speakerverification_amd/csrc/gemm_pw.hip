@@ -52,7 +52,7 @@ template <int BN> struct TileCfg {
     static constexpr int LOADS = (PBM + BN) / 64;              // global_load_lds per thread per K-step: 6 / 8
 };
 
-enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_RELU_TANH = 3, EPI_LRELU03 = 4 };
+enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_RELU_TANH = 3, EPI_LRELU03 = 4, EPI_BN_LRELU03 = 5, EPI_LRELU001 = 6 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -73,6 +73,7 @@ __device__ __forceinline__ float act1(float v) {
     if (EPI == EPI_RELU || EPI == EPI_RELU_TANH) return fmaxf(v, 0.0f);
     if (EPI == EPI_GELU) return sizeof(T) == 2 ? gelu_fast(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (EPI == EPI_LRELU03) return v > 0.0f ? v : 0.3f * v;
+    if (EPI == EPI_LRELU001) return v > 0.0f ? v : 0.01f * v;
     return v;
 }
 
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
                     t = act1<T, EPI>(t);
                     t = fmaf(t, sc4[e], sh4[e]);
                     if (EPI == EPI_RELU_TANH) t = tanhf(t);
+                    if (EPI == EPI_BN_LRELU03) t = t > 0.0f ? t : 0.3f * t;
                     v[e] = t;
                 }
                 if (OUT_F32) {
@@ -296,6 +298,8 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     if (p.act1 == ACT_GELU && p.act2 == ACT_NONE) return launch_inst<T, EPI_GELU, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_RELU && p.act2 == ACT_TANH) return launch_inst<T, EPI_RELU_TANH, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_LRELU03 && p.act2 == ACT_NONE) return launch_inst<T, EPI_LRELU03, OUT_F32, BN>(p, stream);
+    if (p.act1 == ACT_NONE && p.act2 == ACT_LRELU03) return launch_inst<T, EPI_BN_LRELU03, OUT_F32, BN>(p, stream);
+    if (p.act1 == ACT_LRELU001 && p.act2 == ACT_NONE) return launch_inst<T, EPI_LRELU001, OUT_F32, BN>(p, stream);
     return hipErrorInvalidValue;
 }
 
@@ -304,7 +308,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     const int epc = bf16 ? 8 : 4;
     const int bk = bf16 ? 64 : 32;
-    if (p.taps > 1 || p.A2) return false;
+    if (p.taps > 1 || p.A2 || p.R) return false;
     if (p.K != p.Kp || p.Kp % bk != 0) return false;         // every K chunk of every row must be real data
     if (p.N % 8 != 0 || p.lda % epc != 0) return false;
     const bool out_f32 = !bf16 || p.out_f32;

@@ -22,6 +22,8 @@ struct GemmParams {
     const float* bias_utt = nullptr;
     const float* scale = nullptr;
     const float* shift = nullptr;
+    const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last (generic kernel only)
+    int ldr = 0;
     int M = 0, N = 0, K = 0, Kp = 0;
     int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
     int T = 1;
@@ -124,6 +126,21 @@ struct AspFusedParams {
 };
 bool asp_fused_supported(int T, int C, int att_channels, int Kp);
 hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// RawNet2 (rawnet2.hip)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream);
+// LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
+hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
+                          const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
+                          hipStream_t stream);
+hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
+                            float slope, hipStream_t stream);
+hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream);
+hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
+                                hipStream_t stream);
+hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Scoring

@@ -1,0 +1,317 @@
+// rawnet2.hip — RawNet2 (sinc front-end, ASP aggregation) kernels that are not plain GEMMs.
+// Reference: models/RawNet2_custom.py:161-227, models/RawNet_baseline.py:13-24 (LayerNorm),
+// :62-68 (AFMS), :221-232 (RawNetBasicBlock), :320-361 (SincConv_fast).
+//
+//   rn_ln_stats   : per-utterance mean and 1/(unbiased std + 1e-6) over the L samples
+//   rn_sinc       : LayerNorm apply + sinc conv (k = 251, valid) + |.| + max_pool1d(3) + BN + LeakyReLU(0.3)
+//                   in ONE kernel: the (B, 128, 31750) conv output never exists.  The conv is an MFMA
+//                   product whose "im2col" operand is read straight out of an LDS copy of the waveform
+//                   (hop 1 => rows overlap in all but one sample).  MFMA tile (g, j) holds conv positions
+//                   3*(32g + r) + j, so the three max-pool partners of a pooled frame sit in the same
+//                   lane / register of three accumulators and the pool is an elementwise max.
+//                   bf16: v_mfma_f32_32x32x16_bf16, operand fetched as aligned 16-byte reads from 8
+//                   sample-shifted LDS copies;  fp32: v_mfma_f32_32x32x2_f32 with 4-byte reads.
+//   rn_bn_act     : y = LeakyReLU(x*scale + shift)                       (pre-activation of the blocks)
+//   rn_maxpool3   : max_pool1d(3) along frames
+//   rn_afms_apply : (x + alpha) * s[b, c]                                (AFMS, RawNet_baseline.py:66-67)
+//   rn_attn_pool  : softmax over frames, m = sum x w, s = sqrt(clamp(sum x^2 w - m^2, 1e-5))
+#include "common.h"
+#include "kernels.h"
+
+namespace svhip {
+
+namespace {
+
+__global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restrict__ x, int L, float* __restrict__ stats) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* __restrict__ p = x + (int64_t)b * L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < L; i += 256) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)L;
+    __syncthreads();
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < L; i += 256) { const float d = p[i] - mean; q = fmaf(d, d, q); }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float var = (red[0] + red[1] + red[2] + red[3]) / (float)(L - 1);      // torch.std: unbiased
+        stats[2 * b] = mean;
+        stats[2 * b + 1] = 1.0f / (sqrtf(var) + 1e-6f);
+    }
+}
+
+constexpr int SINC_PT = 64;                 // pooled frames per iteration
+constexpr int SINC_POS = 3 * SINC_PT;       // conv positions per iteration
+constexpr int SINC_SAMPLES = 464;           // >= SINC_POS + 255 + 8, multiple of 8
+
+template <typename T> struct SincCfg;
+template <> struct SincCfg<bf16_t> {
+    static constexpr int KSTEPS = 16;                       // K = 256 (251 taps zero padded) in steps of 16
+    static constexpr int COPY_BYTES = SINC_SAMPLES * 2 + 32;   // +32: successive copies start 2 bank-slots apart
+    static constexpr int LDS = 8 * COPY_BYTES;
+};
+template <> struct SincCfg<float> {
+    static constexpr int KSTEPS = 126;                      // K = 252 in steps of 2
+    static constexpr int LDS = SINC_SAMPLES * 4;
+};
+
+// filters: bf16: [128][256] bf16 (k contiguous); fp32: [128][252] fp32.
+template <typename T>
+__global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict__ wav, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const void* __restrict__ filt, const float* __restrict__ bn_scale,
+                                                         const float* __restrict__ bn_shift, T* __restrict__ out, int L, int T1,
+                                                         int tiles_per_wg) {
+    typedef SincCfg<T> CF;
+    constexpr bool BF = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // n-tile: filters wave*32 .. +31
+    const int fr = lane & 31, fh = lane >> 5;
+    const float mean = stats[2 * b], inv = stats[2 * b + 1];
+    const float* __restrict__ x = wav + (int64_t)b * L;
+
+    // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand)
+    bf16x8 wfb[BF ? 16 : 1];
+    float wff[BF ? 1 : 126];
+    if (BF) {
+        const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(wave * 32 + fr) * 256 * 2 + fh * 16;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wfb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 32);
+    } else {
+        const float* w = reinterpret_cast<const float*>(filt) + (int64_t)(wave * 32 + fr) * 252 + fh;
+#pragma unroll
+        for (int kk = 0; kk < 126; ++kk) wff[kk] = w[2 * kk];
+    }
+
+    for (int it = 0; it < tiles_per_wg; ++it) {
+        const int tp0 = (blockIdx.x * tiles_per_wg + it) * SINC_PT;
+        if (tp0 >= T1) break;                                        // workgroup-uniform
+        const int s0 = 3 * tp0;                                      // first sample of this tile
+        __syncthreads();                                             // previous tile's reads are done
+        for (int i = tid; i < SINC_SAMPLES; i += 256) {
+            const int j = s0 + i;
+            float v = 0.0f;
+            if (j < L) v = gamma[j] * (x[j] - mean) * inv + beta[j];          // RawNet_baseline.py:24
+            if (BF) {
+                const bf16_t bv = static_cast<bf16_t>(v);
+#pragma unroll
+                for (int p = 0; p < 8; ++p)                                   // copy p holds the tile shifted by p samples
+                    if (i - p >= 0) *reinterpret_cast<bf16_t*>(smem + p * CF::LDS / 8 + (i - p) * 2) = bv;
+            } else {
+                reinterpret_cast<float*>(smem)[i] = v;
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+        if (BF) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int s = 3 * (32 * g + fr) + j;                      // conv position inside the tile
+                    const char* base = smem + (s & 7) * (CF::LDS / 8) + ((s >> 3) + fh) * 16;
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
+                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[kk], xf, acc[g][j], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float* base = reinterpret_cast<const float*>(smem) + 3 * (32 * g + fr) + j + fh;
+#pragma unroll
+                    for (int kk = 0; kk < 126; ++kk)
+                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wff[kk], base[2 * kk], acc[g][j], 0, 0, 0);
+                }
+        }
+        // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 filters per group
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int tp = tp0 + 32 * g + fr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = wave * 32 + 8 * q + 4 * fh;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_scale + f);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(bn_shift + f);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const float m = fmaxf(fmaxf(fabsf(acc[g][0][r]), fabsf(acc[g][1][r])), fabsf(acc[g][2][r]));
+                    const float y = fmaf(m, sc[e], sh[e]);
+                    v[e] = y > 0.0f ? y : 0.3f * y;
+                }
+                if (tp < T1) {
+                    T* o = out + ((int64_t)b * T1 + tp) * 128 + f;
+                    if (BF) {
+                        typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 pk = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+                        *reinterpret_cast<bf16x4*>(o) = pk;
+                    } else {
+                        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rn_bn_act_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int C, float slope, int64_t chunks) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpr = C / VEC;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < chunks; id += (int64_t)gridDim.x * 256) {
+        const int c = (int)(id % cpr) * VEC;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + id * VEC), o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float t = fmaf(v.get(j), scale[c + j], shift[c + j]);
+            o.set(j, t > 0.0f ? t : slope * t);
+        }
+        *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rn_maxpool3_kernel(const T* __restrict__ x, T* __restrict__ y, int Tin, int Tout, int C,
+                                                          int64_t chunks) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpr = C / VEC;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < chunks; id += (int64_t)gridDim.x * 256) {
+        const int c = (int)(id % cpr) * VEC;
+        const int64_t row = id / cpr;                       // b * Tout + t
+        const int64_t b = row / Tout;
+        const int t = (int)(row - b * Tout);
+        const T* p = x + ((b * Tin + 3 * t) * (int64_t)C + c);
+        Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(p), bb = *reinterpret_cast<const Vec16<T>*>(p + C),
+                 cc = *reinterpret_cast<const Vec16<T>*>(p + 2 * C), o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), cc.get(j)));
+        *reinterpret_cast<Vec16<T>*>(y + row * C + c) = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ alpha,
+                                                            const float* __restrict__ s, int Tn, int C, int64_t chunks) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cpr = C / VEC;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < chunks; id += (int64_t)gridDim.x * 256) {
+        const int c = (int)(id % cpr) * VEC;
+        const int64_t b = (id / cpr) / Tn;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + id * VEC), o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.set(j, (v.get(j) + alpha[c + j]) * s[b * C + c + j]);
+        *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;
+    }
+}
+
+// one thread per (b, c): softmax over the Tn (= 14) frames of the fp32 logits, weighted mean / std of x
+template <typename T>
+__global__ __launch_bounds__(256) void rn_attn_pool_kernel(const float* __restrict__ logits, const T* __restrict__ x, int Tn, int C,
+                                                           float* __restrict__ out, int B) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= B * C) return;
+    const int b = id / C, c = id - b * C;
+    const float* lg = logits + (int64_t)b * Tn * C + c;
+    const T* xp = x + (int64_t)b * Tn * C + c;
+    float mx = -INFINITY;
+    for (int t = 0; t < Tn; ++t) mx = fmaxf(mx, lg[(int64_t)t * C]);
+    float se = 0.0f;
+    for (int t = 0; t < Tn; ++t) se += expf(lg[(int64_t)t * C] - mx);
+    float m = 0.0f, q = 0.0f;
+    for (int t = 0; t < Tn; ++t) {
+        const float w = expf(lg[(int64_t)t * C] - mx) / se;
+        const float xv = to_f32<T>(xp[(int64_t)t * C]);
+        m = fmaf(xv, w, m);
+        q = fmaf(xv * xv, w, q);
+    }
+    out[(int64_t)b * 2 * C + c] = m;
+    out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q - m * m, 1e-5f));
+}
+
+inline int grid_for(int64_t items) {
+    int64_t g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(rn_ln_stats_kernel, dim3(B), dim3(256), 0, stream, wav, L, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
+                          const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
+                          hipStream_t stream) {
+    if (T1 != (L - 250) / 3 || L < 251 + 3) return hipErrorInvalidValue;
+    const int tiles = (T1 + SINC_PT - 1) / SINC_PT;
+    const int tpw = 4;                                        // pooled tiles per workgroup (amortises the filter fragments)
+    dim3 grid((tiles + tpw - 1) / tpw, B), block(256);
+    if (bf16)
+        hipLaunchKernelGGL(rn_sinc_kernel<bf16_t>, grid, block, SincCfg<bf16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
+                           bn_shift, reinterpret_cast<bf16_t*>(out), L, T1, tpw);
+    else
+        hipLaunchKernelGGL(rn_sinc_kernel<float>, grid, block, SincCfg<float>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
+                           bn_shift, reinterpret_cast<float*>(out), L, T1, tpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
+                            float slope, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec) return hipErrorInvalidValue;
+    const int64_t chunks = rows * (C / vec);
+    if (bf16) hipLaunchKernelGGL(rn_bn_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, scale, shift, C, slope, chunks);
+    else hipLaunchKernelGGL(rn_bn_act_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, scale, shift, C, slope, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec) return hipErrorInvalidValue;
+    const int Tout = Tin / 3;
+    const int64_t chunks = (int64_t)B * Tout * (C / vec);
+    if (bf16) hipLaunchKernelGGL(rn_maxpool3_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, Tin, Tout, C, chunks);
+    else hipLaunchKernelGGL(rn_maxpool3_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, Tin, Tout, C, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
+                                hipStream_t stream) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec) return hipErrorInvalidValue;
+    const int64_t chunks = (int64_t)B * T * (C / vec);
+    if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks);
+    else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream) {
+    const int n = B * C;
+    if (bf16) hipLaunchKernelGGL(rn_attn_pool_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const bf16_t*)x, T, C, out, B);
+    else hipLaunchKernelGGL(rn_attn_pool_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const float*)x, T, C, out, B);
+    return hipGetLastError();
+}
+
+}  // namespace svhip

@@ -1,0 +1,42 @@
+"""Drop-in for the reference plug-in ``models/RawNet2_custom.py`` (MainModel :230-243) in the variant
+the fusion models instantiate (``front_proc='sinc'``, ``aggregate='asp'``, Raw_ECAPA_sinc_asp.py:26-28).
+
+    model = MainModel(nOut=320, front_proc='sinc', aggregate='asp', att_dim=128, audio_spec={...})
+    emb = model(wav)          # (B, 32000) waveform -> (B, nOut); (nOut,) for B == 1
+
+State-dict keys are the reference's (147 tensors); the sinc band-pass filters are rebuilt from
+``first_conv.low_hz_`` / ``band_hz_`` once per weight load instead of once per forward.
+"""
+from __future__ import annotations
+
+from .. import synth
+from ._base import HipModule
+
+
+class RawNet2(HipModule):
+    model_kind = "rawnet2"
+
+    def __init__(self, nOut=512, front_proc="sinc", aggregate="gru", att_dim=128, audio_spec=None, device=None,
+                 compute=None, max_batch=32, **kwargs):
+        if front_proc != "sinc" or aggregate != "asp" or att_dim != 128:
+            raise NotImplementedError("only front_proc='sinc', aggregate='asp', att_dim=128 is built "
+                                      "(the variant of Raw_ECAPA_sinc_asp.py:26-28)")
+        audio_spec = audio_spec or {"sample_rate": 16000, "sentence_len": 2.0}
+        if int(audio_spec["sample_rate"]) != 16000:
+            raise NotImplementedError("the sinc front-end is built for sample_rate 16000 (RawNet2_custom.py:55-63)")
+        self.nb_samp = int(audio_spec["sentence_len"] * audio_spec["sample_rate"])      # LayerNorm(nb_samp), :58-60
+        compute = compute or kwargs.get("hip_compute", "f32")
+        super().__init__(synth.rawnet2_param_spec(nOut=nOut, nb_samp=self.nb_samp, att_dim=att_dim),
+                         dict(embed_dim=nOut), device=device if device is not None else kwargs.get("device"),
+                         compute=compute, max_batch=max_batch)
+
+    def forward(self, x):
+        if x.ndim != 2 or x.shape[1] != self.nb_samp:
+            raise ValueError(f"RawNet2 was built for (batch, {self.nb_samp}) waveforms, got {tuple(x.shape)} "
+                             "(LayerNorm gamma/beta fix the length, RawNet_baseline.py:16-18)")
+        eng = self._get_engine(self.nb_samp)
+        return self._squeeze(self._batched(eng.embed_wave, x))
+
+
+def MainModel(nOut=512, **kwargs):
+    return RawNet2(nOut=nOut, **kwargs)

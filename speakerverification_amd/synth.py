@@ -139,6 +139,12 @@ def synth_state_dict(spec, seed=1):
         elif leaf == "weight":
             fan_in = int(np.prod(shape[1:]))
             std = math.sqrt(2.0 / fan_in)
+            # RawNet2's residual stack has no normalisation on the skip path: with full He gain the
+            # activations grow to O(500) and the reference's own fp32 arithmetic is only good to ~1e-3
+            # (fp32 vs fp64 oracle).  Gain 0.7 keeps outputs at the O(20) the reference shows with its
+            # default init and the fp32 noise floor at ~1e-5, so that a 1e-4 parity bar means something.
+            if name.startswith("layer") and (".conv" in name or "shortcut" in name):
+                std *= 0.7
             sd[name] = (std * rng.standard_normal(shape)).astype(np.float32)
         else:  # pragma: no cover
             raise KeyError(name)

@@ -1,0 +1,57 @@
+"""GPU parity: RawNet2 (sinc front-end, ASP) through the C ABI vs the reference-pinned golden fixture."""
+import os
+
+import numpy as np
+import pytest
+
+from speakerverification_amd import synth
+from speakerverification_amd.models import RawNet2_custom
+
+pytestmark = pytest.mark.gpu
+
+SPEC = dict(sample_rate=16000, sentence_len=2.0, win_len=0.025, hop_len=0.01, channels=1)
+
+
+def make(compute, seed_w):
+    m = RawNet2_custom.MainModel(nOut=320, front_proc="sinc", aggregate="asp", att_dim=128, audio_spec=SPEC, compute=compute)
+    m.load_state_dict(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=seed_w))
+    return m
+
+
+def test_rawnet2_fp32_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
+    m = make("f32", int(g["seed_w"]))
+    x = synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"]))
+    out = m(x)
+    ref = g["out"]
+    assert out.shape == ref.shape == (2, 320)
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(out - ref).max())
+    print("rawnet2 fp32 err", err, "scale", scale)
+    # outputs are un-normalised and large (|out| ~ 280 with these weights): tolerance 1e-4 of the scale
+    assert err <= 1e-4 * scale
+    # what scoring consumes: L2-normalised embeddings within 1e-4
+    on = out / np.linalg.norm(out, axis=1, keepdims=True)
+    rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    assert float(np.abs(on - rn).max()) <= 1e-4
+    assert m(x[:1]).shape == (320,)
+
+
+def test_rawnet2_bf16_close(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
+    m = make("bf16", int(g["seed_w"]))
+    x = synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"]))
+    out = m(x)
+    ref = g["out"]
+    cos = np.sum(out * ref, axis=1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+    rel = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print("rawnet2 bf16 rel", rel, "cos", cos)
+    # bf16 storage through 8 un-normalised residual blocks + a bf16 sinc front-end: stated tolerance is
+    # cosine >= 0.99 to the fp32 reference embedding and max error <= 15 % of the embedding scale
+    assert rel <= 0.15 and float(cos.min()) >= 0.99
+
+
+def test_rawnet2_rejects_other_lengths():
+    m = make("f32", 1)
+    with pytest.raises(ValueError):
+        m(np.zeros((1, 16000), np.float32))
