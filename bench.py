@@ -39,7 +39,7 @@ CHANNELS = 1024
 EMBED = 192
 PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
-DOMINANT = "gemm_pointwise"    # gemm_kernel<bf16, CONV=false, A2=false>: tdnn1/tdnn2 x3, mfa, asp.tdnn, asp.conv
+DOMINANT = "gemm_pw2"          # gemm_pw2_kernel<EPI_GELU>: tdnn1/tdnn2 x3 + mfa (the 256 x 256 bf16 pointwise-conv GEMM)
 
 
 def parse():
@@ -169,6 +169,8 @@ def main():
 def run(args, rank, world, local, dev, dist):
     B, K, W = args.batch, args.steps, args.warmup
     global EMBED, DOMINANT
+    if args.compute == "f32" and args.model == "ecapa":
+        DOMINANT = "gemm_pw"
     if args.model == "rawnet2":
         EMBED, DOMINANT = 320, "gemm_conv"
         eng = Engine(model="rawnet2", compute=args.compute, embed_dim=EMBED, max_batch=B, samples=SAMPLES, device=local,

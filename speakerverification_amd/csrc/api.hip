@@ -626,7 +626,8 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     hipStream_t st = h->stream;
     (void)label;
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
-    const char* klabel = L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : "gemm_pointwise";
+    const char* klabel = L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv")
+                                    : (gemm_pw2_supported(p, bf) ? "gemm_pw2" : (gemm_pw_supported(p, bf) ? "gemm_pw" : "gemm_generic"));
     return run(h, klabel, (double)M * L.flops_per_row, [&]() { return launch_gemm(p, bf, st); });
 }
 
