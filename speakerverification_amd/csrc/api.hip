@@ -67,6 +67,7 @@ struct svhip_handle {
     ConvLayer blocks0, mfa, asp_tdnn, asp_conv;
     ConvLayer tdnn1[3], tdnn2[3], res2[3][7];
     LinearLayer se1[3], se2[3], asp_ctx, fc;
+    float* se2T[3] = {};                      // se_block.conv2 weight transposed to [128][C]
     float *aspbn_scale = nullptr, *aspbn_shift = nullptr;
     float *in_w = nullptr, *in_b = nullptr;   // instance norm affine
 
@@ -443,6 +444,13 @@ int finalize_ecapa(svhip_handle* h) {
         if ((rc = make_tdnn(h, h->tdnn2[i - 1], p + ".tdnn2", 1))) return rc;
         if ((rc = make_linear(h, h->se1[i - 1], p + ".se_block.conv1.conv.weight", p + ".se_block.conv1.conv.bias"))) return rc;
         if ((rc = make_linear(h, h->se2[i - 1], p + ".se_block.conv2.conv.weight", p + ".se_block.conv2.conv.bias"))) return rc;
+        {
+            const HostTensor* w2 = getw(h, p + ".se_block.conv2.conv.weight");      // (C, 128, 1)
+            std::vector<float> t((size_t)128 * C);
+            for (int c = 0; c < C; ++c)
+                for (int n = 0; n < 128; ++n) t[(size_t)n * C + c] = w2->data[(size_t)c * 128 + n];
+            if ((rc = dev_upload(h, &h->se2T[i - 1], t))) return rc;
+        }
     }
     if ((rc = make_tdnn(h, h->mfa, "mfa", 1))) return rc;
     // asp.tdnn over cat[x, mean, std]: the x columns go through the GEMM, the time-constant columns
@@ -671,11 +679,8 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
         }
         if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], h->H2, C, h->H3, C, M, ACT_GELU))) return rc;
         if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(h->H3, bf, C, B, T, C, h->d_mean, st); }))) return rc;
-        if ((rc = run(h, "se_fc", 2.0 * B * 128 * C, [&]() {
-                 return launch_rowvec_linear(h->d_mean, C, h->se1[i].W, h->se1[i].bias, h->d_s1, 128, B, 128, C, ACT_RELU, st);
-             }))) return rc;
-        if ((rc = run(h, "se_fc", 2.0 * B * 128 * C, [&]() {
-                 return launch_rowvec_linear(h->d_s1, 128, h->se2[i].W, h->se2[i].bias, h->d_s2, C, B, C, 128, ACT_SIGMOID, st);
+        if ((rc = run(h, "se_mlp", 4.0 * B * 128 * C, [&]() {
+                 return launch_se_mlp(h->d_mean, h->se1[i].W, h->se1[i].bias, h->se2T[i], h->se2[i].bias, h->d_s2, B, C, 128, st);
              }))) return rc;
         void* xout = off(h->CAT, (size_t)i * C, e);
         if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(h->H3, C, h->d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))

@@ -124,6 +124,46 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
     }
 }
 
+// ---- squeeze-excitation MLP: s = sigmoid(W2 relu(W1 m + b1) + b2)  (ECAPA_TDNN.py:171-176) ----------------
+// One workgroup per utterance; the hidden layer (H = 128 units) lives in LDS between the two
+// matrix-vector products; W1 is [H][C], W2T is the TRANSPOSED second layer [H][C] so that both
+// products read their weights coalesced along C.  Four hidden units per wave are in flight at once
+// and the second product is unrolled 8-deep so the L2 round trips overlap.
+__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ W1,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2T,
+                                                     const float* __restrict__ b2, float* __restrict__ s, int B, int C, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xm = reinterpret_cast<float*>(smem);          // [C]
+    float* hid = xm + C;                                 // [H]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < C; i += 256) xm[i] = mean[(int64_t)b * C + i];
+    __syncthreads();
+    for (int n0 = wave * 4; n0 < H; n0 += 16) {          // 4 hidden units per wave per pass
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < C; c += 64) {
+            const float x = xm[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaf(W1[(int64_t)(n0 + u) * C + c], x, a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = wave_sum(a[u]);
+            if (lane == 0) hid[n0 + u] = fmaxf(t + b1[n0 + u], 0.f);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {         // output channel c: dot over H, weights coalesced along c
+        float a0 = b2[c], a1 = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < H; n += 2) {
+            a0 = fmaf(W2T[(int64_t)n * C + c], hid[n], a0);
+            a1 = fmaf(W2T[(int64_t)(n + 1) * C + c], hid[n + 1], a1);
+        }
+        s[(int64_t)b * C + c] = 1.0f / (1.0f + expf(-(a0 + a1)));
+    }
+}
+
 // ---- SE gate + residual -------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ s,
@@ -252,6 +292,14 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
     dim3 grid((N + 7) / 8, (B + 7) / 8), block(256);
     hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, 0, stream, in, ld_in, W, bias, out, ld_out, B, N, K, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_se_mlp(const float* mean, const float* W1, const float* b1, const float* W2T, const float* b2, float* s,
+                         int B, int C, int H, hipStream_t stream) {
+    const size_t lds = (size_t)(C + H) * sizeof(float);
+    if (lds > 64 * 1024 || B <= 0 || H % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), lds, stream, mean, W1, b1, W2T, b2, s, B, C, H);
     return hipGetLastError();
 }
 

@@ -43,7 +43,10 @@ constexpr int QGROUP_M = 4;
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
 
-__device__ __forceinline__ int hswz(int row, int chunk) { return row * HROWB + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// chunk swizzle key of a row: conflict-free for the 32x32x16 fragment pattern ((row >> 2) & 3) and for the
+// 16x16x32 pattern (its 16-lane ds_read_b128 groups mix chunks c and c+1 of rows {a, a+12} / {a+4, a+8}: key -x & 3)
+template <bool M16> __device__ __forceinline__ int hkey(int row) { return M16 ? ((0 - (row >> 2)) & 3) : ((row >> 2) & 3); }
+template <bool M16> __device__ __forceinline__ int hswz(int row, int chunk) { return row * HROWB + ((chunk ^ hkey<M16>(row)) << 4); }
 
 __device__ __forceinline__ float gelu_fast(float x) {      // erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
     const float z = fabsf(x) * 0.70710678118654752440f;
@@ -65,7 +68,7 @@ __device__ __forceinline__ float act1(float v) {
     return v;
 }
 
-template <int EPI>
+template <int EPI, bool M16>
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const bool isA = j < 2;
         const int g = wave + 8 * (j & 1);
         const int r = g * 16 + (lane >> 2);
-        const int lc = (lane & 3) ^ ((r >> 2) & 3);
+        const int lc = (lane & 3) ^ hkey<M16>(r);
         if (isA) {
             const int m = min(m0 + r, p.M - 1);
             src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * 8) * 2;
@@ -115,13 +118,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (int64_t)h * HROWB), (lds_void*)(base + dst[j]), 16, 0, 0);
     };
 
-    f32x16 acc[4][2];
+    // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
+    f32x16 acc32[M16 ? 1 : 4][M16 ? 1 : 2];
+    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    if (M16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) acc16[M16 ? i : 0][M16 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[M16 ? 0 : i][M16 ? 0 : j][r] = 0.0f;
+    }
 
     const int nh = p.Kp / 32;                       // half-steps (host guarantees Kp % 64 == 0, so nh >= 2)
     issue(0);
@@ -132,19 +144,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();                   // half-step 0 of every wave has landed
     if (wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind group 0
 
-    const int fr = lane & 31, fh = lane >> 5;
-    const int arow = wm * 128 + fr, wrow = wn * 64 + fr;
+    const int fr = lane & 31, fh = lane >> 5;       // 32x32x16 fragment coordinates
+    const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
+    const int arow = wm * 128 + (M16 ? r16 : fr), wrow = wn * 64 + (M16 ? r16 : fr);
     for (int h = 0; h < nh; ++h) {
         // ---------------- phase L(h): fragments of half-step h -> registers; DMA for h+3 ----------------
         const char* As = smem + (h & (NRING - 1)) * HSTAGE;
         const char* Ws = As + HA;
-        bf16x8 xf[2][4], wf[2][2];
+        bf16x8 xf[8], wf[4];                         // 12 fragments (48 VGPRs) in both shapes
+        if (M16) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(As + hswz<M16>(arow + i * 16, q4));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8*>(As + hswz(arow + i * 32, 2 * s + fh));
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Ws + hswz<M16>(wrow + j * 16, q4));
+        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[s][j] = *reinterpret_cast<const bf16x8*>(Ws + hswz(wrow + j * 32, 2 * s + fh));
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[s * 4 + i] = *reinterpret_cast<const bf16x8*>(As + hswz<M16>(arow + i * 32, 2 * s + fh));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wf[s * 2 + j] = *reinterpret_cast<const bf16x8*>(Ws + hswz<M16>(wrow + j * 32, 2 * s + fh));
+            }
         }
         if (h + 3 < nh) {
             issue(h + 3);
@@ -155,45 +175,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        // ---------------- phase C(h): 16 MFMAs ------------------------------------------------------------
+        // ---------------- phase C(h): 16 (32x32x16) or 32 (16x16x32) MFMAs -------------------------------
         __builtin_amdgcn_s_setprio(1);
+        if (M16) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    acc16[M16 ? i : 0][M16 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc16[M16 ? i : 0][M16 ? j : 0], 0, 0, 0);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc32[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 2 + j], xf[s * 4 + i], acc32[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count
     __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: reuse the ring
 
-    // ---- epilogue: acc[i][j][4g+e] is (m = wm*128 + i*32 + fr, n = wn*64 + j*32 + 8g + 4fh + e) --------
+    // ---- epilogue: every lane owns 4 consecutive channels (n .. n+3) of one frame per accumulator group ----
+    //   32x32x16: acc32[i][j][4g+e] = (m = wm*128 + i*32 + fr,  n = wn*64 + j*32 + 8g + 4fh + e)
+    //   16x16x32: acc16[i][j][e]    = (m = wm*128 + i*16 + r16, n = wn*64 + j*16 + 4q4 + e)
     constexpr int ORB = QBN * 2;                    // 512-byte output rows
+    constexpr int NGRP = M16 ? 4 : 8;               // channel groups per wave (64 channels / 16 or / 8 per group pair)
+    constexpr int NROW = M16 ? 8 : 4;               // frame blocks per wave
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int cg = 0; cg < NGRP; ++cg) {
+        const int nl = M16 ? (wn * 64 + cg * 16 + 4 * q4) : (wn * 64 + (cg >> 2) * 32 + 8 * (cg & 3) + 4 * fh);
+        const int n = n0 + nl;
+        const bool nok = n < p.N;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (nok) {
+            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.scale) { sc4 = *reinterpret_cast<const f32x4*>(p.scale + n); sh4 = *reinterpret_cast<const f32x4*>(p.shift + n); }
+        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + j * 32 + 8 * g + 4 * fh;
-            const int n = n0 + nl;
-            const bool nok = n < p.N;
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-            if (nok) {
-                if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (p.scale) { sc4 = *reinterpret_cast<const f32x4*>(p.scale + n); sh4 = *reinterpret_cast<const f32x4*>(p.shift + n); }
+        for (int i = 0; i < NROW; ++i) {
+            const int ml = M16 ? (wm * 128 + i * 16 + r16) : (wm * 128 + i * 32 + fr);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
+                v[e] = fmaf(act1<EPI>(a + b4[e]), sc4[e], sh4[e]);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = wm * 128 + i * 32 + fr;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(act1<EPI>(acc[i][j][4 * g + e] + b4[e]), sc4[e], sh4[e]);
-                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
-                *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
-            }
+            typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+            *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
         }
     }
     __syncthreads();
@@ -210,17 +242,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
 }
 
-template <int EPI>
+template <int EPI, bool M16>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pw2_kernel<EPI>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -235,11 +267,12 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
 
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
+    const bool m16 = !(p.debug & 64);               // 16x16x32 by default (holds a higher clock on real data); 64 = A/B switch for tools/gemm_bench
     switch (p.act1) {
-        case ACT_NONE: return launch_inst<EPI_NONE>(p, stream);
-        case ACT_RELU: return launch_inst<EPI_RELU>(p, stream);
-        case ACT_GELU: return launch_inst<EPI_GELU>(p, stream);
-        case ACT_LRELU03: return launch_inst<EPI_LRELU03>(p, stream);
+        case ACT_NONE: return m16 ? launch_inst<EPI_NONE, true>(p, stream) : launch_inst<EPI_NONE, false>(p, stream);
+        case ACT_RELU: return m16 ? launch_inst<EPI_RELU, true>(p, stream) : launch_inst<EPI_RELU, false>(p, stream);
+        case ACT_GELU: return m16 ? launch_inst<EPI_GELU, true>(p, stream) : launch_inst<EPI_GELU, false>(p, stream);
+        case ACT_LRELU03: return m16 ? launch_inst<EPI_LRELU03, true>(p, stream) : launch_inst<EPI_LRELU03, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
