@@ -244,6 +244,36 @@ int build_fbank_tables(svhip_handle* h) {
                         }
                         basis[((((size_t)q * fb.n_pairs + pr) * 2 + part) * 64 + lane) * 4 + j] = v;
                     }
+    // bf16x3 tables: the same windowed taps split into bf16 hi + lo, k-steps of 16 (zero padded)
+    fb.n_k16 = (c.win_length + 15) / 16;
+    fb.split_bf16 = (h->bf16 && c.hop_length % 8 == 0) ? 1 : 0;
+    if (fb.split_bf16) {
+        std::vector<uint16_t> bhi((size_t)fb.n_k16 * fb.n_pairs * 2 * 64 * 8, 0), blo(bhi.size(), 0);
+        for (int kk = 0; kk < fb.n_k16; ++kk)
+            for (int pr = 0; pr < fb.n_pairs; ++pr)
+                for (int part = 0; part < 2; ++part)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = lane & 31, hh = lane >> 5;
+                            const int tap = 16 * kk + 8 * hh + j, bin = 32 * pr + r;
+                            float v = 0.0f;
+                            if (bin < fb.n_bins && tap < c.win_length) {
+                                const double ang = 2.0 * PI * (double)bin * (double)(fb.lpad + tap) / (double)c.n_fft;
+                                v = (float)(part == 0 ? std::cos(ang) : std::sin(ang)) * win[tap];
+                            }
+                            const uint16_t hi = f32_to_bf16_rne(v);
+                            uint32_t hu = (uint32_t)hi << 16;
+                            float hf; memcpy(&hf, &hu, 4);
+                            const size_t idx = ((((size_t)kk * fb.n_pairs + pr) * 2 + part) * 64 + lane) * 8 + j;
+                            bhi[idx] = hi;
+                            blo[idx] = f32_to_bf16_rne(v - hf);
+                        }
+        uint16_t *dh, *dl;
+        int rc2;
+        if ((rc2 = dev_upload(h, &dh, bhi))) return rc2;
+        if ((rc2 = dev_upload(h, &dl, blo))) return rc2;
+        fb.basis_hi = dh; fb.basis_lo = dl;
+    }
     // Slaney mel bank (librosa 0.7 filters.mel(htk=False, norm=1)) in double, stored float32, sparse rows
     const double sr = c.fb_sr;
     const double fmax = c.fmax > 0 ? c.fmax : sr / 2;
@@ -277,6 +307,7 @@ int build_fbank_tables(svhip_handle* h) {
     if ((rc = dev_upload(h, &d_ms, mstart))) return rc;
     if ((rc = dev_upload(h, &d_ml, mlen))) return rc;
     if ((rc = dev_upload(h, &d_mo, moff))) return rc;
+    fb.n_melw = (int)mw.size();
     fb.basis = d_basis; fb.mel_w = d_mw; fb.mel_start = d_ms; fb.mel_len = d_ml; fb.mel_off = d_mo;
     return SVHIP_OK;
 }

@@ -26,19 +26,27 @@ constexpr int FB_THREADS = 192;
 constexpr int FB_PT_STRIDE = 289;     // 9*32 + 1
 constexpr int FB_PAIRS_PER_WAVE = 3;
 
+// SPLIT = false: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the 1e-4-parity path.
+// SPLIT = true : bf16x3 — samples and basis are split into bf16 hi + lo parts and the product is
+//                hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (dropped term ~2^-16 relative): 5x
+//                fewer matrix-pipe cycles, used by bf16-compute handles whose features are rounded to
+//                bf16 (2^-8) right after.
+template <bool SPLIT>
 __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const float* __restrict__ wav,
                                                            int L, int T, float* __restrict__ mel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ns = (FB_FRAMES - 1) * tb.hop + tb.win_length;       // samples touched by the tile
-    const int ns_pad = (ns + 3) & ~3;
-    float* ys = reinterpret_cast<float*>(smem);
+    const int ns_pad = ((ns + 15) & ~15) + 16;                     // + one zero-basis k-step of slack for SPLIT
+    float* ys = reinterpret_cast<float*>(smem);                    // SPLIT: [ns_pad] bf16 hi | [ns_pad] bf16 lo
     float* pt = ys + ns_pad;                                       // [32][289]
+    float* melw = pt + FB_FRAMES * FB_PT_STRIDE;                   // packed non-zero mel weights (LDS copy)
 
     const int b = blockIdx.y;
     const int f0 = blockIdx.x * FB_FRAMES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* __restrict__ x = wav + (int64_t)b * L;
 
+    for (int i = tid; i < tb.n_melw; i += FB_THREADS) melw[i] = tb.mel_w[i];
     // ---- 1. pre-emphasised + reflect-padded samples -> LDS -------------------------------------
     const int j0 = f0 * tb.hop + tb.lpad - tb.n_fft / 2;
     const float coef = tb.preemph;
@@ -52,7 +60,13 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const
             const float prev = x[jj == 0 ? 1 : jj - 1];            // F.pad(reflect,(1,0)): x[-1] := x[1]
             v = __fadd_rn(__fmul_rn(-coef, prev), v);              // conv1d with taps [-coef, 1]
         }
-        ys[i] = v;
+        if (SPLIT) {
+            const bf16_t hi = static_cast<bf16_t>(v);
+            reinterpret_cast<bf16_t*>(ys)[i] = hi;
+            reinterpret_cast<bf16_t*>(ys)[ns_pad + i] = static_cast<bf16_t>(v - static_cast<float>(hi));
+        } else {
+            ys[i] = v;
+        }
     }
     __syncthreads();
 
@@ -66,20 +80,47 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
 
-    const f32x4* __restrict__ basis = reinterpret_cast<const f32x4*>(tb.basis);
-    const float* arow = ys + r * tb.hop + 4 * h;
-    for (int q = 0; q < tb.n_q; ++q) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+    if (SPLIT) {
+        const bf16x8* __restrict__ bh = reinterpret_cast<const bf16x8*>(tb.basis_hi);
+        const bf16x8* __restrict__ bl = reinterpret_cast<const bf16x8*>(tb.basis_lo);
+        const bf16_t* yh = reinterpret_cast<const bf16_t*>(ys) + r * tb.hop + 8 * h;
+        const bf16_t* yl = yh + ns_pad;
+        // (a register double-buffer of the basis fragments was tried: 212 VGPRs cost a wave per SIMD and
+        //  lost more than the prefetch gained; occupancy hides the L2 latency better here)
+        for (int kk = 0; kk < tb.n_k16; ++kk) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(yh + 16 * kk);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(yl + 16 * kk);
 #pragma unroll
-        for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a) {
-            const int pair = wave * FB_PAIRS_PER_WAVE + a;
-            if (pair < tb.n_pairs) {
+            for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a) {
+                const int pair = wave * FB_PAIRS_PER_WAVE + a;
+                if (pair < tb.n_pairs) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f32x4 b4 = basis[((int64_t)(q * tb.n_pairs + pair) * 2 + c) * 64 + lane];
+                    for (int c = 0; c < 2; ++c) {
+                        const int64_t bi = ((int64_t)(kk * tb.n_pairs + pair) * 2 + c) * 64 + lane;
+                        const bf16x8 b_hi = bh[bi], b_lo = bl[bi];
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b_hi, acc[a][c], 0, 0, 0);   // small terms first
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_lo, acc[a][c], 0, 0, 0);
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_hi, acc[a][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        const f32x4* __restrict__ basis = reinterpret_cast<const f32x4*>(tb.basis);
+        const float* arow = ys + r * tb.hop + 4 * h;
+        for (int q = 0; q < tb.n_q; ++q) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * q);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[a][c], 0, 0, 0);
+            for (int a = 0; a < FB_PAIRS_PER_WAVE; ++a) {
+                const int pair = wave * FB_PAIRS_PER_WAVE + a;
+                if (pair < tb.n_pairs) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x4 b4 = basis[((int64_t)(q * tb.n_pairs + pair) * 2 + c) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[a][c], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -105,7 +146,7 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const
         const int i = idx & 31, m = idx >> 5;
         const int f = f0 + i;
         const int st = tb.mel_start[m], ln = tb.mel_len[m];
-        const float* __restrict__ w = tb.mel_w + tb.mel_off[m];
+        const float* w = melw + tb.mel_off[m];
         const float* prow = pt + i * FB_PT_STRIDE + st;
         float s = 0.0f;
         for (int k = 0; k < ln; ++k) s = fmaf(w[k], prow[k], s);
@@ -182,10 +223,15 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
         tb.n_bins > 32 * tb.n_pairs || tb.n_q * 8 != tb.win_length || L < tb.n_fft || B <= 0)
         return hipErrorInvalidValue;
     const int ns = (FB_FRAMES - 1) * tb.hop + tb.win_length;
-    const int ns_pad = (ns + 3) & ~3;
-    const size_t lds = (size_t)(ns_pad + FB_FRAMES * FB_PT_STRIDE) * sizeof(float);
+    const int ns_pad = ((ns + 15) & ~15) + 16;
+    const size_t lds = (size_t)(ns_pad + FB_FRAMES * FB_PT_STRIDE + tb.n_melw) * sizeof(float);
     dim3 grid((T + FB_FRAMES - 1) / FB_FRAMES, B), block(FB_THREADS);
-    hipLaunchKernelGGL(fbank_kernel, grid, block, lds, stream, tb, wav, L, T, mel);
+    if (tb.split_bf16) {
+        if (!tb.basis_hi || !tb.basis_lo || tb.hop % 8 != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(fbank_kernel<true>, grid, block, lds, stream, tb, wav, L, T, mel);
+    } else {
+        hipLaunchKernelGGL(fbank_kernel<false>, grid, block, lds, stream, tb, wav, L, T, mel);
+    }
     return hipGetLastError();
 }
 

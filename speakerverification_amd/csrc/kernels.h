@@ -71,7 +71,12 @@ hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 struct FbankTables {           // device pointers, built once per handle
     const float* basis = nullptr;      // [q][tile][lane] float4: windowed cos/sin taps laid out for MFMA B operands
+    const void* basis_hi = nullptr;    // bf16x3 path: [k16][pair][part][lane] 8 x bf16 (hi / lo parts of the same taps)
+    const void* basis_lo = nullptr;
+    int n_k16 = 13;                    // ceil(win_length / 16)
+    int split_bf16 = 0;                // 1: bf16x3 DFT (bf16-compute handles)
     const float* mel_w = nullptr;      // packed non-zero mel weights
+    int n_melw = 0;                    // number of packed weights
     const int* mel_start = nullptr;    // [n_mels] first bin
     const int* mel_len = nullptr;      // [n_mels] number of bins
     const int* mel_off = nullptr;      // [n_mels] offset into mel_w
