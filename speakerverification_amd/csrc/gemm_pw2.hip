@@ -68,7 +68,10 @@ __device__ __forceinline__ float act1(float v) {
     return v;
 }
 
-template <int EPI, bool M16>
+// CONV = true: the A operand is the im2col view of a dilated 1-D convolution (k = tap*cin + c reads frame
+// t + (tap - taps/2)*dil of the same utterance, reflect or zero padded; chunks with k >= K read a zero page):
+// only the per-lane DMA source address changes, the rest of the kernel is identical.
+template <int EPI, bool M16, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     // ---- DMA geometry: per half-step, wave w fills 16-row groups g = w, w + 8 of A and of W --------
     const char* src[4];
     int dst[4];
+    int cutt[2] = {0, 0}, ct[2] = {0, 0}, clc[2] = {0, 0};       // CONV: utterance base row, frame, logical chunk of the two A rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool isA = j < 2;
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             const int m = min(m0 + r, p.M - 1);
             src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * 8) * 2;
             dst[j] = g * 1024;
+            if (CONV) { const int b = m / p.T; cutt[j] = b * p.T; ct[j] = m - b * p.T; clc[j] = lc; }
         } else {
             const int n = min(n0 + r, p.Wrows - 1);
             src[j] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + lc * 8) * 2;
@@ -114,8 +119,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     auto issue = [&](int h) {
         char* base = smem + (h & (NRING - 1)) * HSTAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (int64_t)h * HROWB), (lds_void*)(base + dst[j]), 16, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const char* s = src[j] + (int64_t)h * HROWB;
+            if (CONV && j < 2) {
+                const int k = h * 32 + clc[j] * 8;
+                const int tap = k / p.cin;
+                int tt = ct[j] + (tap - (p.taps >> 1)) * p.dil;
+                bool ok = k < p.K;
+                if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
+                else ok = ok && tt >= 0 && tt < p.T;
+                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cutt[j] + tt) * p.lda + (k - tap * p.cin)) * 2
+                       : reinterpret_cast<const char*>(p.zero_page);
+            }
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dst[j]), 16, 0, 0);
+        }
     };
 
     // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
@@ -242,37 +259,54 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
 }
 
-template <int EPI, bool M16>
+template <int EPI, bool M16, bool CONV>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16, CONV>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
 bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
-    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE) return false;
+    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE || p.A2 || p.R) return false;
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
-    if (p.N < 256 || p.Kp % 64 != 0) return false;
-    return gemm_pw_supported(p, bf16);
+    if (p.N < 256 || p.Kp % 64 != 0 || p.N % 8 != 0 || p.lda % 8 != 0 || p.ldy % 8 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y)) & 15) return false;
+    if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
+    if (p.scale && ((reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15)) return false;
+    if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; needs the zero page for padded k / frames
+        if (!p.zero_page || p.cin % 8 != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;
+        if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return false;
+        return true;
+    }
+    return p.K == p.Kp;
 }
 
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     const bool m16 = !(p.debug & 64);               // 16x16x32 by default (holds a higher clock on real data); 64 = A/B switch for tools/gemm_bench
+    if (p.taps > 1) {
+        switch (p.act1) {
+            case ACT_NONE: return launch_inst<EPI_NONE, true, true>(p, stream);
+            case ACT_RELU: return launch_inst<EPI_RELU, true, true>(p, stream);
+            case ACT_GELU: return launch_inst<EPI_GELU, true, true>(p, stream);
+            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, true>(p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.act1) {
-        case ACT_NONE: return m16 ? launch_inst<EPI_NONE, true>(p, stream) : launch_inst<EPI_NONE, false>(p, stream);
-        case ACT_RELU: return m16 ? launch_inst<EPI_RELU, true>(p, stream) : launch_inst<EPI_RELU, false>(p, stream);
-        case ACT_GELU: return m16 ? launch_inst<EPI_GELU, true>(p, stream) : launch_inst<EPI_GELU, false>(p, stream);
-        case ACT_LRELU03: return m16 ? launch_inst<EPI_LRELU03, true>(p, stream) : launch_inst<EPI_LRELU03, false>(p, stream);
+        case ACT_NONE: return m16 ? launch_inst<EPI_NONE, true, false>(p, stream) : launch_inst<EPI_NONE, false, false>(p, stream);
+        case ACT_RELU: return m16 ? launch_inst<EPI_RELU, true, false>(p, stream) : launch_inst<EPI_RELU, false, false>(p, stream);
+        case ACT_GELU: return m16 ? launch_inst<EPI_GELU, true, false>(p, stream) : launch_inst<EPI_GELU, false, false>(p, stream);
+        case ACT_LRELU03: return m16 ? launch_inst<EPI_LRELU03, true, false>(p, stream) : launch_inst<EPI_LRELU03, false, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

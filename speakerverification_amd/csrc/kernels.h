@@ -22,6 +22,7 @@ struct GemmParams {
     const float* bias_utt = nullptr;
     const float* scale = nullptr;
     const float* shift = nullptr;
+    const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
     const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last (generic kernel only)
     int ldr = 0;
     int M = 0, N = 0, K = 0, Kp = 0;
