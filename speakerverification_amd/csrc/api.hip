@@ -99,7 +99,10 @@ struct svhip_handle {
     float* d_wav = nullptr;       // (Bmax, L)
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
-    float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
+    float* d_zero = nullptr;
+    float* d_colsum = nullptr;    // pw2 column-sum partials, per lane: [sum | sumsq] x (tiles*4) x 3C floats
+    int64_t colsum_region = 0;    // floats per (lane, kind) region
+    bool last_colsum_done = false;      // 256 zero bytes (DMA source for padded conv chunks)
     void* X_in = nullptr;         // (M, n_mels)
     void* X0 = nullptr;           // (M, C)
     void *H1 = nullptr, *H2 = nullptr, *H3 = nullptr;   // (M, C)
@@ -653,6 +656,8 @@ int alloc_workspace(svhip_handle* h) {
         if ((rc = dev_alloc(h, &h->d_ctx, B * 128))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_raw, B * 2 * C3))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_bn, B * 2 * C3))) return rc;
+        h->colsum_region = (int64_t)((M + 255) / 256 + 2) * 16 * C3;
+        if ((rc = dev_alloc(h, &h->d_colsum, (size_t)4 * h->colsum_region))) return rc;
     }
     return SVHIP_OK;
 }
@@ -660,8 +665,11 @@ int alloc_workspace(svhip_handle* h) {
 // ---- GEMM call helper -------------------------------------------------------------------------------
 int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void* A, int lda, void* Y, int ldy, int M,
               int act1, int act2 = ACT_NONE, const void* A2 = nullptr, int lda2 = 0, const float* bias_utt = nullptr,
-              int ld_bu = 0, bool out_f32 = false, int T = 0, int pad_mode = PAD_REFLECT, const void* R = nullptr, int ldr = 0) {
+              int ld_bu = 0, bool out_f32 = false, int T = 0, int pad_mode = PAD_REFLECT, const void* R = nullptr, int ldr = 0,
+              float* colsum = nullptr, int colsum_sq = 0, int64_t colsum_stride = 0) {
     GemmParams p;
+    p.colsum = colsum; p.colsum_sq = colsum_sq; p.colsum_stride = colsum_stride;
+    h->last_colsum_done = false;
     p.R = R; p.ldr = ldr; p.zero_page = h->d_zero;
     p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
     p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
@@ -672,6 +680,10 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     const bool bf = h->bf16;
     hipStream_t st = h->cur;
     (void)label;
+    if (p.colsum) {                       // only the pw2 epilogue produces the partials; otherwise the caller falls back
+        if (gemm_pw2_supported(p, bf) && p.taps == 1) h->last_colsum_done = true;
+        else p.colsum = nullptr;
+    }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
     const char* klabel = (L.taps > 1 && !gemm_pw2_supported(p, bf)) ? (A2 ? "gemm_conv_add" : "gemm_conv")
                                     : (gemm_pw2_supported(p, bf) ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2") : (gemm_pw_supported(p, bf) ? "gemm_pw" : "gemm_generic"));
@@ -710,6 +722,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     float* d_pool_bn = h->d_pool_bn + (size_t)b0 * 2 * C3;
     float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     (void)d_s1;
+    float* cs_base = (bf && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
     int rc;
     if ((rc = run(h, "prologue", 0, [&]() {
              return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st);
@@ -739,8 +752,14 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
                     return rc;
             }
         }
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], H2, C, H3, C, M, ACT_GELU))) return rc;
-        if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(H3, bf, C, B, T, C, d_mean, st); }))) return rc;
+        // tdnn2; its epilogue also leaves per-utterance column sums (the SE squeeze) when the pw2 kernel runs
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], H2, C, H3, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
+                            PAD_REFLECT, nullptr, 0, cs_base, 0, h->colsum_region))) return rc;
+        if (h->last_colsum_done) {
+            if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, false, B, T, C, M, d_mean, 0.f, st); }))) return rc;
+        } else {
+            if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(H3, bf, C, B, T, C, d_mean, st); }))) return rc;
+        }
         if ((rc = run(h, "se_mlp", 4.0 * B * 128 * C, [&]() {
                  return launch_se_mlp(d_mean, h->se1[i].W, h->se1[i].bias, h->se2T[i], h->se2[i].bias, d_s2, B, C, 128, st);
              }))) return rc;
@@ -750,8 +769,13 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         xin = xout;
         ldin = C3;
     }
-    if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, CAT, C3, MFA, C3, M, ACT_GELU))) return rc;
-    if ((rc = run(h, "asp_gstats", 0, [&]() { return launch_colstats(MFA, bf, C3, B, T, C3, d_gstats, 1e-12f, st); }))) return rc;
+    if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
+                        PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region))) return rc;
+    if (h->last_colsum_done) {
+        if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, true, B, T, C3, M, d_gstats, 1e-12f, st); }))) return rc;
+    } else {
+        if ((rc = run(h, "asp_gstats", 0, [&]() { return launch_colstats(MFA, bf, C3, B, T, C3, d_gstats, 1e-12f, st); }))) return rc;
+    }
     if ((rc = run(h, "asp_ctx", 2.0 * B * 128 * 2 * C3, [&]() {
              return launch_rowvec_linear(d_gstats, 2 * C3, h->asp_ctx.W, h->asp_ctx.bias, d_ctx, 128, B, 128, 2 * C3, ACT_NONE, st);
          }))) return rc;

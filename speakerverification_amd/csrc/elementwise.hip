@@ -124,6 +124,35 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
     }
 }
 
+// ---- finalize the column-sum partials written by the pw2 GEMM epilogue --------------------------------------
+// part[((tm*8 + rg)*2 + seg)*C + c]: utterance b owns segment seg = b - (tm*256)/T of tile tm.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int64_t sq_stride, int with_std,
+                                                              int T, int C, int M, float* __restrict__ out, float eps) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = b * T, r1 = r0 + T - 1;
+    float s = 0.f, q = 0.f;
+    for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
+        const int seg = b - (tm * 256) / T;
+        if (seg < 0 || seg > 1) continue;
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const int64_t o = ((int64_t)(tm * 8 + rg) * 2 + seg) * C + c;
+            s += part[o];
+            if (with_std) q += part[sq_stride + o];
+        }
+    }
+    const float mean = s / (float)T;
+    if (with_std) {
+        out[(int64_t)b * 2 * C + c] = mean;
+        out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q / (float)T - mean * mean, eps));
+    } else {
+        out[(int64_t)b * C + c] = mean;
+    }
+    (void)M;
+}
+
 // ---- squeeze-excitation MLP: s = sigmoid(W2 relu(W1 m + b1) + b2)  (ECAPA_TDNN.py:171-176) ----------------
 // One workgroup per utterance; the hidden layer (H = 128 units) lives in LDS between the two
 // matrix-vector products; W1 is [H][C], W2T is the TRANSPOSED second layer [H][C] so that both
@@ -292,6 +321,12 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
     dim3 grid((N + 7) / 8, (B + 7) / 8), block(256);
     hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, 0, stream, in, ld_in, W, bias, out, ld_out, B, N, K, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
+                                  float* out, float eps, hipStream_t stream) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, part, sq_stride, with_std ? 1 : 0, T, C, M, out, eps);
     return hipGetLastError();
 }
 

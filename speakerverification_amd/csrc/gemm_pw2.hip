@@ -246,6 +246,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         }
     }
     __syncthreads();
+    if (p.colsum) {
+        // per-utterance column sums of this tile (feeds the SE mean / the ASP global statistics without
+        // another pass over HBM): thread = (column, 128-row half), bf16 values straight from the LDS image
+        // thread = (8-byte chunk of 4 channels, 32-row group): 32 ds_read_b64 per thread
+        const int c8 = tid & 63, rg = tid >> 6;                 // chunk column 0..63, row group 0..7
+        const int rb = (m0 / p.T + 1) * p.T - m0;            // first tile row that belongs to the next utterance
+        const int rend = min(256, p.M - m0);
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
+        typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+        const int lo = rg * 32, hi = min(rg * 32 + 32, rend);
+        const int mid = max(lo, min(hi, rb));                   // rows [lo, mid) -> segment 0, [mid, hi) -> segment 1
+        for (int row = lo; row < mid; ++row) {
+            const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(smem + row * ORB + ((c8 ^ (row & 15)) << 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = static_cast<float>(v4[e]);
+                s0[e] += v;
+                if (p.colsum_sq) q0[e] = fmaf(v, v, q0[e]);
+            }
+        }
+        for (int row = mid; row < hi; ++row) {
+            const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(smem + row * ORB + ((c8 ^ (row & 15)) << 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = static_cast<float>(v4[e]);
+                s1[e] += v;
+                if (p.colsum_sq) q1[e] = fmaf(v, v, q1[e]);
+            }
+        }
+        const int n = n0 + c8 * 4;
+        if (n < p.N) {
+            const int64_t o = ((int64_t)(tile_m * 8 + rg) * 2) * p.N + n;
+            *reinterpret_cast<f32x4*>(p.colsum + o) = f32x4{s0[0], s0[1], s0[2], s0[3]};
+            *reinterpret_cast<f32x4*>(p.colsum + o + p.N) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+            if (p.colsum_sq) {
+                *reinterpret_cast<f32x4*>(p.colsum + p.colsum_stride + o) = f32x4{q0[0], q0[1], q0[2], q0[3]};
+                *reinterpret_cast<f32x4*>(p.colsum + p.colsum_stride + o + p.N) = f32x4{q1[0], q1[1], q1[2], q1[3]};
+            }
+        }
+    }
     char* Yb = reinterpret_cast<char*>(p.Y);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {               // 256 rows x 32 16-byte chunks / 512 threads
@@ -277,6 +317,7 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
 
 bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
     if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE || p.A2 || p.R) return false;
+    if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;      // at most one utterance boundary per 256-row tile
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
     if (p.N < 256 || p.Kp % 64 != 0 || p.N % 8 != 0 || p.lda % 8 != 0 || p.ldy % 8 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y)) & 15) return false;

@@ -22,6 +22,12 @@ struct GemmParams {
     const float* bias_utt = nullptr;
     const float* scale = nullptr;
     const float* shift = nullptr;
+    // pw2 only: per-utterance column sums of the (bf16-rounded) output, taken from the LDS output tile:
+    //   colsum[((tile_m*8 + rg)*2 + seg) * N + n] = sum over the rows of 32-row group rg that belong to
+    //   utterance (tile_m*256 / T + seg); with colsum_sq the sums of squares follow at offset colsum_stride.
+    float* colsum = nullptr;
+    int colsum_sq = 0;
+    int64_t colsum_stride = 0;
     const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
     const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last (generic kernel only)
     int ldr = 0;
@@ -111,6 +117,9 @@ hipError_t launch_se_mlp(const float* mean, const float* W1, const float* b1, co
 // out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
                            bool bf16, int B, int T, int C, hipStream_t stream);
+// reduce the pw2 column-sum partials: out (B, C) = mean over T  [and out (B, 2C) = [mean | std] with sq]
+hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
+                                  float* out, float eps, hipStream_t stream);
 // strided 2-D copy of a column block: dst[m, 0:C) = src[m, 0:C)
 hipError_t launch_copy_cols(const void* src, int lds, void* dst, int ldd, bool bf16, int M, int C, hipStream_t stream);
 // attentive statistics: softmax over T of logits (fp32, ld = C), weighted mean / std of X, then

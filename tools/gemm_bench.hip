@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     else { fill_f32<<<2048, 256>>>((float*)A, maxA, 1, 1.0f); fill_f32<<<2048, 256>>>((float*)A2, maxA, 2, 1.0f); fill_f32<<<2048, 256>>>((float*)W, maxW, 3, 0.05f); }
     fill_f32<<<16, 256>>>(bias, 4096, 4, 0.1f); fill_f32<<<16, 256>>>(scale, 4096, 5, 1.0f); fill_f32<<<16, 256>>>(shift, 4096, 6, 0.1f);
     void* zp; CK(hipMalloc(&zp, 256)); CK(hipMemset(zp, 0, 256));
+    float* csum; const int64_t csr = (int64_t)(M / 256 + 2) * 16 * 3 * C; CK(hipMalloc(&csum, 2 * csr * 4));
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -58,6 +59,7 @@ int main(int argc, char** argv) {
         p.M = s.M; p.N = s.N; p.K = s.K; p.Kp = round_up(s.K, gemm_bk(bf16)); p.Wrows = round_up(s.N, 128);
         p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = T;
         p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = PAD_REFLECT; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = debug; p.zero_page = zp;
+        if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; }
         for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
         CK(hipStreamSynchronize(st));
         const int it = 5;
