@@ -1169,13 +1169,13 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
 }
 
 // out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed)
-static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO) {
+static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO, int64_t ldo) {
     if (D % 32 != 0) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embedding dim %d must be a multiple of 32", D);
     if (Na > (1 << 30) / 1 || Nb > (1 << 30)) SV_FAIL(h, SVHIP_ERR_INVALID, "matrix too large");
     GemmParams p;
     p.A = dA; p.W = dB; p.Y = dO;
     p.M = (int)Na; p.N = (int)Nb; p.K = D; p.Kp = D; p.Wrows = (int)Nb;
-    p.lda = D; p.ldy = (int)Nb; p.T = 1;
+    p.lda = D; p.ldy = (int)ldo; p.T = 1;
     hipStream_t st = h->stream;
     return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
 }
@@ -1191,7 +1191,7 @@ int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float*
     if ((rc = tA.in(A, (size_t)Na * D * 4, din, &dA))) return rc;
     if ((rc = tB.in(B, (size_t)Nb * D * 4, din, &dB))) return rc;
     if ((rc = tO.out(out, (size_t)Na * Nb * 4, dout, &dO))) return rc;
-    if ((rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO))) return rc;
+    if ((rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb))) return rc;
     if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream));
     if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
     return SVHIP_OK;
@@ -1214,13 +1214,14 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     if ((rc = tM.out(mu, (size_t)N * 4, dout, &dM))) return rc;
     if ((rc = tS.out(sigma, (size_t)N * 4, dout, &dS))) return rc;
     // cohort scores are produced slab by slab into an HBM scratch (rows x K fp32) and reduced per row
-    const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 30) / ((int64_t)K * 4)));
+    const int64_t ldk = (K + 3) & ~3;                             // row stride of the slab (16-byte rows for the DMA GEMM)
+    const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 31) / (ldk * 4)));
     float* slab = nullptr;
-    SV_HIP(h, hipMalloc((void**)&slab, (size_t)slab_rows * K * 4));
+    SV_HIP(h, hipMalloc((void**)&slab, (size_t)slab_rows * ldk * 4));
     for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
         const int64_t rows = std::min(slab_rows, N - r0);
-        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab);
-        if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
+        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab, ldk);
+        if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, (int)ldk, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
         if (rc) break;
     }
     (void)hipStreamSynchronize(h->stream);

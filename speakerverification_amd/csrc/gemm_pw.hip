@@ -310,9 +310,15 @@ bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     const int bk = bf16 ? 64 : 32;
     if (p.taps > 1 || p.A2 || p.R) return false;
     if (p.K != p.Kp || p.Kp % bk != 0) return false;         // every K chunk of every row must be real data
-    if (p.N % 8 != 0 || p.lda % epc != 0) return false;
     const bool out_f32 = !bf16 || p.out_f32;
-    if (p.ldy % (out_f32 ? 4 : 8) != 0) return false;
+    if (p.lda % epc != 0) return false;
+    if (out_f32) {
+        // 16-byte output chunks = 4 floats: a ragged last chunk may spill into row padding, never into the next row
+        if (p.ldy % 4 != 0 || p.ldy < ((p.N + 3) & ~3)) return false;
+        if (p.N % 4 != 0 && (p.bias || p.scale || p.bias_utt)) return false;      // per-channel vectors are read as float4
+    } else if (p.N % 8 != 0 || p.ldy % 8 != 0) {
+        return false;
+    }
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y)) & 15) return false;
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
     if (p.scale && ((reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15)) return false;

@@ -167,7 +167,7 @@ hipError_t launch_l2norm(float* E, int64_t N, int D, hipStream_t stream);
 hipError_t launch_score_pairs(const float* E, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out, hipStream_t stream);
 hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const float* sigma, const int32_t* ia,
                                const int32_t* ib, int64_t P, float* out, hipStream_t stream);
-// S (rows x K) fp32 cohort scores -> mean / population std of the `top` largest per row
-hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int top, float* mu, float* sigma, hipStream_t stream);
+// S (rows x K, row stride ld) fp32 cohort scores -> mean / population std of the `top` largest per row
+hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int top, float* mu, float* sigma, hipStream_t stream);
 
 }  // namespace svhip

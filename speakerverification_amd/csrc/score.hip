@@ -84,60 +84,211 @@ __device__ __forceinline__ int wave_isum(int v) {
     return v;
 }
 
-// One wavefront per row; the row (K fp32 scores) is staged in LDS as sortable keys, the `top`-th
-// largest key is found by a 32-step bitwise search (count(key >= candidate) by ds_read_b128 sweeps),
-// then mean / population std of the selected values (ties at the threshold counted exactly).
-__global__ __launch_bounds__(256) void topk_stats_kernel(const float* __restrict__ S, int64_t rows, int K, int Kp, int top,
-                                                         int rows_per_wg, float* __restrict__ mu, float* __restrict__ sigma) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* keys = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * Kp;
-    const int64_t row = (int64_t)blockIdx.x * rows_per_wg + wave;
-    const bool active = (wave < rows_per_wg) && (row < rows);
-    if (active) {
-        const float* __restrict__ s = S + row * K;
-        for (int k = lane; k < Kp; k += 64) keys[k] = (k < K) ? fkey(s[k]) : 0u;    // pad = smallest key
-    }
-    __syncthreads();
-    if (!active) return;
-    const u32x4* k4 = reinterpret_cast<const u32x4*>(keys);
-    const int n4 = Kp >> 2;
+// Exact mean / population std of the `top` largest of n sortable keys held as `per` keys per lane
+// (unused slots = key 0, the smallest): 32-step bitwise search for the top-th largest key, ties at the
+// threshold counted exactly.
+template <int PER>
+__device__ __forceinline__ void select_stats(const uint32_t (&k)[PER], int top, float& mean_out, float& sd_out) {
     uint32_t prefix = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit);
         int cnt = 0;
-        for (int i = lane; i < n4; i += 64) {
-            const u32x4 v = k4[i];
-            cnt += (v[0] >= cand) + (v[1] >= cand) + (v[2] >= cand) + (v[3] >= cand);
-        }
-        cnt = wave_isum(cnt);
-        if (cnt >= top) prefix = cand;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) cnt += (k[j] >= cand);
+        if (wave_isum(cnt) >= top) prefix = cand;
     }
-    // prefix == key of the top-th largest element
     const float vth = fkey_inv(prefix);
     float sum = 0.0f;
     int cgt = 0;
-    for (int i = lane; i < n4; i += 64) {
-        const u32x4 v = k4[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (v[j] > prefix) { sum += fkey_inv(v[j]); ++cgt; }
-    }
+    for (int j = 0; j < PER; ++j)
+        if (k[j] > prefix) { sum += fkey_inv(k[j]); ++cgt; }
     sum = wave_sum(sum);
     cgt = wave_isum(cgt);
     const float nt = (float)(top - cgt);
     const float mean = (sum + nt * vth) / (float)top;
     float sq = 0.0f;
-    for (int i = lane; i < n4; i += 64) {
-        const u32x4 v = k4[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (v[j] > prefix) { const float d = fkey_inv(v[j]) - mean; sq = fmaf(d, d, sq); }
-    }
+    for (int j = 0; j < PER; ++j)
+        if (k[j] > prefix) { const float d = fkey_inv(k[j]) - mean; sq = fmaf(d, d, sq); }
     sq = wave_sum(sq);
     const float dth = vth - mean;
-    const float var = (sq + nt * dth * dth) / (float)top;
-    if (lane == 0) { mu[row] = mean; sigma[row] = sqrtf(var); }
+    mean_out = mean;
+    sd_out = sqrtf((sq + nt * dth * dth) / (float)top);
+}
+
+constexpr int TOPK_CAP = 512;            // candidate slots per row (8 per lane)
+
+// Register-resident variant: one wavefront per row, the row lives in NV float4 registers per lane (K <= 256*NV),
+// only the <= 512 compacted candidates touch LDS (2 KiB per wave), so many waves per CU hide the HBM latency of
+// the slab read.  Same selection logic as topk_stats_kernel; the rare fallback is the exact 32-pass search
+// over the registers.
+template <int NV>
+__global__ __launch_bounds__(256) void topk_stats_reg_kernel(const float* __restrict__ S, int64_t rows, int K, int ld, int top,
+                                                             float* __restrict__ mu, float* __restrict__ sigma) {
+    __shared__ uint32_t cand_all[4][TOPK_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    uint32_t* cand = cand_all[wave];
+    const float* __restrict__ s = S + row * ld;
+    u32x4 kv[NV];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int k0 = (j * 64 + lane) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 < K) v = *reinterpret_cast<const f32x4*>(s + k0);            // ld % 4 == 0: a ragged tail reads row padding
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = k0 + e < K;
+            kv[j][e] = in ? fkey(v[e]) : 0u;
+            if (in) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+        }
+    }
+    float mean_out = 0.f, sd_out = 0.f;
+    bool done = false;
+    if (top <= 256 && K >= 4 * top) {
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        const float m = s1 / (float)K;
+        const float sd = sqrtf(fmaxf(s2 / (float)K - m * m, 0.0f));
+        const float frac = 2.0f * (float)top / (float)K;
+        const float tq = sqrtf(-2.0f * logf(fmaxf(frac, 1e-6f)));
+        float z = tq - (2.30753f + 0.27061f * tq) / (1.0f + 0.99229f * tq + 0.04481f * tq * tq);
+        for (int attempt = 0; attempt < 4 && !done; ++attempt) {
+            const uint32_t tkey = fkey(m + z * sd);
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool pred = kv[j][e] > tkey;
+                    const unsigned long long mask = __ballot(pred);
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pred && pos < TOPK_CAP) cand[pos] = kv[j][e];
+                    base += __popcll(mask);
+                }
+            if (base >= top && base <= TOPK_CAP) {
+                uint32_t ck[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int idx = lane + 64 * j; ck[j] = idx < base ? cand[idx] : 0u; }
+                select_stats<8>(ck, top, mean_out, sd_out);
+                done = true;
+            } else {
+                z += (base < top) ? -0.6f : 0.5f;
+            }
+        }
+    }
+    if (!done) {
+        uint32_t flat[NV * 4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) flat[j * 4 + e] = kv[j][e];
+        select_stats<NV * 4>(flat, top, mean_out, sd_out);
+    }
+    if (lane == 0) { mu[row] = mean_out; sigma[row] = sd_out; }
+}
+
+// One wavefront per row.  The row (K fp32 scores, row stride ld) is staged in LDS as sortable keys.
+// Fast path (top <= 256, K >= 4*top): a threshold tau = mean + z*std picked from the row's own first
+// two moments keeps <= 512 candidates (expected ~2*top), which are compacted with wave ballots and
+// selected exactly in registers; tau is re-aimed at most 3 times.  Anything else (small K, unlucky
+// distributions) takes the exact 32-pass search over the whole row.  Both paths give the same answer.
+__global__ __launch_bounds__(256) void topk_stats_kernel(const float* __restrict__ S, int64_t rows, int K, int ld, int Kp, int top,
+                                                         int rows_per_wg, float* __restrict__ mu, float* __restrict__ sigma) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * (Kp + TOPK_CAP);
+    uint32_t* cand = keys + Kp;
+    const int64_t row = (int64_t)blockIdx.x * rows_per_wg + wave;
+    const bool active = (wave < rows_per_wg) && (row < rows);
+    float s1 = 0.0f, s2 = 0.0f;
+    if (active) {
+        const float* __restrict__ s = S + row * ld;
+        for (int k = lane; k < Kp; k += 64) {
+            const float v = (k < K) ? s[k] : 0.0f;
+            keys[k] = (k < K) ? fkey(v) : 0u;                                       // pad = smallest key
+            if (k < K) { s1 += v; s2 = fmaf(v, v, s2); }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const u32x4* k4 = reinterpret_cast<const u32x4*>(keys);
+    const int n4 = Kp >> 2;
+    float mean_out, sd_out;
+    bool done = false;
+    if (top <= 256 && K >= 4 * top) {
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        const float m = s1 / (float)K;
+        const float sd = sqrtf(fmaxf(s2 / (float)K - m * m, 0.0f));
+        // aim for ~2*top candidates: upper-tail quantile of a normal with the row's moments
+        const float frac = 2.0f * (float)top / (float)K;                         // <= 0.5
+        const float tq = sqrtf(-2.0f * logf(fmaxf(frac, 1e-6f)));               // Abramowitz-Stegun 26.2.22 inverse normal tail
+        float z = tq - (2.30753f + 0.27061f * tq) / (1.0f + 0.99229f * tq + 0.04481f * tq * tq);
+        for (int attempt = 0; attempt < 4 && !done; ++attempt) {
+            const uint32_t tkey = fkey(m + z * sd);
+            int base = 0;
+            for (int i = lane; i < n4 + 63 - ((n4 + 63) % 64) ; i += 64) {       // every lane runs the same trip count (ballots)
+                const bool in = i < n4;
+                const u32x4 v = in ? k4[i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool pred = v[j] > tkey;
+                    const unsigned long long mask = __ballot(pred);
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pred && pos < TOPK_CAP) cand[pos] = v[j];
+                    base += __popcll(mask);
+                }
+            }
+            if (base >= top && base <= TOPK_CAP) {
+                uint32_t ck[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int idx = lane + 64 * j; ck[j] = idx < base ? cand[idx] : 0u; }
+                select_stats<8>(ck, top, mean_out, sd_out);
+                done = true;
+            } else {
+                z += (base < top) ? -0.6f : 0.5f;
+            }
+        }
+    }
+    if (!done) {
+        uint32_t prefix = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t c = prefix | (1u << bit);
+            int cnt = 0;
+            for (int i = lane; i < n4; i += 64) {
+                const u32x4 v = k4[i];
+                cnt += (v[0] >= c) + (v[1] >= c) + (v[2] >= c) + (v[3] >= c);
+            }
+            if (wave_isum(cnt) >= top) prefix = c;
+        }
+        const float vth = fkey_inv(prefix);
+        float sum = 0.0f;
+        int cgt = 0;
+        for (int i = lane; i < n4; i += 64) {
+            const u32x4 v = k4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > prefix) { sum += fkey_inv(v[j]); ++cgt; }
+        }
+        sum = wave_sum(sum);
+        cgt = wave_isum(cgt);
+        const float nt = (float)(top - cgt);
+        const float mean = (sum + nt * vth) / (float)top;
+        float sq = 0.0f;
+        for (int i = lane; i < n4; i += 64) {
+            const u32x4 v = k4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (v[j] > prefix) { const float d = fkey_inv(v[j]) - mean; sq = fmaf(d, d, sq); }
+        }
+        sq = wave_sum(sq);
+        const float dth = vth - mean;
+        mean_out = mean;
+        sd_out = sqrtf((sq + nt * dth * dth) / (float)top);
+    }
+    if (lane == 0) { mu[row] = mean_out; sigma[row] = sd_out; }
 }
 
 }  // namespace
@@ -161,11 +312,17 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
     return hipGetLastError();
 }
 
-hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int top, float* mu, float* sigma, hipStream_t stream) {
+hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int top, float* mu, float* sigma, hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
-    if (top <= 0 || top > K) return hipErrorInvalidValue;
+    if (top <= 0 || top > K || ld < K) return hipErrorInvalidValue;
+    if (ld % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0 && K <= 256 * 24) {      // register-resident rows
+        const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+        if (K <= 256 * 8) hipLaunchKernelGGL(topk_stats_reg_kernel<8>, grid, block, 0, stream, S, rows, K, ld, top, mu, sigma);
+        else hipLaunchKernelGGL(topk_stats_reg_kernel<24>, grid, block, 0, stream, S, rows, K, ld, top, mu, sigma);
+        return hipGetLastError();
+    }
     const int Kp = (K + 3) & ~3;
-    const size_t row_bytes = (size_t)Kp * sizeof(uint32_t);
+    const size_t row_bytes = (size_t)(Kp + TOPK_CAP) * sizeof(uint32_t);
     int rpw = (int)((150 * 1024) / row_bytes);
     if (rpw < 1) return hipErrorInvalidValue;          // K > 38400: not supported by the LDS-resident selection
     if (rpw > 4) rpw = 4;
@@ -175,7 +332,7 @@ hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int top, float
         hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(topk_stats_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), lds, stream, S, rows, K, Kp, top, rpw, mu, sigma);
+    hipLaunchKernelGGL(topk_stats_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), lds, stream, S, rows, K, ld, Kp, top, rpw, mu, sigma);
     return hipGetLastError();
 }
 
