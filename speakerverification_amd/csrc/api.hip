@@ -91,6 +91,7 @@ struct svhip_handle {
     ConvLayer rn_att0, rn_att3;
     LinearLayer rn_fc;
     void* rn_buf[6] = {};                 // activation ping-pong buffers
+    float* rn_scratch = nullptr;
     float *rn_stats = nullptr, *rn_mean = nullptr, *rn_s = nullptr, *rn_logits = nullptr, *rn_pooled = nullptr;
     int rn_T1 = 0;
     const void* rn_dbg_x = nullptr; int rn_dbg_T = 0, rn_dbg_C = 0;   // SVHIP_RN_STOP developer hook (tests)
@@ -626,6 +627,7 @@ int alloc_workspace(svhip_handle* h) {
         }
         if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
         if ((rc = dev_alloc(h, &h->rn_mean, B * 512))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_scratch, B * 16 * 512))) return rc;
         if ((rc = dev_alloc(h, &h->rn_s, B * 512))) return rc;
         int tf = h->rn_T1;
         for (int i = 0; i < 6; ++i) tf /= 3;                      // six max_pool1d(3) stages follow the front-end
@@ -862,7 +864,7 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
             y = hb;
         }
         // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
-        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, h->rn_mean, st); }))) return rc;
+        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, h->rn_mean, st, h->rn_scratch, 16); }))) return rc;
         if ((rc = run(h, "rn_afms_fc", 2.0 * B * K.cout * K.cout, [&]() {
                  return launch_rowvec_linear(h->rn_mean, K.cout, K.afms_fc.W, K.afms_fc.bias, h->rn_s, K.cout, B, K.cout, K.cout, ACT_SIGMOID, st);
              }))) return rc;

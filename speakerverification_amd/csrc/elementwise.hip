@@ -69,6 +69,50 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ X, 
         }
 }
 
+// ---- long-T column mean in two deterministic stages (RawNet2 AFMS: T up to 10583, C = 128) -------------------
+// stage 1: grid (ceil(C / (64*VEC)), B, TS): partial sums over a T-slice -> part (B, TS, C);  stage 2: sum / T.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_slice_kernel(const T* __restrict__ X, int ldx, int Tn, int C, int TS,
+                                                           float* __restrict__ part) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float red[4][64 * VEC];
+    const int b = blockIdx.y, ts = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * VEC;
+    const bool ok = c0 < C;
+    const int per = (Tn + TS - 1) / TS;
+    const int t0 = ts * per, t1 = min(Tn, t0 + per);
+    const T* __restrict__ base = X + (int64_t)b * Tn * ldx + c0;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.0f;
+    if (ok)
+        for (int t = t0 + wave; t < t1; t += 4) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(base + (int64_t)t * ldx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += v.get(j);
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[wave][lane * VEC + j] = s[j];
+    __syncthreads();
+    if (wave == 0 && ok)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int e = lane * VEC + j;
+            part[((int64_t)b * TS + ts) * C + c0 + j] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        }
+}
+
+__global__ __launch_bounds__(256) void colsum_slice_finalize_kernel(const float* __restrict__ part, int TS, int C, int Tn,
+                                                                    float* __restrict__ mean, int n) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const int b = id / C, c = id - b * C;
+    float s = 0.0f;
+    for (int ts = 0; ts < TS; ++ts) s += part[((int64_t)b * TS + ts) * C + c];
+    mean[id] = s / (float)Tn;
+}
+
 // ---- small-M linear: out[b, n] = act(bias[n] + W[n, :] . in[b, :]) -----------------------------
 // grid (ceil(N / 8), ceil(B / 8)), block 256: an 8 (n) x 8 (b) output block per workgroup, K split
 // over the 4 waves, float4 loads along K (both operands are read once per block instead of once per
@@ -297,9 +341,20 @@ inline int grid_for(int64_t work_items) {
 
 }  // namespace
 
-hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream) {
+hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
+                          float* scratch, int scratch_slices) {
     const int vec = bf16 ? 8 : 4;
     if (C % vec != 0 || ldx % vec != 0) return hipErrorInvalidValue;
+    const int gx = (C + 64 * vec - 1) / (64 * vec);
+    if (scratch && scratch_slices > 1 && T >= 1024 && gx * B < 2048) {       // too few workgroups for a long T: slice it
+        const int TS = scratch_slices;
+        dim3 grid(gx, B, TS), block(256);
+        if (bf16) hipLaunchKernelGGL(colsum_slice_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, TS, scratch);
+        else hipLaunchKernelGGL(colsum_slice_kernel<float>, grid, block, 0, stream, (const float*)X, ldx, T, C, TS, scratch);
+        const int n = B * C;
+        hipLaunchKernelGGL(colsum_slice_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, TS, C, T, mean, n);
+        return hipGetLastError();
+    }
     dim3 grid((C + 64 * vec - 1) / (64 * vec), B), block(256);
     if (bf16) hipLaunchKernelGGL((colstats_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, mean, C, 0.f);
     else hipLaunchKernelGGL((colstats_kernel<float, false>), grid, block, 0, stream, (const float*)X, ldx, T, C, mean, C, 0.f);

@@ -302,7 +302,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         return hipErrorInvalidValue;
     }
     if (p.bias_utt && (p.T <= 0)) return hipErrorInvalidValue;
-    if (p.taps > 1 && gemm_pw2_supported(p, bf16)) return launch_gemm_pw2(p, stream);       // conv-gather on the LDS-DMA kernel
+    if (p.taps > 1 && gemm_pw2_supported(p, bf16)) return launch_gemm_pw2(p, stream);       // conv-gather on the LDS-DMA kernels
     if (gemm_pw_supported(p, bf16)) return launch_gemm_pw(p, bf16, stream);
     return bf16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }

@@ -94,7 +94,9 @@ template <> struct Frag<bf16_t> {
     }
 };
 
-template <typename T, int EPI, bool OUT_F32, int PBN>
+// CONV: the A operand is the im2col view of a dilated 1-D convolution (per-lane DMA source = frame
+// t + (tap - taps/2)*dil of the same utterance, reflect / zero padded; padded chunks read a zero page).
+template <typename T, int EPI, bool OUT_F32, int PBN, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     typedef Frag<T> FR;
     typedef typename FR::chunk_t chunk_t;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     // ---- DMA geometry: wave w fills 8-row groups g = w + 8j (j < 4: A rows, j >= 4: W rows) ----
     const char* src[LOADS_PER_STAGE];
     int dst[LOADS_PER_STAGE];
+    int cutt[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0}, clc[4] = {0, 0, 0, 0};     // CONV: utterance base row, frame, logical chunk
 #pragma unroll
     for (int j = 0; j < LOADS_PER_STAGE; ++j) {
         const int g = wave + 8 * j;                                    // 8-row group: 0..31 A, 32.. W
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
             const int m = min(m0 + r, p.M - 1);
             src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * EPC) * sizeof(T);
             dst[j] = g * 1024;
+            if (CONV) { const int b = m / p.T; cutt[j] = b * p.T; ct[j] = m - b * p.T; clc[j] = lc; }
         } else {
             const int n = min(n0 + r, p.Wrows - 1);
             src[j] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + lc * EPC) * sizeof(T);
@@ -147,8 +151,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     auto issue = [&](int stage, int kt) {
         char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int j = 0; j < LOADS_PER_STAGE; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src[j] + (int64_t)kt * ROWB), (lds_void*)(base + dst[j]), 16, 0, 0);
+        for (int j = 0; j < LOADS_PER_STAGE; ++j) {
+            const char* s = src[j] + (int64_t)kt * ROWB;
+            if (CONV && j < 4) {
+                const int k = kt * BK + clc[j] * EPC;
+                const int tap = k / p.cin;
+                int tt = ct[j] + (tap - (p.taps >> 1)) * p.dil;
+                bool ok = k < p.K;
+                if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
+                else ok = ok && tt >= 0 && tt < p.T;
+                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cutt[j] + tt) * p.lda + (k - tap * p.cin)) * sizeof(T)
+                       : reinterpret_cast<const char*>(p.zero_page);
+            }
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dst[j]), 16, 0, 0);
+        }
     };
 
     f32x16 acc[MI][2];
@@ -240,6 +256,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
                     if (EPI == EPI_BN_LRELU03) t = t > 0.0f ? t : 0.3f * t;
                     v[e] = t;
                 }
+                if (p.R && nok) {                                           // residual (RawNet2 conv2 + shortcut)
+                    const int m = min(m0 + ml, p.M - 1);
+                    const T* rp = reinterpret_cast<const T*>(p.R) + (int64_t)m * p.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += to_f32<T>(rp[e]);
+                }
                 if (OUT_F32) {
                     const int c16 = nl >> 2;                                  // 16-byte chunk index
                     f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -277,18 +299,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     }
 }
 
-template <typename T, int EPI, bool OUT_F32, int BN>
-hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+template <typename T, int EPI, bool OUT_F32, int BN, bool CONV>
+hipError_t launch_inst2(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + PBM - 1) / PBM, ntn = (p.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<BN>::LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pw_kernel<T, EPI, OUT_F32, BN>), dim3(ntm * ntn), dim3(512), TileCfg<BN>::LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>), dim3(ntm * ntn), dim3(512), TileCfg<BN>::LDS, stream, p);
     return hipGetLastError();
+}
+
+template <typename T, int EPI, bool OUT_F32, int BN>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+    return p.taps > 1 ? launch_inst2<T, EPI, OUT_F32, BN, true>(p, stream) : launch_inst2<T, EPI, OUT_F32, BN, false>(p, stream);
 }
 
 template <typename T, bool OUT_F32, int BN>
@@ -308,8 +335,15 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     const int epc = bf16 ? 8 : 4;
     const int bk = bf16 ? 64 : 32;
-    if (p.taps > 1 || p.A2 || p.R) return false;
-    if (p.K != p.Kp || p.Kp % bk != 0) return false;         // every K chunk of every row must be real data
+    if (p.A2) return false;
+    if (p.Kp % bk != 0) return false;
+    if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; padded k / frames read the zero page
+        if (!p.zero_page || p.cin % epc != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;
+        if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return false;
+    } else if (p.K != p.Kp) {
+        return false;                                        // every K chunk of every row must be real data
+    }
+    if (p.R && (p.ldr % 4 != 0 || (reinterpret_cast<uintptr_t>(p.R) & 7))) return false;
     const bool out_f32 = !bf16 || p.out_f32;
     if (p.lda % epc != 0) return false;
     if (out_f32) {

@@ -105,7 +105,9 @@ hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, i
 // Frame-major reductions / elementwise (activation dtype templated inside)
 // ---------------------------------------------------------------------------------------------
 // mean over the T rows of each utterance: X (B*T, ldx) cols [0,C) -> mean (B, C) fp32
-hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream);
+// (optional scratch of B * scratch_slices * C floats: long T with few channels is reduced in two stages)
+hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
+                          float* scratch = nullptr, int scratch_slices = 0);
 // mean and population std over T (two pass, clamp 1e-12 as ECAPA_TDNN.py:222-227): -> stats (B, 2C) = [mean | std]
 hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int C, float* stats, float eps, hipStream_t stream);
 // out[b, n] = act( bias[n] + sum_k W[n, k] * in[b, k] ), all fp32 (small-M linear layers)
