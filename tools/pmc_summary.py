@@ -20,6 +20,8 @@ LABELS = {"gemm_pw2_kernel": "gemm_pw2", "gemm_pw_kernel": "gemm_pw", "res2net_c
 
 
 def label(name):
+    if "gemm_pw2_kernel" in name and name.replace(" ", "").split(">(")[0].endswith("true"):
+        return "gemm_pw2_conv"                      # gemm_pw2_kernel<EPI, M16, CONV = true>
     for k, v in LABELS.items():
         if k in name:
             return v
