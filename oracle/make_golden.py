@@ -245,6 +245,35 @@ def golden_e2e(ref):
     print("e2e fixture: scores", out["scores_ne2"][:4], "...")
 
 
+def golden_fusion(ref):
+    """Raw_ECAPA_sinc_asp (the repo's fusion model, next row SURVEY 8f-3): ECAPA C=512 on raw mel power
+    (features='raw': NO log / mean-norm, ECAPA_TDNN.py:473) concatenated with RawNet2 sinc/asp (512-192 dims)."""
+    from models import Raw_ECAPA_sinc_asp as fus     # reference module; needs the OracleMel stub installed by golden_e2e
+
+    kwargs = dict(n_mels=80, augment=False, augment_options={"augment_chain": []}, features="raw",
+                  audio_spec=dict(sample_rate=16000, sentence_len=2.0, win_len=0.025, hop_len=0.01, channels=1))
+    model = fus.MainModel(nOut=512, **kwargs).eval()
+    sd_e = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=1)
+    sd_r = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1)
+    model.ECAPA_TDNN.load_state_dict(torch_sd(sd_e), strict=True)
+    model.rawnet2v2.load_state_dict(torch_sd(sd_r), strict=True)
+    keys = [k for k in model.state_dict().keys()]
+    x = torch.from_numpy(synth.synth_waveforms(2, 32000, seed=20220829))
+    with torch.no_grad():
+        out = model(x)
+        # oracle composition must agree
+        mel = o_fbank.melspectrogram(x)
+        o1 = o_ecapa.ecapa_forward(mel, o_ecapa.to_torch_sd(sd_e), features="raw")
+        o2 = o_rawnet2.rawnet2_forward(x, o_ecapa.to_torch_sd(sd_r))
+        oo = torch.cat([o1, o2], dim=-1)
+    err = float((oo - out).abs().max())
+    print(f"fusion: oracle-vs-reference max|d| = {err:.3e}, out {tuple(out.shape)} |max| {float(out.abs().max()):.2f}")
+    assert err < 1e-4 * float(out.abs().max())
+    prefixes = sorted({k.split(".")[0] for k in keys})
+    np.savez_compressed(os.path.join(GOLD, "fusion_raw_ecapa.npz"), out=out.numpy(), n_keys=len(keys),
+                        prefixes=np.array(prefixes))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -267,6 +296,12 @@ def main():
         import traceback
         traceback.print_exc()
         print("e2e fixture skipped:", repr(e))
+    try:
+        golden_fusion(ref)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("fusion fixture skipped:", repr(e))
     with open(os.path.join(GOLD, "param_specs.json"), "w") as f:
         json.dump({k: [[n, list(s)] for n, s in v] for k, v in specs.items()}, f)
     print("golden fixtures written to", GOLD)
