@@ -106,6 +106,14 @@ int svhip_embed_features(svhip_handle* h, const float* feat, int32_t B, int32_t 
  * compute_features then __S__.forward (ECAPA), or __S__.forward directly (RawNet2). */
 int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* emb_out, int32_t flags);
 
+/* Eval-mode cropping on device.  Replaces, for decoded 16-bit PCM, the cropping half of loadWAV
+ * (src/processing/audio_loader.py:110-150): wrap-pad files not longer than L to L+1 samples, take num_eval
+ * crops of L samples at int(linspace(0, len - L, num_eval)), scale by 1/32768 (soundfile float32).  pcm holds
+ * the files back to back; file f is pcm[offsets[f] .. offsets[f] + lengths[f]).  crops_out is
+ * (n_files * num_eval, L) fp32.  Ships int16 over PCIe instead of num_eval overlapping fp32 crops. */
+int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, const int64_t* offsets, const int32_t* lengths,
+                     int32_t n_files, int32_t num_eval, int32_t L, float* crops_out, int32_t flags);
+
 /* Scoring.  Replaces the per-trial loop of ModelHandling.evaluateFromList / testFromList
  * (src/model.py:415-448,526-553) and src/utils.py:126-169.
  *   l2norm       : F.normalize(p=2, dim=1) in place (src/model.py:421-423), eps 1e-12.
@@ -113,7 +121,7 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
  *                  one crop per row).
  *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150) — fp32 MFMA.
  *   asnorm_stats : per row of E: S = cohort @ e (utils.py:142), top-`top` largest, population
- *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  Never materialises N x K.
+ *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  Cohort scores exist only as <= 2 GiB slabs.
  *   asnorm_pairs : out[p] = 0.5*((s-mu[a])/sd[a] + (s-mu[b])/sd[b]), s = E[a].E[b] (utils.py:148-160).
  * Pointers follow `flags` (indices are int32, device or host like the other inputs). */
 int svhip_l2norm(svhip_handle* h, float* E, int64_t N, int32_t D, int32_t flags);

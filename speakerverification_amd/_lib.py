@@ -53,6 +53,7 @@ _SIGNATURES = {
     "svhip_fbank": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_embed_features": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_embed_wave": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "svhip_crop_pcm16": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_l2norm": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32]),
     "svhip_score_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_score_matrix": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int32]),

@@ -1092,6 +1092,40 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
     return finish(h, flags);
 }
 
+int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, const int64_t* offsets, const int32_t* lengths,
+                     int32_t n_files, int32_t num_eval, int32_t L, float* crops_out, int32_t flags) {
+    if (!h || !pcm || !offsets || !lengths || !crops_out || n_files <= 0 || num_eval <= 0 || L <= 0 || n_samples <= 0) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    if (!din)      // host metadata is range-checked before it reaches the GPU
+        for (int f = 0; f < n_files; ++f)
+            if (lengths[f] <= 0 || offsets[f] < 0 || offsets[f] + lengths[f] > n_samples)
+                SV_FAIL(h, SVHIP_ERR_INVALID, "file %d: offset/length outside the PCM buffer", f);
+    void *d_pcm = nullptr, *d_off = nullptr, *d_len = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        if (!din) { if (d_pcm) (void)hipFree(d_pcm); if (d_off) (void)hipFree(d_off); if (d_len) (void)hipFree(d_len); }
+        if (!dout && d_out) (void)hipFree(d_out);
+    };
+    hipError_t e = hipSuccess;
+    const size_t out_bytes = (size_t)n_files * num_eval * L * 4;
+    if (!din) {
+        if ((e = hipMalloc(&d_pcm, (size_t)n_samples * 2)) == hipSuccess) e = hipMalloc(&d_off, (size_t)n_files * 8);
+        if (e == hipSuccess) e = hipMalloc(&d_len, (size_t)n_files * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_pcm, pcm, (size_t)n_samples * 2, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, (size_t)n_files * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_len, lengths, (size_t)n_files * 4, hipMemcpyHostToDevice, h->stream);
+    } else { d_pcm = const_cast<int16_t*>(pcm); d_off = const_cast<int64_t*>(offsets); d_len = const_cast<int32_t*>(lengths); }
+    if (e == hipSuccess) { if (dout) d_out = crops_out; else e = hipMalloc(&d_out, out_bytes); }
+    if (e != hipSuccess) { cleanup(); SV_FAIL(h, SVHIP_ERR_HIP, "crop staging failed: %s", hipGetErrorString(e)); }
+    int rc = run(h, "crop_pcm16", 0, [&]() { return launch_crop_pcm16((const int16_t*)d_pcm, (const int64_t*)d_off, (const int32_t*)d_len, n_files, num_eval, L, (float*)d_out, h->stream); });
+    if (!rc && !dout) e = hipMemcpyAsync(crops_out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
+    if (!(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
+    cleanup();
+    if (rc) return rc;
+    if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "crop copy-out failed: %s", hipGetErrorString(e));
+    return SVHIP_OK;
+}
+
 // ---- scoring ------------------------------------------------------------------------------------------
 namespace {
 struct TempBuf {      // device staging for host-pointer calls

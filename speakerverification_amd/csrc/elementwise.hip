@@ -333,6 +333,32 @@ __global__ __launch_bounds__(256) void asp_pool_kernel(const float* __restrict__
     }
 }
 
+// ---- eval-mode cropping on device (reference processing/audio_loader.py:110-150 for decoded PCM) -----------------
+// pcm: all files' int16 samples back to back; file f = pcm[off[f] .. off[f]+len[f]).  Crop c of file f starts at
+// int(linspace(0, n - L, num_eval)[c]) where n = len (or L+1 after wrap padding when len <= L); samples are
+// scaled by 1/32768 (soundfile's float32 convention).  One workgroup per crop.
+__global__ __launch_bounds__(256) void crop_pcm16_kernel(const int16_t* __restrict__ pcm, const int64_t* __restrict__ off,
+                                                         const int32_t* __restrict__ len, int num_eval, int L,
+                                                         float* __restrict__ out) {
+    const int crop = blockIdx.x;
+    const int f = crop / num_eval, c = crop - f * num_eval;
+    const int n0 = len[f];
+    const int n = n0 <= L ? L + 1 : n0;                       // np.pad(audio, (0, L - n0 + 1), 'wrap')
+    // np.linspace(0, n - L, num_eval)[c] = c * ((n - L) / (num_eval - 1)) in float64, truncated by int()
+    int start = 0;
+    if (num_eval > 1) {
+        const double step = (double)(n - L) / (double)(num_eval - 1);
+        start = (c == num_eval - 1) ? (n - L) : (int)((double)c * step);
+    }
+    const int16_t* __restrict__ src = pcm + off[f];
+    float* __restrict__ dst = out + (int64_t)crop * L;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        int j = start + i;
+        if (j >= n0) j = (j - n0) % n0;                       // wrap padding reads the file again from its start
+        dst[i] = (float)src[j] * (1.0f / 32768.0f);
+    }
+}
+
 inline int grid_for(int64_t work_items) {
     int64_t g = (work_items + 255) / 256;
     const int64_t cap = 256 * 8;
@@ -376,6 +402,13 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
     dim3 grid((N + 7) / 8, (B + 7) / 8), block(256);
     hipLaunchKernelGGL(rowvec_linear_kernel, grid, block, 0, stream, in, ld_in, W, bias, out, ld_out, B, N, K, act);
+    return hipGetLastError();
+}
+
+hipError_t launch_crop_pcm16(const int16_t* pcm, const int64_t* off, const int32_t* len, int n_files, int num_eval, int L,
+                             float* out, hipStream_t stream) {
+    if (n_files <= 0 || num_eval <= 0 || L <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(crop_pcm16_kernel, dim3(n_files * num_eval), dim3(256), 0, stream, pcm, off, len, num_eval, L, out);
     return hipGetLastError();
 }
 

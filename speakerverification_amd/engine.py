@@ -189,6 +189,18 @@ class Engine:
         self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
+    def crop_pcm16(self, pcm_list, num_eval, L=32000):
+        """list of 1-D int16 arrays (decoded files) -> (len(list) * num_eval, L) fp32 eval-mode crops, cropped on
+        the device (int16 travels over PCIe; reference semantics of loadWAV for 16-bit files)."""
+        lens = np.asarray([len(a) for a in pcm_list], dtype=np.int32)
+        offs = np.zeros(len(pcm_list), dtype=np.int64)
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        pcm = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int16) for a in pcm_list]))
+        out = np.empty((len(pcm_list) * num_eval, L), dtype=np.float32)
+        self._ck(self.lib.svhip_crop_pcm16(self.h, pcm.ctypes.data, pcm.size, offs.ctypes.data, lens.ctypes.data, len(pcm_list),
+                                           int(num_eval), int(L), out.ctypes.data, 0))
+        return out
+
     # ---- scoring ---------------------------------------------------------------------------------------------
     def l2norm_(self, E):
         N, D = E.shape

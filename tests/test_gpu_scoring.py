@@ -107,3 +107,14 @@ def test_large_pair_list_properties():
     ref = (E[ia.long()[:4096]] * E[ib.long()[:4096]]).sum(1).abs()
     assert float((ab[:4096] - ref).abs().max()) <= 1e-6
     eng.close()
+
+
+def test_device_cropping_matches_reference_semantics(eng):
+    """svhip_crop_pcm16 == loadWAV's eval-mode crops of 16-bit files (oracle crop_eval on x/32768), bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    files = [rng.integers(-20000, 20000, n).astype(np.int16) for n in (32000, 48000, 20000, 64000, 32001, 31999, 90011)]
+    for ne in (1, 2, 3, 10):
+        got = eng.crop_pcm16(files, ne, 32000).reshape(len(files), ne, 32000)
+        for f, a in enumerate(files):
+            want = o_scoring.crop_eval(a.astype(np.float32) / 32768.0, 32000, ne, peak_normalize=False)
+            assert np.array_equal(got[f], want), (f, ne)
