@@ -91,6 +91,27 @@ def golden_ecapa(ref, C, T, B, seed_w, seed_x, full):
     return ref_spec
 
 
+def golden_ecapa_input_norm(ref):
+    """ECAPA with input_norm=True (InstanceNorm1d(80, affine) after log / mean-norm, ECAPA_TDNN.py:406-409,477-478)
+    and with features='raw' + input_norm (the fusion-model variant: no log)."""
+    C, T, B = 64, 50, 2
+    out = {}
+    for tag, features in (("mel", "melspectrogram"), ("raw", "raw")):
+        m = ref.ECAPA_TDNN.MainModel(nOut=192, channels=[C] * 4 + [3 * C], n_mels=80, augment=False,
+                                     augment_options={"augment_chain": []}, features=features, input_norm=True).eval()
+        spec = synth.ecapa_param_spec(C=C, input_norm=True)
+        assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in spec]
+        sd = synth.synth_state_dict(spec, seed=4)
+        m.load_state_dict(torch_sd(sd), strict=True)
+        mel = torch.from_numpy(synth.synth_mel(B, 80, T, seed=13))
+        with torch.no_grad():
+            o = m(mel)
+            oo = o_ecapa.ecapa_forward(mel, o_ecapa.to_torch_sd(sd), features=features, input_norm=True)
+        assert float((o - oo).abs().max()) < 1e-5 * float(o.abs().max())
+        out["out_" + tag] = o.numpy()
+    np.savez_compressed(os.path.join(GOLD, "ecapa_C64_input_norm.npz"), **out)
+
+
 def golden_rawnet2(ref, B, seed_w, seed_x):
     model = ref.RawNet2_custom.MainModel(
         nOut=320, front_proc="sinc", aggregate="asp", att_dim=128,
@@ -241,6 +262,21 @@ def golden_e2e(ref):
     out["embed_utt0_ne3"] = emb.numpy()
     emb_arr = mh.embed_utterance((0.25 * np.sin(np.arange(40000) / 7.0)).astype(np.float32), num_eval=2, normalize=False)
     out["embed_array_ne2"] = emb_arr.numpy()
+    # cohort preparation (model.py:578-609) and CSV pair testing (model.py:455-554) through the reference
+    meta = os.path.join(tmp, "train_meta.txt")
+    with open(meta, "w") as fh:
+        fh.writelines(f"spk{i // 4} {f}\n" for i, f in enumerate(files))
+    cohort_path = os.path.join(tmp, "cohort.npy")
+    assert mh.prepare(save_path=cohort_path, prepare_type="cohorts", num_eval=2, source=meta) is True
+    out["cohort_ne2"] = np.load(cohort_path)
+    pairs = os.path.join(tmp, "pairs.txt")
+    with open(pairs, "w") as fh:
+        fh.write("audio_1,audio_2\n")
+        fh.writelines(f"{files[i]},{files[i + 1]}\n" for i in range(5))
+    os.makedirs(os.path.join(tmp, "ECAPA_TDNN/AAmSoftmaxAP/result"), exist_ok=True)
+    res = mh.testFromList(test_list=pairs, thresh_score=0.5, cohorts_path=None, num_eval=2, scoring_mode="cosine",
+                          output_file=os.path.join(tmp, "pairs_out.txt"))
+    out["test_scores_ne2"] = np.array([float(r.split(",")[2]) for r in res], np.float64)
     np.savez_compressed(os.path.join(GOLD, "e2e_config1.npz"), **out)
     print("e2e fixture: scores", out["scores_ne2"][:4], "...")
 
@@ -290,6 +326,7 @@ def main():
     specs["ecapa_C512"] = golden_ecapa(ref, C=512, T=401, B=2, seed_w=1, seed_x=11, full=False)
     specs["ecapa_C1024"] = golden_ecapa(ref, C=1024, T=401, B=2, seed_w=1, seed_x=11, full=False)
     specs["rawnet2"] = golden_rawnet2(ref, B=2, seed_w=1, seed_x=20220829)
+    golden_ecapa_input_norm(ref)
     try:
         golden_e2e(ref)
     except Exception as e:  # pragma: no cover - reported, not fatal

@@ -45,8 +45,6 @@ def ecapa_param_spec(C=1024, n_mels=80, nOut=192, input_norm=False):
     """Ordered (name, shape) list == ``ECAPA_TDNN(...).state_dict()`` of the reference."""
     C3 = 3 * C
     spec = []
-    if input_norm:  # nn.InstanceNorm1d(affine=True, track_running_stats=False), ECAPA_TDNN.py:406-409
-        spec += [("instance_norm.weight", (n_mels,)), ("instance_norm.bias", (n_mels,))]
     spec += _tdnn("blocks.0", n_mels, C, ECAPA_KERNEL_SIZES[0])
     for i in (1, 2, 3):
         p = f"blocks.{i}"
@@ -59,6 +57,9 @@ def ecapa_param_spec(C=1024, n_mels=80, nOut=192, input_norm=False):
                  (p + ".se_block.conv1.conv.bias", (SE_CHANNELS,)),
                  (p + ".se_block.conv2.conv.weight", (C, SE_CHANNELS, 1)),
                  (p + ".se_block.conv2.conv.bias", (C,))]
+    if input_norm:  # nn.InstanceNorm1d(affine=True, track_running_stats=False), ECAPA_TDNN.py:406-409;
+        # registered after the (still empty) blocks ModuleList, so it follows blocks.* in state_dict order
+        spec += [("instance_norm.weight", (n_mels,)), ("instance_norm.bias", (n_mels,))]
     spec += _tdnn("mfa", C3, C3, 1)
     spec += _tdnn("asp.tdnn", 3 * C3, ATT_CHANNELS, 1)
     spec += [("asp.conv.conv.weight", (C3, ATT_CHANNELS, 1)), ("asp.conv.conv.bias", (C3,))]

@@ -73,3 +73,40 @@ def test_single_crop_returns_vector_like_the_reference():
     assert tuple(out.shape) == (192,)
     out = enc.forward(synth.synth_waveforms(3))
     assert tuple(out.shape) == (3, 192)
+
+
+def test_prepare_cohorts_and_test_from_list_match_reference(handler, golden_dir):
+    """ModelHandling.prepare('cohorts') (src/model.py:578-609) and testFromList (:455-554) vs the reference's outputs."""
+    mh, tmp = handler
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    files, _, _ = make_e2e_files(tmp)
+    meta = os.path.join(tmp, "train_meta.txt")
+    with open(meta, "w") as fh:
+        fh.writelines(f"spk{i // 4} {f}\n" for i, f in enumerate(files))
+    out = os.path.join(tmp, "cohort.npy")
+    assert mh.prepare(save_path=out, prepare_type="cohorts", num_eval=2, source=meta) is True
+    cohort = np.load(out)
+    assert cohort.shape == g["cohort_ne2"].shape
+    assert float(np.abs(cohort - g["cohort_ne2"]).max()) <= 1e-4
+    pairs = os.path.join(tmp, "pairs.txt")
+    with open(pairs, "w") as fh:
+        fh.write("audio_1,audio_2\n")
+        fh.writelines(f"{files[i]},{files[i + 1]}\n" for i in range(5))
+    res = mh.testFromList(test_list=pairs, thresh_score=0.5, cohorts_path=None, num_eval=2, scoring_mode="cosine",
+                          output_file=os.path.join(tmp, "pairs_out.txt"))
+    got = np.array([float(r.split(",")[2]) for r in res])
+    assert float(np.abs(got - g["test_scores_ne2"]).max()) <= 1e-4
+    # AS-norm mode end to end on the device embeddings: counterpart == the reference's ZT_norm_similarity per trial
+    from oracle import scoring as o_scoring
+    import torch
+    rng = np.random.Generator(np.random.PCG64(3))
+    coh = rng.standard_normal((300, 192)).astype(np.float32)
+    coh /= np.linalg.norm(coh, axis=1, keepdims=True)
+    cpath = os.path.join(tmp, "big_cohort.npy")
+    np.save(cpath, coh)
+    trial_path = os.path.join(tmp, "trials.txt")
+    sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path=cpath,
+                                      num_eval=2, scoring_mode="norm")
+    embs = {f: torch.nn.functional.normalize(mh.embed_utterance(f, num_eval=2, normalize=False), p=2, dim=1).numpy() for f in files}
+    want = [o_scoring.zt_norm_similarity(embs[t.split()[0]], embs[t.split()[1]], coh, 200) for t in tr]
+    assert float(np.abs(np.array(sc) - np.array(want)).max()) <= 2e-3      # (s - mu) / sigma amplifies 1e-6 score noise by 1/sigma ~ 1e2
