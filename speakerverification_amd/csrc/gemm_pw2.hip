@@ -48,24 +48,47 @@ enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
 template <bool M16> __device__ __forceinline__ int hkey(int row) { return M16 ? ((0 - (row >> 2)) & 3) : ((row >> 2) & 3); }
 template <bool M16> __device__ __forceinline__ int hswz(int row, int chunk) { return row * HROWB + ((chunk ^ hkey<M16>(row)) << 4); }
 
-__device__ __forceinline__ float gelu_fast(float x) {      // erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __expf(-z * z);
-    const float erf_abs = fmaf(-poly * t, e, 1.0f);
-    return 0.5f * fmaf(fabsf(x), erf_abs, x);
+// GELU for the bf16 path: x * sigmoid(x * (c0 + c1 s + c2 s^2)), s = min(x^2, 52) (the polynomial peaks at s = 52.6, so the
+// clamp keeps it monotone); coefficients are a minimax fit to 0.5 x (1 + erf(x / sqrt 2)) over [-8, 8]: |err| <= 2.6e-5 absolute,
+// i.e. below half a bf16 ulp of every |gelu| >= 0.0066 (the output is rounded to bf16 right after).  Two elements at a
+// time so the polynomial runs on v_pk_mul_f32 / v_pk_fma_f32; coefficients pre-multiplied by -log2(e) for v_exp_f32.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_pair(f32x2_t x) {
+    constexpr float L2E = 1.44269504088896340736f;
+    const f32x2_t k0 = {-1.5950157685710367f * L2E, -1.5950157685710367f * L2E};
+    const f32x2_t k1 = {-0.07401129204455145f * L2E, -0.07401129204455145f * L2E};
+    const f32x2_t k2 = {0.0007030335770637797f * L2E, 0.0007030335770637797f * L2E};
+    f32x2_t s = x * x;
+    s.x = fminf(s.x, 52.0f); s.y = fminf(s.y, 52.0f);
+    f32x2_t q = s * k2 + k1;
+    q = q * s + k0;
+    const f32x2_t z = x * q;
+    f32x2_t e = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+    e = e + f32x2_t{1.0f, 1.0f};
+    const f32x2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return x * r;
 }
 
 template <int EPI>
-__device__ __forceinline__ float act1(float v) {
-    if (EPI == EPI_RELU) return fmaxf(v, 0.0f);
-    if (EPI == EPI_GELU) return gelu_fast(v);
-    if (EPI == EPI_LRELU03) return v > 0.0f ? v : 0.3f * v;
-    return v;
+__device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4& b4, const f32x4& sc4, const f32x4& sh4) {
+    if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2_t x = {a[2 * h] + b4[2 * h], a[2 * h + 1] + b4[2 * h + 1]};
+            const f32x2_t g = gelu_pair(x);
+            const f32x2_t sc = {sc4[2 * h], sc4[2 * h + 1]}, sh = {sh4[2 * h], sh4[2 * h + 1]};
+            const f32x2_t y = g * sc + sh;
+            v[2 * h] = y.x; v[2 * h + 1] = y.y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = a[e] + b4[e];
+            if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
+            if (EPI == EPI_LRELU03) t = t > 0.0f ? t : 0.3f * t;
+            v[e] = fmaf(t, sc4[e], sh4[e]);
+        }
+    }
 }
 
 // CONV = true: the A operand is the im2col view of a dilated 1-D convolution (k = tap*cin + c reads frame
@@ -235,11 +258,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         for (int i = 0; i < NROW; ++i) {
             const int ml = M16 ? (wm * 128 + i * 16 + r16) : (wm * 128 + i * 32 + fr);
             float v[4];
+            f32x4 a4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
-                v[e] = fmaf(act1<EPI>(a + b4[e]), sc4[e], sh4[e]);
-            }
+            for (int e = 0; e < 4; ++e)
+                a4[e] = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
+            act4<EPI>(v, a4, b4, sc4, sh4);
             typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
