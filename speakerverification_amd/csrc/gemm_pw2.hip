@@ -42,6 +42,11 @@ constexpr int PW2_LDS = NRING * HSTAGE;         // 128 KiB (also holds the 256 x
 constexpr int QGROUP_M = 4;
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
+#ifdef SVHIP_GEMM_DEBUG
+constexpr bool DBG2 = true;      // tools/gemm_bench ablations (GemmParams::debug: 1 no DMA, 2 no MFMA, 16 no fragment reads, 32 no loop barriers)
+#else
+constexpr bool DBG2 = false;
+#endif
 
 // chunk swizzle key of a row: conflict-free for the 32x32x16 fragment pattern ((row >> 2) & 3) and for the
 // 16x16x32 pattern (its 16-lane ds_read_b128 groups mix chunks c and c+1 of rows {a, a+12} / {a+4, a+8}: key -x & 3)
@@ -94,7 +99,10 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
 // CONV = true: the A operand is the im2col view of a dilated 1-D convolution (k = tap*cin + c reads frame
 // t + (tap - taps/2)*dil of the same utterance, reflect or zero padded; chunks with k >= K read a zero page):
 // only the per-lane DMA source address changes, the rest of the kernel is identical.
-template <int EPI, bool M16, bool CONV>
+// PH4 = true (needs M16, !CONV): the K loop runs in 64-wide K tiles of four phases, one accumulator quadrant (64 frames x 32
+// channels, 16 MFMAs) per phase; LDS holds 2 K tiles x {X-lo, X-hi, W-lo, W-hi} half-tiles of 128 rows x 128 bytes, so every
+// global_load_lds instruction moves whole 128-byte lines (the 32-wide ring moves half lines).  See the block comment at the loop.
+template <int EPI, bool M16, bool CONV, bool PH4>
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -118,6 +126,153 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
 
+    // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
+    f32x16 acc32[M16 ? 1 : 4][M16 ? 1 : 2];
+    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+    if (M16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[M16 ? i : 0][M16 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[M16 ? 0 : i][M16 ? 0 : j][r] = 0.0f;
+    }
+
+
+    const int fr = lane & 31, fh = lane >> 5;       // 32x32x16 fragment coordinates
+    const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
+    if constexpr (PH4) {
+        // ---- four-phase K tiles ---------------------------------------------------------------------------------------
+        // Half-tile types: 0 X-lo (frames wm*128 + 0..63 of both wave rows), 1 X-hi (+64..127), 2 W-lo (channels wn*64 + 0..31
+        // of the four wave columns), 3 W-hi (+32..63); each 128 rows x 64 k = 16 KiB, two buffers (K-tile parity) per type.
+        // Row rho of a half-tile lives at rho*128 + ((chunk ^ ((rho >> 1) & 7)) << 4): conflict-free for the ds_read_b128
+        // lane groups of the 16x16x32 fragment pattern, and the DMA (lane-linear in LDS) applies it on the source chunk.
+        // Phase g = 4k + ph reads (L) then multiplies (C):  ph 0: X-lo(k) -> quadrant (lo, W-lo)   ph 1: W-hi(k) -> (lo, hi)
+        //                                                    ph 2: X-hi(k) -> (hi, W-hi)          ph 3: W-lo(k+1) -> (hi, W-lo(k))
+        // so each half-tile is read in exactly one phase, and phase g restages the buffer read in phase g-2 with the
+        // half-tile needed in phase g+6 (issue order == need order; W-lo(0) first).  A wave waits (counted vmcnt) in phase g
+        // for what phase g+1 reads; the two wave groups run one phase apart.
+        constexpr int HT = 16384;
+        const char* src[4][2];
+        int dsto[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((rho >> 1) & 7);
+            dsto[jj] = (wave * 2 + jj) * 1024;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty) {
+                if (ty < 2) {
+                    const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
+                    src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + c * 8) * 2;
+                } else {
+                    const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
+                    src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
+                }
+            }
+        }
+        auto issue = [&](int ty, int kt) {
+            char* base = smem + ((kt & 1) * 4 + ty) * HT;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src[ty][jj] + (int64_t)kt * 128), (lds_void*)(base + dsto[jj]), 16, 0, 0);
+        };
+        auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
+            if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int nkt = p.Kp / 64;
+        const int total = 4 * nkt;                    // half-tiles of this tile's K loop
+        issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
+        if (nkt > 1) { issue(2, 1); issue(0, 1); issue(3, 1); }
+        wait_left(min(7, total) - 2);
+        __builtin_amdgcn_s_barrier();                 // W-lo(0), X-lo(0) of every wave have landed
+        if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
+
+        const int xoff = (wm * 64 + r16) * 128, woff = (wn * 32 + r16) * 128;
+        const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 32 + r16) >> 1) & 7;     // rho + 16 i keeps bits 1..3 of rho
+        bf16x8 xf[4][2], wlo[2][2], whi[2][2], wnx[2][2];
+        {   // W-lo(0)
+            const char* b = smem + 2 * HT;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = *reinterpret_cast<const bf16x8*>(b + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4));
+        }
+#define PW2_PHASE_END(gidx)                                                                         \
+        if (steady) {                                                                                   \
+            constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
+            const int kk_ = kt + (((gidx) + 6) >> 2);                                                   \
+            if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
+            __builtin_amdgcn_s_barrier();                                                               \
+        } else {                                                                                        \
+            const int g_ = 4 * kt + (gidx);                                                             \
+            if (7 + g_ < total) {                                                                       \
+                const int need = g_ + 6, kk = need >> 2, pp = need & 3;                                 \
+                if (pp == 0) issue(0, kk); else if (pp == 1) issue(3, kk); else if (pp == 2) issue(1, kk); else issue(2, kk + 1); \
+            }                                                                                           \
+            wait_left(min(8 + g_, total) - (g_ + 3));                                                   \
+            __builtin_amdgcn_s_barrier();                                                               \
+        }
+#define PW2_MFMA(I0, WARR, J0)                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                    acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+        __builtin_amdgcn_s_barrier();
+#define PW2_KTILE(steady_)                                                                          \
+        {                                                                                               \
+            constexpr bool steady = (steady_);                                                          \
+            const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
+            /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                    xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+            PW2_PHASE_END(0)                                                                            \
+            PW2_MFMA(0, wlo, 0)                                                                         \
+            /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                    whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+            PW2_PHASE_END(1)                                                                            \
+            PW2_MFMA(0, whi, 2)                                                                         \
+            /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                    xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+            PW2_PHASE_END(2)                                                                            \
+            PW2_MFMA(4, whi, 2)                                                                         \
+            /* phase 3: W-lo(kt+1) into the spare registers; X-hi x W-lo(kt) */                         \
+            if (steady || kt + 1 < nkt) {                                                               \
+                const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
+                        wnx[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+            }                                                                                           \
+            PW2_PHASE_END(3)                                                                            \
+            PW2_MFMA(4, wlo, 0)                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];               \
+        }
+        int kt = 0;
+        for (; kt + 2 < nkt; ++kt) PW2_KTILE(true)      // every issue exists, five half-tiles stay in flight
+        for (; kt < nkt; ++kt) PW2_KTILE(false)         // last two K tiles: nothing left to issue, counted drain
+#undef PW2_KTILE
+#undef PW2_PHASE_END
+#undef PW2_MFMA
+    } else {
     // ---- DMA geometry: per half-step, wave w fills 16-row groups g = w, w + 8 of A and of W --------
     const char* src[4];
     int dst[4];
@@ -143,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         char* base = smem + (h & (NRING - 1)) * HSTAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const char* s = src[j] + (int64_t)h * HROWB;
+            const char* s = src[j] + (int64_t)((DBG2 && (p.debug & 4)) ? (h & 3) : h) * HROWB;
             if (CONV && j < 2) {
                 const int k = h * 32 + clc[j] * 8;
                 const int tap = k / p.cin;
@@ -158,23 +313,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         }
     };
 
-    // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
-    f32x16 acc32[M16 ? 1 : 4][M16 ? 1 : 2];
-    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
-    if (M16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[M16 ? i : 0][M16 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[M16 ? 0 : i][M16 ? 0 : j][r] = 0.0f;
-    }
-
     const int nh = p.Kp / 32;                       // half-steps (host guarantees Kp % 64 == 0, so nh >= 2)
     issue(0);
     issue(1);
@@ -184,15 +322,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();                   // half-step 0 of every wave has landed
     if (wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind group 0
 
-    const int fr = lane & 31, fh = lane >> 5;       // 32x32x16 fragment coordinates
-    const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
     const int arow = wm * 128 + (M16 ? r16 : fr), wrow = wn * 64 + (M16 ? r16 : fr);
+    bf16x8 dbg_x[8], dbg_w[4];
+    if (DBG2) {
+        for (int i = 0; i < 8; ++i) dbg_x[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.A) + (lane + 64 * i) * 16);
+        for (int j = 0; j < 4; ++j) dbg_w[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.W) + (lane + 64 * j) * 16);
+    }
     for (int h = 0; h < nh; ++h) {
         // ---------------- phase L(h): fragments of half-step h -> registers; DMA for h+3 ----------------
         const char* As = smem + (h & (NRING - 1)) * HSTAGE;
         const char* Ws = As + HA;
         bf16x8 xf[8], wf[4];                         // 12 fragments (48 VGPRs) in both shapes
-        if (M16) {
+        if (DBG2 && (p.debug & 16)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xf[i] = dbg_x[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = dbg_w[j];
+        } else if (M16) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(As + hswz<M16>(arow + i * 16, q4));
 #pragma unroll
@@ -206,7 +352,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                 for (int j = 0; j < 2; ++j) wf[s * 2 + j] = *reinterpret_cast<const bf16x8*>(Ws + hswz<M16>(wrow + j * 32, 2 * s + fh));
             }
         }
-        if (h + 3 < nh) {
+        if (DBG2 && (p.debug & 1)) {
+        } else if (h + 3 < nh) {
             issue(h + 3);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // retires this wave's DMAs of half-step h+1
         } else if (h + 2 < nh) {
@@ -214,10 +361,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(DBG2 && (p.debug & 32))) __builtin_amdgcn_s_barrier();
         // ---------------- phase C(h): 16 (32x32x16) or 32 (16x16x32) MFMAs -------------------------------
         __builtin_amdgcn_s_setprio(1);
-        if (M16) {
+        if (DBG2 && (p.debug & 2)) {
+        } else if (M16) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -233,7 +381,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                         acc32[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 2 + j], xf[s * 4 + i], acc32[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
+        if (!(DBG2 && (p.debug & 32))) __builtin_amdgcn_s_barrier();
+    }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count
     __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: reuse the ring
@@ -322,17 +471,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
 }
 
-template <int EPI, bool M16, bool CONV>
+template <int EPI, bool M16, bool CONV, bool PH4 = false>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16, CONV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16, CONV, PH4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16, CONV>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16, CONV, PH4>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -363,6 +512,15 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
             case ACT_RELU: return launch_inst<EPI_RELU, true, true>(p, stream);
             case ACT_GELU: return launch_inst<EPI_GELU, true, true>(p, stream);
             case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, true>(p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (m16 && !(p.debug & 512)) {                  // four-phase K tiles (default); 512 = A/B switch back to the 32-wide ring
+        switch (p.act1) {
+            case ACT_NONE: return launch_inst<EPI_NONE, true, false, true>(p, stream);
+            case ACT_RELU: return launch_inst<EPI_RELU, true, false, true>(p, stream);
+            case ACT_GELU: return launch_inst<EPI_GELU, true, false, true>(p, stream);
+            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, false, true>(p, stream);
             default: return hipErrorInvalidValue;
         }
     }
