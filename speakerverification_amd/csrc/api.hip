@@ -757,13 +757,13 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         // tdnn2; its epilogue also leaves per-utterance column sums (the SE squeeze) when the pw2 kernel runs
         if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], H2, C, H3, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
                             PAD_REFLECT, nullptr, 0, cs_base, 0, h->colsum_region))) return rc;
-        if (h->last_colsum_done) {
-            if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, false, B, T, C, M, d_mean, 0.f, st); }))) return rc;
-        } else {
+        const bool from_part = h->last_colsum_done;      // the squeeze comes straight from the GEMM's column-sum partials
+        if (!from_part) {
             if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(H3, bf, C, B, T, C, d_mean, st); }))) return rc;
         }
         if ((rc = run(h, "se_mlp", 4.0 * B * 128 * C, [&]() {
-                 return launch_se_mlp(d_mean, h->se1[i].W, h->se1[i].bias, h->se2T[i], h->se2[i].bias, d_s2, B, C, 128, st);
+                 return launch_se_mlp(from_part ? nullptr : d_mean, from_part ? cs_base : nullptr, T, h->se1[i].W, h->se1[i].bias,
+                                      h->se2T[i], h->se2[i].bias, d_s2, B, C, 128, st);
              }))) return rc;
         void* xout = off(CAT, (size_t)i * C, e);
         if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))

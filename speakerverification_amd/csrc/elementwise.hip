@@ -198,26 +198,51 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 // ---- squeeze-excitation MLP: s = sigmoid(W2 relu(W1 m + b1) + b2)  (ECAPA_TDNN.py:171-176) ----------------
-// One workgroup per utterance; the hidden layer (H = 128 units) lives in LDS between the two
-// matrix-vector products; W1 is [H][C], W2T is the TRANSPOSED second layer [H][C] so that both
-// products read their weights coalesced along C.  Four hidden units per wave are in flight at once
-// and the second product is unrolled 8-deep so the L2 round trips overlap.
-__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ W1,
-                                                     const float* __restrict__ b1, const float* __restrict__ W2T,
-                                                     const float* __restrict__ b2, float* __restrict__ s, int B, int C, int H) {
+// One workgroup per utterance; the hidden layer (H = 128 units) lives in LDS between the two matrix-vector
+// products; W1 is [H][C], W2T is the TRANSPOSED second layer [H][C] so that both products read their weights
+// coalesced along C in 16-byte loads (the kernel is bound by how many of those each lane keeps in flight:
+// 1 MB of fp32 weights per workgroup out of L2).  With `part` the squeeze (mean over frames) is taken straight
+// from the column-sum partials of the pw2 GEMM epilogue (layout: colsum_finalize_kernel above).
+__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ part, int T,
+                                                     const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W2T, const float* __restrict__ b2,
+                                                     float* __restrict__ s, int B, int C, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xm = reinterpret_cast<float*>(smem);          // [C]
-    float* hid = xm + C;                                 // [H]
+    f32x4* xm4 = reinterpret_cast<f32x4*>(smem);                // [C / 4]
+    float* hid = reinterpret_cast<float*>(smem) + C;            // [H]
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < C; i += 256) xm[i] = mean[(int64_t)b * C + i];
-    __syncthreads();
-    for (int n0 = wave * 4; n0 < H; n0 += 16) {          // 4 hidden units per wave per pass
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < C; c += 64) {
-            const float x = xm[c];
+    const int nch = C >> 2;
+    if (part) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+        const int r0 = b * T, r1 = r0 + T - 1;
+        const float inv = 1.0f / (float)T;
+        for (int ch = threadIdx.x; ch < nch; ch += 256) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
+                const int seg = b - (tm * 256) / T;
+                if (seg < 0 || seg > 1) continue;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = fmaf(W1[(int64_t)(n0 + u) * C + c], x, a[u]);
+                for (int rg = 0; rg < 8; ++rg) acc += p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch + ch];
+            }
+            xm4[ch] = acc * inv;
+        }
+    } else {
+        const f32x4* m4 = reinterpret_cast<const f32x4*>(mean + (int64_t)b * C);
+        for (int ch = threadIdx.x; ch < nch; ch += 256) xm4[ch] = m4[ch];
+    }
+    __syncthreads();
+    const f32x4* W14 = reinterpret_cast<const f32x4*>(W1);
+    for (int n0 = wave * 4; n0 < H; n0 += 16) {                 // 4 hidden units per wave per pass
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ch = lane; ch < nch; ch += 64) {
+            const f32x4 x = xm4[ch];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 w = W14[(int64_t)(n0 + u) * nch + ch];
+                a[u] = fmaf(w[0], x[0], fmaf(w[1], x[1], fmaf(w[2], x[2], fmaf(w[3], x[3], a[u]))));
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -226,14 +251,18 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {         // output channel c: dot over H, weights coalesced along c
-        float a0 = b2[c], a1 = 0.f;
+    const f32x4* W24 = reinterpret_cast<const f32x4*>(W2T);
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {           // 4 output channels per thread: dot over H
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(b2 + 4 * ch), a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int n = 0; n < H; n += 2) {
-            a0 = fmaf(W2T[(int64_t)n * C + c], hid[n], a0);
-            a1 = fmaf(W2T[(int64_t)(n + 1) * C + c], hid[n + 1], a1);
+            a0 += W24[(int64_t)n * nch + ch] * hid[n];
+            a1 += W24[(int64_t)(n + 1) * nch + ch] * hid[n + 1];
         }
-        s[(int64_t)b * C + c] = 1.0f / (1.0f + expf(-(a0 + a1)));
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = 1.0f / (1.0f + expf(-(a0[e] + a1[e])));
+        *reinterpret_cast<f32x4*>(s + (int64_t)b * C + 4 * ch) = o;
     }
 }
 
@@ -418,11 +447,11 @@ hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool wit
     return hipGetLastError();
 }
 
-hipError_t launch_se_mlp(const float* mean, const float* W1, const float* b1, const float* W2T, const float* b2, float* s,
-                         int B, int C, int H, hipStream_t stream) {
+hipError_t launch_se_mlp(const float* mean, const float* part, int T, const float* W1, const float* b1, const float* W2T,
+                         const float* b2, float* s, int B, int C, int H, hipStream_t stream) {
     const size_t lds = (size_t)(C + H) * sizeof(float);
-    if (lds > 64 * 1024 || B <= 0 || H % 16 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), lds, stream, mean, W1, b1, W2T, b2, s, B, C, H);
+    if (lds > 64 * 1024 || B <= 0 || H % 16 != 0 || C % 4 != 0 || (!mean && !part)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), lds, stream, mean, part, T, W1, b1, W2T, b2, s, B, C, H);
     return hipGetLastError();
 }
 

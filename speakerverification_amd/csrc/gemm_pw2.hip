@@ -39,7 +39,7 @@ constexpr int HA = QBM * HROWB;                 // 16 KiB
 constexpr int HSTAGE = HA + QBN * HROWB;        // 32 KiB
 constexpr int NRING = 4;
 constexpr int PW2_LDS = NRING * HSTAGE;         // 128 KiB (also holds the 256 x 256 bf16 output tile)
-constexpr int QGROUP_M = 4;
+constexpr int QGROUP_M = 8;
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
 #ifdef SVHIP_GEMM_DEBUG
@@ -114,10 +114,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int grp_t = id / (QGROUP_M * ntn);
-    const int within = id - grp_t * (QGROUP_M * ntn);
-    const int gm = min(QGROUP_M, ntm - grp_t * QGROUP_M);
-    const int tile_m = grp_t * QGROUP_M + within % gm;
+    const int qgm = (DBG2 && (p.debug & 1024)) ? 8 : (DBG2 && (p.debug & 2048)) ? 2 : QGROUP_M;
+    const int grp_t = id / (qgm * ntn);
+    const int within = id - grp_t * (qgm * ntn);
+    const int gm = min(qgm, ntm - grp_t * qgm);
+    const int tile_m = grp_t * qgm + within % gm;
     const int tile_n = within / gm;
     const int m0 = tile_m * QBM, n0 = tile_n * QBN;
 
@@ -232,16 +233,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                     acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                  \
         __builtin_amdgcn_s_barrier();
-#define PW2_KTILE(steady_)                                                                          \
+#define PW2_KTILE(steady_, KT_, WCUR, WNXT)                                                         \
         {                                                                                               \
             constexpr bool steady = (steady_);                                                          \
+            const int kt = (KT_);                                                                       \
             const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
             /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
                     xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
             PW2_PHASE_END(0)                                                                            \
-            PW2_MFMA(0, wlo, 0)                                                                         \
+            PW2_MFMA(0, WCUR, 0)                                                                        \
             /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
@@ -254,21 +256,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                     xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
             PW2_PHASE_END(2)                                                                            \
             PW2_MFMA(4, whi, 2)                                                                         \
-            /* phase 3: W-lo(kt+1) into the spare registers; X-hi x W-lo(kt) */                         \
+            /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
             if (steady || kt + 1 < nkt) {                                                               \
                 const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
                     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
-                        wnx[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+                        WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
             }                                                                                           \
             PW2_PHASE_END(3)                                                                            \
-            PW2_MFMA(4, wlo, 0)                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];               \
+            PW2_MFMA(4, WCUR, 0)                                                                        \
         }
-        int kt = 0;
-        for (; kt + 2 < nkt; ++kt) PW2_KTILE(true)      // every issue exists, five half-tiles stay in flight
-        for (; kt < nkt; ++kt) PW2_KTILE(false)         // last two K tiles: nothing left to issue, counted drain
+        int kt0 = 0;
+        for (; kt0 + 2 < nkt; ++kt0) {                  // steady state: every issue exists, five half-tiles stay in flight
+            PW2_KTILE(true, kt0, wlo, wnx)              // (two K tiles per trip with the W-lo sets swapping roles spills: slower)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+        }
+        for (; kt0 < nkt; ++kt0) {                      // last two K tiles: issues run out, counted drain
+            PW2_KTILE(false, kt0, wlo, wnx)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+        }
 #undef PW2_KTILE
 #undef PW2_PHASE_END
 #undef PW2_MFMA

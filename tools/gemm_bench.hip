@@ -28,7 +28,9 @@ struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bo
 int main(int argc, char** argv) {
     const bool bf16 = !(argc > 1 && atoi(argv[1]) == 0);
     const int B = argc > 2 ? atoi(argv[2]) : 256;
-    const int debug = argc > 3 ? atoi(argv[3]) : 0;
+    std::vector<int> debugs;                       // comma-separated list: the variants run interleaved in this process (A/B)
+    { const char* d = argc > 3 ? argv[3] : "0"; while (*d) { debugs.push_back(atoi(d)); while (*d && *d != ',') ++d; if (*d == ',') ++d; } }
+    const int rounds = argc > 5 ? atoi(argv[5]) : 1;
     const float dscale = argc > 4 ? (float)atof(argv[4]) : 1.0f;
     const int T = 401, M = B * T, C = 1024;
     const int esz = bf16 ? 2 : 4;
@@ -58,17 +60,21 @@ int main(int argc, char** argv) {
         p.A = A; p.A2 = s.a2 ? A2 : nullptr; p.W = W; p.Y = Y; p.bias = bias; p.scale = scale; p.shift = shift;
         p.M = s.M; p.N = s.N; p.K = s.K; p.Kp = round_up(s.K, gemm_bk(bf16)); p.Wrows = round_up(s.N, 128);
         p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = T;
-        p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = PAD_REFLECT; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = debug; p.zero_page = zp;
-        if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; }
-        for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
-        CK(hipStreamSynchronize(st));
-        const int it = 5;
-        CK(hipEventRecord(e0, st));
-        for (int i = 0; i < it; ++i) CK(launch_gemm(p, bf16, st));
-        CK(hipEventRecord(e1, st));
-        CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
-        printf("%-40s %8.3f ms  %8.1f TFLOP/s\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = PAD_REFLECT; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = 0; p.zero_page = zp;
+        for (int rd = 0; rd < rounds; ++rd)
+        for (int debug : debugs) {
+            p.debug = debug;
+            if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; } else { p.colsum = nullptr; }
+            for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
+            CK(hipStreamSynchronize(st));
+            const int it = 10;
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < it; ++i) CK(launch_gemm(p, bf16, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+            printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        }
     }
     return 0;
 }
