@@ -126,6 +126,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};  // tools/gemm_bench (debug bit 16384): s_memtime at the stage boundaries
+#define PW2_STAMP(i) if (DBG2 && (p.debug & 16384) && p.R) ts[i] = __builtin_readcyclecounter();
+    PW2_STAMP(0)
 
     // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
     f32x16 acc32[M16 ? 1 : 4][M16 ? 1 : 2];
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         if (nkt > 1) { issue(2, 1); issue(0, 1); issue(3, 1); }
         wait_left(min(7, total) - 2);
         __builtin_amdgcn_s_barrier();                 // W-lo(0), X-lo(0) of every wave have landed
+        PW2_STAMP(1)
         if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
 
         const int xoff = (wm * 64 + r16) * 128, woff = (wn * 32 + r16) * 128;
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count
     __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: reuse the ring
+    PW2_STAMP(2)
 
     // ---- epilogue: every lane owns 4 consecutive channels (n .. n+3) of one frame per accumulator group ----
     //   32x32x16: acc32[i][j][4g+e] = (m = wm*128 + i*32 + fr,  n = wn*64 + j*32 + 8g + 4fh + e)
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         }
     }
     __syncthreads();
+    PW2_STAMP(3)
     if (p.colsum) {
         // per-utterance column sums of this tile (feeds the SE mean / the ASP global statistics without
         // another pass over HBM): thread = (column, 128-row half), bf16 values straight from the LDS image
@@ -470,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             }
         }
     }
+    PW2_STAMP(4)
     char* Yb = reinterpret_cast<char*>(p.Y);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {               // 256 rows x 32 16-byte chunks / 512 threads
@@ -481,6 +488,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const int m = m0 + row, n = n0 + q * 8;
         if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
     }
+    if (DBG2 && (p.debug & 16384) && p.R) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[5] = __builtin_readcyclecounter();
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.R)) + (int64_t)blockIdx.x * 8;
+            for (int i = 0; i < 6; ++i) o[i] = ts[i];
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[6] = hwid; o[7] = xcc;
+        }
+    }
+#undef PW2_STAMP
 }
 
 template <int EPI, bool M16, bool CONV, bool PH4 = false>
@@ -500,7 +519,7 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
-    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE || p.A2 || p.R) return false;
+    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE || p.A2 || (p.R && !(DBG2 && (p.debug & 16384)))) return false;
     if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;      // at most one utterance boundary per 256-row tile
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
     if (p.N < 256 || p.Kp % 64 != 0 || p.N % 8 != 0 || p.lda % 8 != 0 || p.ldy % 8 != 0) return false;

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "kernels.h"
 #include "common.h"
 using namespace svhip;
@@ -74,6 +75,48 @@ int main(int argc, char** argv) {
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
             printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+            if (debug & 16384) {          // stage timestamps of one launch (non-persistent pw2 kernel)
+                const int nwg = ((s.M + 255) / 256) * ((s.N + 255) / 256);
+                unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 64)); CK(hipMemset(dts, 0, (size_t)nwg * 64));
+                p.R = dts;
+                CK(launch_gemm(p, bf16, st)); CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hts((size_t)nwg * 8);
+                CK(hipMemcpy(hts.data(), dts, (size_t)nwg * 64, hipMemcpyDeviceToHost));
+                p.R = nullptr; CK(hipFree(dts));
+                unsigned long long t0 = ~0ull, t1 = 0;      // s_memtime is per XCD: calibrate on the XCD of workgroup 0
+                const unsigned xcc0 = (unsigned)hts[7] & 15;
+                double sum[5] = {0, 0, 0, 0, 0};
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long* o = &hts[(size_t)w * 8];
+                    if (((unsigned)o[7] & 15) == xcc0) { if (o[0] < t0) t0 = o[0]; if (o[5] > t1) t1 = o[5]; }
+                    for (int i = 0; i < 5; ++i) sum[i] += (double)(o[i + 1] - o[i]);
+                }
+                const double span = (double)(t1 - t0), tick_us = ms * 1e3 / span;      // calibrate ticks with the event time
+                printf("    stamps: span %.0f ticks (%.5f us/tick); mean per WG [us]: prologue %.2f | main %.2f | epi-compute+stage %.2f | colsum %.2f | stores+drain %.2f | total %.2f\n",
+                       span, tick_us, sum[0] / nwg * tick_us, sum[1] / nwg * tick_us, sum[2] / nwg * tick_us, sum[3] / nwg * tick_us, sum[4] / nwg * tick_us,
+                       (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / nwg * tick_us);
+                // gaps between consecutive workgroups on the same CU slot: sort by (xcc, hw_id cu/se bits)
+                std::vector<std::pair<unsigned long long, int>> order;
+                std::vector<std::vector<int>> percu(8 * 4096);
+                for (int w = 0; w < nwg; ++w) {
+                    const unsigned long long* o = &hts[(size_t)w * 8];
+                    const unsigned hw = (unsigned)o[6], xcc = (unsigned)o[7] & 15;
+                    const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;      // gfx9 HW_ID: CU_ID[11:8] SH_ID[12] SE_ID[15:13]
+                    percu[(xcc * 8 + se) * 32 + sh * 16 + cu].push_back(w);
+                }
+                double gap = 0; int ngap = 0, ncu = 0; double busy = 0;
+                for (auto& v : percu) {
+                    if (v.empty()) continue;
+                    ++ncu;
+                    std::sort(v.begin(), v.end(), [&](int a, int b) { return hts[(size_t)a * 8] < hts[(size_t)b * 8]; });
+                    for (size_t i = 0; i < v.size(); ++i) {
+                        busy += (double)(hts[(size_t)v[i] * 8 + 5] - hts[(size_t)v[i] * 8]);
+                        if (i) { gap += (double)hts[(size_t)v[i] * 8] - (double)hts[(size_t)v[i - 1] * 8 + 5]; ++ngap; }
+                    }
+                }
+                printf("    %d CU slots seen, mean gap between successive WGs on a CU %.2f us, mean busy per CU %.1f us of %.1f us\n",
+                       ncu, ngap ? gap / ngap * tick_us : 0.0, busy / ncu * tick_us, span * tick_us);
+            }
         }
     }
     return 0;
