@@ -445,25 +445,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const int rend = min(256, p.M - m0);
         float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
         typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+        // rows [lo, mid) belong to segment 0, [mid, hi) to segment 1; all three are wave-uniform (rg is the wave index).
+        // Almost always a wave's 32 rows sit in one segment: that case runs fully unrolled (32 LDS reads in flight, no selects);
+        // a runtime-bounded loop exposes one LDS round trip per row (2.7 us per tile when every wave took it)
         const int lo = rg * 32, hi = min(rg * 32 + 32, rend);
-        const int mid = max(lo, min(hi, rb));                   // rows [lo, mid) -> segment 0, [mid, hi) -> segment 1
-        for (int row = lo; row < mid; ++row) {
+        const int mid = max(lo, min(hi, rb));
+        auto add_row = [&](int row, float (&sa)[4], float (&qa)[4]) {
             const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(smem + row * ORB + ((c8 ^ (row & 15)) << 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = static_cast<float>(v4[e]);
-                s0[e] += v;
-                if (p.colsum_sq) q0[e] = fmaf(v, v, q0[e]);
+                const float x = static_cast<float>(v4[e]);
+                sa[e] += x;
+                if (p.colsum_sq) qa[e] = fmaf(x, x, qa[e]);
             }
-        }
-        for (int row = mid; row < hi; ++row) {
-            const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(smem + row * ORB + ((c8 ^ (row & 15)) << 3));
+        };
+        if (hi - lo == 32 && (mid == hi || mid == lo)) {
+            if (mid == hi) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = static_cast<float>(v4[e]);
-                s1[e] += v;
-                if (p.colsum_sq) q1[e] = fmaf(v, v, q1[e]);
+                for (int rr = 0; rr < 32; ++rr) add_row(lo + rr, s0, q0);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) add_row(lo + rr, s1, q1);
             }
+        } else {
+            for (int row = lo; row < mid; ++row) add_row(row, s0, q0);
+            for (int row = mid; row < hi; ++row) add_row(row, s1, q1);
         }
         const int n = n0 + c8 * 4;
         if (n < p.N) {
