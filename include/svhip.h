@@ -135,6 +135,29 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                        const float* sigma, const int32_t* ia, const int32_t* ib, int64_t P,
                        float* out, int32_t flags);
 
+/* Packed checkpoint blob.  Replaces, at deployment time, the Python-side checkpoint handling of
+ * ModelHandling.loadParameters (src/model.py:718-746: torch.load of a '.model' file + name-matched copy, and
+ * src/trainer.py:145-205 which writes those files): speakerverification_amd/checkpoint.py converts a reference state dict
+ * once (host-side torch.load) into a flat, versioned, FNV-1a-checksummed tensor archive; svhip_load_blob mmaps it and feeds
+ * every tensor through svhip_load_tensor + svhip_finalize_weights (BatchNorm fold, weight packing, sinc filter bake), so no
+ * Python / torch is needed at run time and the result is bit-identical to the state-dict path.
+ *   blob_write  : n tensors (names are reference state_dict keys of __S__), shapes n x 4 (unused dims ignored), dtypes SVHIP_*.
+ *   blob_open   : mmap + validate (magic, version, size, checksum, every table entry in bounds).  Errors: svhip_blob_last_error().
+ *   blob_tensor : borrow tensor idx (pointers stay valid until blob_close).
+ *   load_blob   : tensors whose names the handle's model does not know are skipped (as loadParameters skips them,
+ *                 model.py:730-736); a known name with the wrong shape, a missing tensor, or a model mismatch is an error. */
+typedef struct svhip_blob svhip_blob;
+int svhip_blob_write(const char* path, int32_t model, int32_t n, const char* const* names, const void* const* data,
+                     const int64_t* shapes, const int32_t* ndims, const int32_t* dtypes);
+int svhip_blob_open(const char* path, svhip_blob** out);
+int32_t svhip_blob_count(const svhip_blob* b);
+int32_t svhip_blob_model(const svhip_blob* b);
+int svhip_blob_tensor(const svhip_blob* b, int32_t idx, const char** name, const void** data, int64_t* shape4,
+                      int32_t* ndim, int32_t* dtype);
+int svhip_blob_close(svhip_blob* b);
+const char* svhip_blob_last_error(void);
+int svhip_load_blob(svhip_handle* h, const char* path);
+
 /* Introspection used by tests and bench.py (not part of the reference's surface).
  *   get_stage    : copy an intermediate activation of the LAST forward to host as fp32, frame-major
  *                  (B, T, C).  Names: "input","blocks.0".."blocks.3","mfa","asp","asp_bn" (ECAPA).

@@ -59,6 +59,16 @@ _SIGNATURES = {
     "svhip_score_matrix": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
     "svhip_asnorm_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "svhip_asnorm_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
+    "svhip_blob_write": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "svhip_blob_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "svhip_blob_count": (C.c_int32, [_P]),
+    "svhip_blob_model": (C.c_int32, [_P]),
+    "svhip_blob_tensor": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "svhip_blob_close": (C.c_int, [_P]),
+    "svhip_blob_last_error": (C.c_char_p, []),
+    "svhip_load_blob": (C.c_int, [_P, C.c_char_p]),
     "svhip_get_stage": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64)]),
     "svhip_profile_enable": (C.c_int, [_P, C.c_int32]),
     "svhip_profile_reset": (C.c_int, [_P]),

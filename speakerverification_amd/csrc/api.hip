@@ -1024,6 +1024,29 @@ int svhip_finalize_weights(svhip_handle* h) {
     return SVHIP_OK;
 }
 
+int svhip_load_blob(svhip_handle* h, const char* path) {
+    if (!h || !path) return SVHIP_ERR_INVALID;
+    if (h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights already finalized");
+    svhip_blob* b = nullptr;
+    if (int rc = svhip_blob_open(path, &b)) SV_FAIL(h, rc, "%s", svhip_blob_last_error());
+    if (svhip_blob_model(b) != h->cfg.model) {
+        const int m = svhip_blob_model(b);
+        svhip_blob_close(b);
+        SV_FAIL(h, SVHIP_ERR_INVALID, "%s holds weights of model %d, this handle is model %d", path, m, h->cfg.model);
+    }
+    std::map<std::string, std::vector<int64_t>> spec;
+    model_spec(h->cfg, spec);
+    const int32_t n = svhip_blob_count(b);
+    for (int32_t i = 0; i < n; ++i) {
+        const char* name; const void* data; int64_t shape[4]; int32_t ndim, dtype;
+        svhip_blob_tensor(b, i, &name, &data, shape, &ndim, &dtype);
+        if (!spec.count(name)) continue;                       // e.g. loss-head tensors of a training checkpoint
+        if (int rc = svhip_load_tensor(h, name, data, shape, ndim, dtype)) { svhip_blob_close(b); return rc; }
+    }
+    svhip_blob_close(b);
+    return svhip_finalize_weights(h);
+}
+
 int svhip_fbank(svhip_handle* h, const float* wav, int32_t B, int32_t L, float* mel_out, int32_t flags) {
     if (!h || !wav || !mel_out) return SVHIP_ERR_INVALID;
     if (B <= 0 || B > h->cfg.max_batch) SV_FAIL(h, SVHIP_ERR_INVALID, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);

@@ -69,6 +69,7 @@ struct Res2Params {
     const float* bias[7] = {};
     const float* scale[7] = {};
     const float* shift[7] = {};
+    int debug = 0;               // tools/res2_bench ablations (only read in -DSVHIP_GEMM_DEBUG builds)
 };
 bool res2net_chain_supported(int C, int T, int dil, int Kp);
 hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t stream);

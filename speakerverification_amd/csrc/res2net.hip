@@ -20,6 +20,11 @@ namespace svhip {
 
 namespace {
 
+#ifdef SVHIP_GEMM_DEBUG
+constexpr bool R2DBG = true;         // ablations: 1 no global traffic in the row passes, 2 no MFMA, 4 no weight staging, 8 no epilogue
+#else
+constexpr bool R2DBG = false;
+#endif
 constexpr int R2_TMAX = 416;         // 13 MFMA m-tiles; T = 401 for 2 s @ 16 kHz
 
 template <int CW> struct R2Cfg {
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 
         for (int tap = 0; tap < 3; ++tap) {
             const bool more = !(s == 7 && tap == 2);
-            if (more) { if (tap < 2) wload(layer, tap + 1); else wload(layer + 1, 0); }
+            if (more && !(R2DBG && (p.debug & 4))) { if (tap < 2) wload(layer, tap + 1); else wload(layer + 1, 0); }
             const int delta = (tap - 1) * p.dil;
             int rbase[MI], rsw[MI];
 #pragma unroll
@@ -112,17 +117,18 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wt + wbase + ((ch ^ wsw) << 4));
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    if ((wq + CF::MW * i) * 32 < T) {          // wave-uniform: skip m-tiles beyond T
+                    if ((wq + CF::MW * i) * 32 < T && !(R2DBG && (p.debug & 2))) {          // wave-uniform: skip m-tiles beyond T
                         const bf16x8 xf = *reinterpret_cast<const bf16x8*>(U + rbase[i] + ((ch ^ rsw[i]) << 4));
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
                     }
                 }
             }
             __syncthreads();                                    // Wt (and, after tap 2, U) are free
-            if (tap < 2) { wstore(); __syncthreads(); }
+            if (tap < 2) { if (!(R2DBG && (p.debug & 4))) wstore(); __syncthreads(); }
         }
 
         // ---- epilogue: acc[i][4g+e] = (t = (wq + MW*i)*32 + fr, n = wn*32 + 8g + 4fh + e) -> U ------
+        if (!(R2DBG && (p.debug & 8)))
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = wn * 32 + 8 * g + 4 * fh;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
                 }
             }
         }
-        if (s < 7) wstore();                                    // next layer's tap-0 slab (loaded during tap 2)
+        if (s < 7 && !(R2DBG && (p.debug & 4))) wstore();      // next layer's tap-0 slab (loaded during tap 2)
         __syncthreads();
 
         // ---- y_s -> H2 (whole rows), U <- y_s + c_{s+1} -------------------------------------------------
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
             const int row = c / NCH, ch = c % NCH;
             char* up = U + row * ROWB + ((ch ^ CF::swz(row)) << 4);
             const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
-            *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
-            if (s < 7) {
+            if (!(R2DBG && (p.debug & 1))) *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
+            if (s < 7 && !(R2DBG && (p.debug & 1))) {
                 const bf16x8 cn = *reinterpret_cast<const bf16x8*>(H1 + (int64_t)row * p.ld + (s + 1) * CW + ch * 8);
                 bf16x8 u;
 #pragma unroll

@@ -146,6 +146,10 @@ class Engine:
     def finalize(self):
         self._ck(self.lib.svhip_finalize_weights(self.h))
 
+    def load_blob(self, path):
+        """mmap a packed checkpoint blob (speakerverification_amd.checkpoint) and finalize: svhip_load_blob."""
+        self._ck(self.lib.svhip_load_blob(self.h, str(path).encode()))
+
     # ---- forward ------------------------------------------------------------------------------------------
     def _out(self, like, shape):
         if _is_torch(like) and like.is_cuda:

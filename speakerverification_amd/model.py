@@ -380,7 +380,12 @@ class ModelHandling:
         tensors are reported and skipped.  (map_location is 'cpu': weights are repacked for the device.)"""
         if not os.path.exists(path):
             raise FileNotFoundError("Model's path is not exists")
-        loaded = torch.load(path, map_location="cpu")
+        from . import checkpoint
+        if checkpoint.is_blob(path):                     # packed blob (checkpoint.convert_checkpoint): bare __S__ names
+            _, sd = checkpoint.read_blob(path)
+            loaded = {"__S__." + k: torch.from_numpy(v) for k, v in sd.items()}
+        else:
+            loaded = torch.load(path, map_location="cpu")
         own = self.__model__.module.state_dict()
         keep = {}
         for name, param in loaded.items():

@@ -91,6 +91,15 @@ class HipModule:
         self._drop_engine()
         return missing, unexpected
 
+    def load_blob(self, path):
+        """Weights from a packed checkpoint blob (checkpoint.convert_checkpoint); tensors of other networks are ignored."""
+        from .. import checkpoint, _lib
+        mid, sd = checkpoint.read_blob(path)
+        want = {"ecapa": _lib.MODEL_ECAPA, "rawnet2": _lib.MODEL_RAWNET2}.get(self.model_kind)
+        if want is not None and mid != want:
+            raise ValueError(f"{path} holds weights of model {mid}, this module is {self.model_kind}")
+        return self.load_state_dict(sd, strict=False)
+
     # ---- engine management ----------------------------------------------------------------------------
     def _drop_engine(self):
         if self._engine is not None:
