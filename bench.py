@@ -135,6 +135,13 @@ def scoring_bench(dev):
     t = timed(lambda: eng.score_matrix(A, Bm, dense))
     res["dense_pairs_per_s"] = 16384 * 16384 / t
     res["dense_TFLOPs"] = 2.0 * 16384 * 16384 * EMBED / t / 1e12
+    # verification metrics over the same 1.2 M-trial list (EER / minDCF inputs; host arrays in, PCIe included)
+    sc_host = out.cpu().numpy()
+    lab_host = (np.arange(P) % 2).astype(np.int32)
+    t = timed(lambda: eng.min_dcf(sc_host, lab_host, 0.05, 1, 1))
+    res["min_dcf_trials_per_s"] = P / t
+    t = timed(lambda: eng.roc_points(sc_host, lab_host))
+    res["roc_points_trials_per_s"] = P / t
     res["config"] = {"embeddings": N, "trials": P, "cohort": K, "top": top, "dim": EMBED}
     eng.close()
     return res

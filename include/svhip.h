@@ -135,6 +135,27 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                        const float* sigma, const int32_t* ia, const int32_t* ib, int64_t P,
                        float* out, int32_t flags);
 
+/* Verification metrics over a scored trial list: the sort-and-accumulate core of the reference's
+ * evaluation tail, which it runs as Python list sorts and loops (src/utils.py:221-275) and sklearn calls (utils.py:74-121).
+ * scores fp32, labels int32 in {0, 1}, P trials (< 2^31); pointers follow `flags`, the scalar results are host pointers.
+ *   roc_points  : sklearn's _binary_clf_curve as roc_curve / precision_recall_curve use it in tuneThresholdfromScore
+ *                 (utils.py:77-80,112): scores through nan_to_num, then one point per DISTINCT score value, highest first:
+ *                 thr[k], fps[k] / tps[k] = negatives / positives scoring >= thr[k].  *n_out distinct values; the output
+ *                 buffers hold P entries.  The caller finishes with the reference's own O(n) selection (drop_intermediate,
+ *                 argmin / argmax, trapezoid) — speakerverification_amd/metrics.py does, in float64 like the reference.
+ *   error_rates : ComputeErrorRates (utils.py:221-256): stable ascending sort (ties keep list order, as sorted() does);
+ *                 fnrs[i] = positives among the i+1 lowest / positives, fprs[i] = 1 - negatives among them / negatives
+ *                 (float64), thresholds[i] = the i-th lowest score.
+ *   min_dcf     : ComputeErrorRates + ComputeMinDcf (utils.py:262-275) fused: the FIRST minimum over i of
+ *                 c_miss*fnrs[i]*p_target + c_fa*fprs[i]*(1-p_target), divided by min(c_miss*p_target, c_fa*(1-p_target));
+ *                 float64, Python's operation order, no fused multiply-add. */
+int svhip_roc_points(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, int64_t* n_out, float* thr,
+                     int64_t* fps, int64_t* tps, int32_t flags);
+int svhip_error_rates(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, double* fnrs, double* fprs,
+                      float* thresholds, int32_t flags);
+int svhip_min_dcf(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, double p_target, double c_miss,
+                  double c_fa, double* min_dcf, float* threshold, int32_t flags);
+
 /* Packed checkpoint blob.  Replaces, at deployment time, the Python-side checkpoint handling of
  * ModelHandling.loadParameters (src/model.py:718-746: torch.load of a '.model' file + name-matched copy, and
  * src/trainer.py:145-205 which writes those files): speakerverification_amd/checkpoint.py converts a reference state dict

@@ -181,6 +181,45 @@ def golden_scoring(ref):
                         pnorm=np.array(pn, np.float64))
 
 
+from tests.metrics_data import metrics_case  # noqa: E402  (seeded trial lists shared with the tests)
+
+
+def golden_metrics(ref):
+    """tuneThresholdfromScore / ComputeErrorRates / ComputeMinDcf of the imported reference (src/utils.py:74-121,221-275),
+    called the way the evaluation drivers call them (Python lists of floats / ints; inference.py, trainer.py)."""
+    from oracle import metrics as o_metrics
+    out = {}
+    for name in ("small", "ties", "distinct", "skewed"):
+        sc, lab = metrics_case(name)
+        scl, labl = [float(v) for v in sc], [int(v) for v in lab]
+        res = ref.utils.tuneThresholdfromScore(scl, labl, [1, 0.1], [5])
+        fnrs, fprs, thr = ref.utils.ComputeErrorRates(scl, labl)
+        dcf, dthr = ref.utils.ComputeMinDcf(fnrs, fprs, thr, 0.05, 1, 1)
+        dcf2, dthr2 = ref.utils.ComputeMinDcf(fnrs, fprs, thr, 0.01, 10, 1)
+        # the oracle restatement must agree with the reference exactly
+        o = o_metrics.tune_threshold_from_score(scl, labl, [1, 0.1], [5])
+        assert o["gmean"][0] == res["gmean"][0] and o["gmean"][1] == res["gmean"][1] and o["gmean"][2] == res["gmean"][2], name
+        assert np.array_equal(np.array(o["roc"][0]), np.array(res["roc"][0])) and o["roc"][1] == res["roc"][1], name
+        assert o["roc"][2] == res["roc"][2] and o["roc"][3] == res["roc"][3], name
+        assert np.array_equal(o["prec_recall"][0], res["prec_recall"][0]) and np.array_equal(o["prec_recall"][1], res["prec_recall"][1]), name
+        assert o["prec_recall"][2] == res["prec_recall"][2] and o["prec_recall"][3] == res["prec_recall"][3], name
+        ofn, ofp, oth = o_metrics.compute_error_rates(scl, labl)
+        assert np.array_equal(ofn, np.array(fnrs)) and np.array_equal(ofp, np.array(fprs)) and np.array_equal(oth, np.array(thr)), name
+        assert o_metrics.compute_min_dcf(ofn, ofp, oth, 0.05, 1, 1) == (dcf, dthr), name
+        assert o_metrics.compute_min_dcf(ofn, ofp, oth, 0.01, 10, 1) == (dcf2, dthr2), name
+        out[name + "_gmean"] = np.array([res["gmean"][0], res["gmean"][1], res["gmean"][2]], np.float64)
+        out[name + "_tuned"] = np.array(res["roc"][0], np.float64)
+        out[name + "_eer_auc_thr"] = np.array([res["roc"][1], res["roc"][2], res["roc"][3]], np.float64)
+        out[name + "_pr_best"] = np.array([res["prec_recall"][2], res["prec_recall"][3]], np.float64)
+        out[name + "_precision"] = np.asarray(res["prec_recall"][0], np.float64)
+        out[name + "_recall"] = np.asarray(res["prec_recall"][1], np.float64)
+        out[name + "_fnrs"] = np.array(fnrs, np.float64)
+        out[name + "_fprs"] = np.array(fprs, np.float64)
+        out[name + "_thr"] = np.array(thr, np.float64)
+        out[name + "_mindcf"] = np.array([dcf, dthr, dcf2, dthr2], np.float64)
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **out)
+
+
 def golden_crop():
     """loadWAV eval-mode cropping for ndarray sources (processing/audio_loader.py:53-152)."""
     from processing.audio_loader import loadWAV     # reference module (stubs cover its imports)
@@ -318,6 +357,7 @@ def main():
     specs = {}
     golden_preemph(ref)
     golden_scoring(ref)
+    golden_metrics(ref)
     try:
         golden_crop()
     except Exception as e:  # pragma: no cover - reported, not fatal

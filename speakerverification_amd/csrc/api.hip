@@ -1294,6 +1294,97 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
 }
 
 // ---- introspection ---------------------------------------------------------------------------------------
+// ---- verification metrics (metrics.hip) ------------------------------------------------------------------------------------
+namespace {
+// shared front half: stage scores / labels, sort, scan.  Labels must be 0 / 1 (host labels are checked).
+struct MetricsRun {
+    svhip_handle* h;
+    TempBuf tS{nullptr}, tL{nullptr};
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    explicit MetricsRun(svhip_handle* hh) : h(hh) { tS.h = hh; tL.h = hh; }
+    ~MetricsRun() { if (ws) (void)hipFree(ws); }
+    int start(const float* scores, const int32_t* labels, int64_t P, bool din, bool nan_to_num, const char* label) {
+        if (P >= ((int64_t)1 << 31)) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "trial lists are limited to 2^31 - 1 entries");
+        if (!din)
+            for (int64_t i = 0; i < P; ++i)
+                if (labels[i] != 0 && labels[i] != 1) SV_FAIL(h, SVHIP_ERR_INVALID, "label %lld of trial %lld is not 0 / 1", (long long)labels[i], (long long)i);
+        SV_HIP(h, hipSetDevice(h->cfg.device));
+        const void *dS, *dL;
+        int rc;
+        if ((rc = tS.in(scores, (size_t)P * 4, din, &dS))) return rc;
+        if ((rc = tL.in(labels, (size_t)P * 4, din, &dL))) return rc;
+        ws_bytes = metrics_workspace_bytes(P);
+        SV_HIP(h, hipMalloc(&ws, ws_bytes));
+        return run(h, label, 0, [&]() { return metrics_sort_scan((const float*)dS, (const int32_t*)dL, P, nan_to_num, ws, ws_bytes, h->stream); });
+    }
+};
+}  // namespace
+
+int svhip_roc_points(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, int64_t* n_out, float* thr, int64_t* fps,
+                     int64_t* tps, int32_t flags) {
+    if (!h || !scores || !labels || !n_out || !thr || !fps || !tps || P <= 0) return SVHIP_ERR_INVALID;
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    MetricsRun m(h);
+    int rc;
+    if ((rc = m.start(scores, labels, P, din, true, "metrics_sort"))) return rc;
+    TempBuf tT{h}, tF{h}, tP{h};
+    void *dT, *dF, *dP;
+    if ((rc = tT.out(thr, (size_t)P * 4, dout, &dT)) || (rc = tF.out(fps, (size_t)P * 8, dout, &dF)) || (rc = tP.out(tps, (size_t)P * 8, dout, &dP))) return rc;
+    int32_t* n_dev = nullptr;
+    if ((rc = run(h, "metrics_roc", 0, [&]() { return metrics_roc_points(P, m.ws, m.ws_bytes, (float*)dT, (int64_t*)dF, (int64_t*)dP, &n_dev, h->stream); }))) return rc;
+    int32_t n32 = 0;
+    SV_HIP(h, hipMemcpyAsync(&n32, n_dev, 4, hipMemcpyDeviceToHost, h->stream));
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    *n_out = n32;
+    if (!dout) {
+        SV_HIP(h, hipMemcpy(thr, dT, (size_t)n32 * 4, hipMemcpyDeviceToHost));
+        SV_HIP(h, hipMemcpy(fps, dF, (size_t)n32 * 8, hipMemcpyDeviceToHost));
+        SV_HIP(h, hipMemcpy(tps, dP, (size_t)n32 * 8, hipMemcpyDeviceToHost));
+    }
+    return SVHIP_OK;
+}
+
+int svhip_error_rates(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, double* fnrs, double* fprs, float* thresholds,
+                      int32_t flags) {
+    if (!h || !scores || !labels || !fnrs || !fprs || !thresholds || P <= 0) return SVHIP_ERR_INVALID;
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    MetricsRun m(h);
+    int rc;
+    if ((rc = m.start(scores, labels, P, din, false, "metrics_sort"))) return rc;
+    TempBuf tA{h}, tB{h}, tC{h};
+    void *dA, *dB, *dC;
+    if ((rc = tA.out(fnrs, (size_t)P * 8, dout, &dA)) || (rc = tB.out(fprs, (size_t)P * 8, dout, &dB)) || (rc = tC.out(thresholds, (size_t)P * 4, dout, &dC))) return rc;
+    if ((rc = run(h, "metrics_rates", 0, [&]() { return metrics_error_rates(P, m.ws, m.ws_bytes, (double*)dA, (double*)dB, (float*)dC, h->stream); }))) return rc;
+    if (!dout) {
+        SV_HIP(h, hipMemcpyAsync(fnrs, dA, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
+        SV_HIP(h, hipMemcpyAsync(fprs, dB, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream));
+        SV_HIP(h, hipMemcpyAsync(thresholds, dC, (size_t)P * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+int svhip_min_dcf(svhip_handle* h, const float* scores, const int32_t* labels, int64_t P, double p_target, double c_miss, double c_fa,
+                  double* min_dcf, float* threshold, int32_t flags) {
+    if (!h || !scores || !labels || !min_dcf || !threshold || P <= 0) return SVHIP_ERR_INVALID;
+    MetricsRun m(h);
+    int rc;
+    if ((rc = m.start(scores, labels, P, flags & SVHIP_IN_DEVICE, false, "metrics_sort"))) return rc;
+    void* res = nullptr;
+    SV_HIP(h, hipMalloc(&res, 16));
+    rc = run(h, "metrics_min_dcf", 0, [&]() { return metrics_min_dcf(P, m.ws, m.ws_bytes, p_target, c_miss, c_fa, (double*)res, (float*)((char*)res + 8), h->stream); });
+    char host[16];
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host, res, 16, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(res);
+    if (rc) return rc;
+    SV_HIP(h, e);
+    memcpy(min_dcf, host, 8);
+    memcpy(threshold, host + 8, 4);
+    return SVHIP_OK;
+}
+
 int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* count) {
     if (!h || !name || !count) return SVHIP_ERR_INVALID;
     if (h->lastB <= 0) SV_FAIL(h, SVHIP_ERR_STATE, "no forward has run yet");

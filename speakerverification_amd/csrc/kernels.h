@@ -176,4 +176,14 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
 // S (rows x K, row stride ld) fp32 cohort scores -> mean / population std of the `top` largest per row
 hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int top, float* mu, float* sigma, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// Verification metrics (metrics.hip): one workspace of metrics_workspace_bytes(P) holds the sorted trial list
+// ---------------------------------------------------------------------------------------------
+size_t metrics_workspace_bytes(int64_t P);
+hipError_t metrics_sort_scan(const float* scores, const int32_t* labels, int64_t P, bool nan_to_num, void* ws, size_t ws_bytes, hipStream_t st);
+hipError_t metrics_roc_points(int64_t P, void* ws, size_t ws_bytes, float* thr, int64_t* fps, int64_t* tps, int32_t** n_runs_dev, hipStream_t st);
+hipError_t metrics_error_rates(int64_t P, void* ws, size_t ws_bytes, double* fnrs, double* fprs, float* thresholds, hipStream_t st);
+hipError_t metrics_min_dcf(int64_t P, void* ws, size_t ws_bytes, double p_target, double c_miss, double c_fa, double* dcf_dev, float* thr_dev,
+                           hipStream_t st);
+
 }  // namespace svhip

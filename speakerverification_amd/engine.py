@@ -242,6 +242,47 @@ class Engine:
                                              (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
         return out
 
+    # ---- verification metrics (host arrays in / out; the trial list is small next to the embeddings) --------------------
+    def _scores_labels(self, scores, labels):
+        if _is_torch(scores):
+            scores = scores.detach().cpu().numpy()
+        if _is_torch(labels):
+            labels = labels.detach().cpu().numpy()
+        s = np.ascontiguousarray(np.asarray(scores, dtype=np.float32).ravel())
+        l = np.ascontiguousarray(np.asarray(labels).ravel().astype(np.int32))
+        if s.shape != l.shape or s.size == 0:
+            raise ValueError("scores and labels must be non-empty and of equal length")
+        return s, l
+
+    def roc_points(self, scores, labels):
+        """-> (fps, tps, thresholds) of sklearn's _binary_clf_curve (float64 counts, highest threshold first)."""
+        s, l = self._scores_labels(scores, labels)
+        P = s.size
+        thr = np.empty(P, np.float32)
+        fps, tps = np.empty(P, np.int64), np.empty(P, np.int64)
+        n = C.c_int64()
+        self._ck(self.lib.svhip_roc_points(self.h, s.ctypes.data, l.ctypes.data, P, C.byref(n), thr.ctypes.data,
+                                           fps.ctypes.data, tps.ctypes.data, 0))
+        k = n.value
+        return fps[:k].astype(np.float64), tps[:k].astype(np.float64), thr[:k].copy()
+
+    def error_rates(self, scores, labels):
+        """ComputeErrorRates (utils.py:221-256) -> (fnrs, fprs float64, thresholds float32), ascending thresholds."""
+        s, l = self._scores_labels(scores, labels)
+        P = s.size
+        fnrs, fprs, thr = np.empty(P, np.float64), np.empty(P, np.float64), np.empty(P, np.float32)
+        self._ck(self.lib.svhip_error_rates(self.h, s.ctypes.data, l.ctypes.data, P, fnrs.ctypes.data, fprs.ctypes.data,
+                                            thr.ctypes.data, 0))
+        return fnrs, fprs, thr
+
+    def min_dcf(self, scores, labels, p_target, c_miss, c_fa):
+        """ComputeErrorRates + ComputeMinDcf (utils.py:221-275) -> (min_dcf, threshold)."""
+        s, l = self._scores_labels(scores, labels)
+        d, t = C.c_double(), C.c_float()
+        self._ck(self.lib.svhip_min_dcf(self.h, s.ctypes.data, l.ctypes.data, s.size, float(p_target), float(c_miss),
+                                        float(c_fa), C.byref(d), C.byref(t), 0))
+        return d.value, t.value
+
     def asnorm_stats(self, E, cohort, top=200):
         N, D = E.shape
         K = cohort.shape[0]

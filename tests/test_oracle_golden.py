@@ -152,3 +152,23 @@ def test_fbank_restatement_is_self_consistent():
     l32 = o_fbank.log_mean_norm(torch.from_numpy(r32).double()).numpy()
     l64 = o_fbank.log_mean_norm(torch.from_numpy(r64)).numpy()
     assert np.abs(l32 - l64).max() <= 1e-4
+
+
+@pytest.mark.parametrize("case", ["small", "ties", "distinct", "skewed"])
+def test_metrics_oracle_matches_reference_outputs(golden_dir, case):
+    """oracle/metrics.py == the reference's tuneThresholdfromScore / ComputeErrorRates / ComputeMinDcf (utils.py:74-121,
+    221-275, run with the installed sklearn by oracle/make_golden.py::golden_metrics), bit for bit."""
+    from oracle import metrics as o_metrics
+    from tests.metrics_data import metrics_case
+    g = np.load(os.path.join(golden_dir, "metrics.npz"))
+    sc, lab = metrics_case(case)
+    res = o_metrics.tune_threshold_from_score([float(v) for v in sc], [int(v) for v in lab], [1, 0.1], [5])
+    assert np.array_equal(np.array([res["gmean"][0], res["gmean"][1], res["gmean"][2]], np.float64), g[case + "_gmean"])
+    assert np.array_equal(np.array(res["roc"][0], np.float64), g[case + "_tuned"])
+    assert np.array_equal(np.array([res["roc"][1], res["roc"][2], res["roc"][3]], np.float64), g[case + "_eer_auc_thr"])
+    assert np.array_equal(res["prec_recall"][0], g[case + "_precision"]) and np.array_equal(res["prec_recall"][1], g[case + "_recall"])
+    fnrs, fprs, thr = o_metrics.compute_error_rates(sc, lab)
+    assert np.array_equal(fnrs, g[case + "_fnrs"]) and np.array_equal(fprs, g[case + "_fprs"]) and np.array_equal(thr, g[case + "_thr"])
+    d = g[case + "_mindcf"]
+    assert o_metrics.compute_min_dcf(fnrs, fprs, thr, 0.05, 1, 1) == (d[0], d[1])
+    assert o_metrics.compute_min_dcf(fnrs, fprs, thr, 0.01, 10, 1) == (d[2], d[3])
