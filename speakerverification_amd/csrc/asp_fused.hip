@@ -13,9 +13,11 @@
 //     v_mfma_f32_32x32x16_bf16 leave the whole logit column of a channel in ONE lane pair
 //     (208 accumulator registers), so max / exp / sum over time are register reductions plus one
 //     cross-half shuffle — the logits never exist in memory;
-//   * x (the mfa output) is streamed once: each wave LDS-DMAs its own 32-frame x 32-channel slabs
-//     (double buffered, private to the wave: only its own vmcnt orders them) and accumulates
-//     sum e*x and sum e*x^2 in fp32;  var = E_w[x^2] - mu^2.
+//   * x (the mfa output) is streamed once: each wave LDS-DMAs its own 32-frame x 32-channel slabs into a private ring
+//     of 7 (only its own vmcnt orders them) and accumulates sum e*x and sum e*x^2 in fp32;  var = E_w[x^2] - mu^2.
+//     The slab stream runs ahead across passes — 6 slabs (12 KB per wave, 48 KB per CU) stay in flight through the
+//     logit MFMAs and the softmax of the next 128 channels: with two slabs in flight the kernel sat at 1.6 TB/s
+//     (bytes in flight, not bandwidth, was the bound).
 #include "common.h"
 #include "kernels.h"
 
@@ -30,7 +32,9 @@ constexpr int AF_TMAX = 416;                       // 13 frame tiles of 32
 constexpr int AF_MT = 13;
 constexpr int AF_ATT_BYTES = AF_TMAX * 256;        // att tile: 256-byte rows (128 bf16)
 constexpr int AF_SLAB = 32 * 64;                   // one wave's x slab: 32 frames x 32 channels bf16
-constexpr int AF_LDS = AF_ATT_BYTES + 4 * 2 * AF_SLAB;   // 104 KiB + 16 KiB
+constexpr int AF_NSLOT = 7;                        // slab ring per wave
+constexpr int AF_AHEAD = 6;                        // slabs in flight per wave
+constexpr int AF_LDS = AF_ATT_BYTES + 4 * AF_NSLOT * AF_SLAB;   // 104 KiB + 56 KiB = all 160 KiB
 
 __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
-    char* slab = smem + AF_ATT_BYTES + wave * 2 * AF_SLAB;
+    char* slab = smem + AF_ATT_BYTES + wave * AF_NSLOT * AF_SLAB;
 
     // ---- att_b -> LDS (rows >= T repeat the last frame; they are masked out of the softmax) ---------
     {
@@ -57,20 +61,27 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
 
     const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(p.X) + (int64_t)b * T * p.ldx;
     const int npass = p.C / 128;
+    // x slab stream: slab s = (pass s / 13, frame tile s % 13) of this wave's 32 channels -> ring slot s % 7;
+    // 32 rows x 64 B = two wave-instructions per slab
+    const int nslab = npass * AF_MT;
+    int is_pass = 0, is_mt = 0, is_slot = 0;          // next slab to issue
+    auto issue_next = [&]() {
+        const int cbase = is_pass * 128 + wave * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = q * 16 + (lane >> 2);
+            const int t = min(is_mt * 32 + row, T - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(X + (int64_t)t * p.ldx + cbase + (lane & 3) * 8),
+                                             (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, 0);
+        }
+        if (++is_mt == AF_MT) { is_mt = 0; ++is_pass; }
+        if (++is_slot == AF_NSLOT) is_slot = 0;
+    };
+    for (int i = 0; i < AF_AHEAD && i < nslab; ++i) issue_next();
+    int s_idx = 0, rd_slot = 0;                       // next slab to consume
     for (int pass = 0; pass < npass; ++pass) {
         const int c0 = pass * 128 + wave * 32;
         const int c = c0 + fr;
-        // x slab DMA for frame tile mt of this wave's 32 channels: 32 rows x 64 B = two wave-instructions
-        auto issue_slab = [&](int mt, int buf) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int row = q * 16 + (lane >> 2);
-                const int t = min(mt * 32 + row, T - 1);
-                __builtin_amdgcn_global_load_lds((gbl_void*)(X + (int64_t)t * p.ldx + c0 + (lane & 3) * 8),
-                                                 (lds_void*)(slab + buf * AF_SLAB + q * 1024), 16, 0, 0);
-            }
-        };
-        issue_slab(0, 0);
 
         // ---- logits for 32 channels x all frames: A = att (rows = frames), B = asp.conv weights ------
         bf16x8 wf[8];
@@ -95,25 +106,31 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[kk], acc[mt], 0, 0, 0);
             }
         }
-        // acc[mt][r]: frame t = mt*32 + (r&3) + 8*(r>>2) + 4*fh, channel c (this lane)
-        const float bias = p.bias[c];
+        // acc[mt][r]: frame t = mt*32 + (r&3) + 8*(r>>2) + 4*fh, channel c (this lane).
+        // softmax over t is invariant to the per-channel bias of asp.conv (constant in t), so it is never added; frames >= T
+        // (tail of the last tile) are masked to -inf; exp(l - mx) = exp2(l*log2e - mx*log2e): one fma + v_exp.
         float mx = -INFINITY;
 #pragma unroll
-        for (int mt = 0; mt < AF_MT; ++mt)
+        for (int mt = 0; mt < AF_MT; ++mt) {
+            if ((mt + 1) * 32 > T) {                 // uniform: only tiles that reach past the utterance (the last one at T = 401)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float l = t < T ? acc[mt][r] + bias : -INFINITY;
-                acc[mt][r] = l;
-                mx = fmaxf(mx, l);
+                for (int r = 0; r < 16; ++r) {
+                    const int t = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (t >= T) acc[mt][r] = -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(acc[mt][r], acc[mt][r + 1]));      // v_max3_f32
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        constexpr float L2E = 1.44269504088896340736f;
+        const float nmx = -mx * L2E;
         float se = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < AF_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(acc[mt][r] - mx);              // exp(-inf) = 0 for masked frames
+                const float e = __builtin_amdgcn_exp2f(fmaf(acc[mt][r], L2E, nmx));      // exp2(-inf) = 0 for masked frames
                 acc[mt][r] = e;
                 se += e;
             }
@@ -121,13 +138,22 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
         float sx = 0.0f, sxx = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < AF_MT; ++mt) {
-            if (mt + 1 < AF_MT) {
-                issue_slab(mt + 1, (mt + 1) & 1);
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        // slab mt landed (own DMAs only)
+            // slot (s_idx + 6) % 7 == (s_idx - 1) % 7 was consumed in the previous iteration: restage it, then wait for slab
+            // s_idx itself (own DMAs only): at most min(6, slabs left) newer slabs may stay in flight
+            asm volatile("" ::: "memory");
+            if (s_idx + AF_AHEAD < nslab) {
+                issue_next();
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int left = nslab - 1 - s_idx;
+                if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            const char* sp = slab + (mt & 1) * AF_SLAB + fr * 2;
+            const char* sp = slab + rd_slot * AF_SLAB + fr * 2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tl = (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -136,6 +162,8 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
                 sx += ex;
                 sxx = fmaf(ex, xv, sxx);
             }
+            ++s_idx;
+            if (++rd_slot == AF_NSLOT) rd_slot = 0;
         }
         se += __shfl_xor(se, 32, 64);
         sx += __shfl_xor(sx, 32, 64);
