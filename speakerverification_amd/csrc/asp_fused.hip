@@ -28,6 +28,11 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
+#ifdef SVHIP_GEMM_DEBUG
+constexpr bool AFDBG = true;
+#else
+constexpr bool AFDBG = false;
+#endif
 constexpr int AF_TMAX = 416;                       // 13 frame tiles of 32
 constexpr int AF_MT = 13;
 constexpr int AF_ATT_BYTES = AF_TMAX * 256;        // att tile: 256-byte rows (128 bf16)
@@ -65,47 +70,99 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
     // 32 rows x 64 B = two wave-instructions per slab
     const int nslab = npass * AF_MT;
     int is_pass = 0, is_mt = 0, is_slot = 0;          // next slab to issue
+    // lane part of the source address (row inside the tile, 16-byte piece) as 32-bit byte offsets: [q] for full tiles,
+    // [2 + q] for the last tile, whose rows are clamped to the last frame
+    uint32_t xoff[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = q * 16 + (lane >> 2);
+        xoff[q] = ((uint32_t)row * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
+        xoff[2 + q] = ((uint32_t)(min((AF_MT - 1) * 32 + row, T - 1) - (AF_MT - 1) * 32) * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
+    }
     auto issue_next = [&]() {
-        const int cbase = is_pass * 128 + wave * 32;
+        const char* gb = reinterpret_cast<const char*>(X) + ((int64_t)is_mt * 32 * p.ldx + is_pass * 128 + wave * 32) * 2;    // uniform
+        const bool last = (is_mt + 1) * 32 > T;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int row = q * 16 + (lane >> 2);
-            const int t = min(is_mt * 32 + row, T - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(X + (int64_t)t * p.ldx + cbase + (lane & 3) * 8),
-                                             (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, 0);
+            uint32_t o = last ? xoff[2 + q] : xoff[q];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gb + o), (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, 0);
         }
         if (++is_mt == AF_MT) { is_mt = 0; ++is_pass; }
         if (++is_slot == AF_NSLOT) is_slot = 0;
     };
     for (int i = 0; i < AF_AHEAD && i < nslab; ++i) issue_next();
     int s_idx = 0, rd_slot = 0;                       // next slab to consume
+    // transposed slab read: a lane needs x[t0 .. t0+3][its channel] for t0 = 8j + 4fh: a 4-row x 16-channel block per 16-lane
+    // group, column-major -> one ds_read_b64_tr_b16 (lane 4q+p supplies row q, channels 4p..4p+3) instead of four 2-byte reads.
+    // Inline asm: through the builtin the compiler orders the read behind EVERY pending LDS-DMA with vmcnt(0), draining the ring.
+    // The reads of slab s+1 are issued at the end of tile s and waited for (lgkmcnt) at the start of tile s+1, across passes too.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 xr0, xr1, xr2, xr3;
+    const uint32_t sp0 = (uint32_t)(uintptr_t)(slab + (4 * fh + ((lane >> 2) & 3)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8);
+    auto read_slab = [&](int slot) {
+        const uint32_t sp = sp0 + slot * AF_SLAB;
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:1024\n\tds_read_b64_tr_b16 %3, %4 offset:1536"
+                     : "=&v"(xr0), "=&v"(xr1), "=&v"(xr2), "=&v"(xr3) : "v"(sp) : "memory");
+    };
+    if (nslab > AF_AHEAD) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // slab 0 landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    read_slab(0);
+    bf16x8 wnext[8];
+    auto load_w = [&](int pass_) {
+        const char* wsrc = reinterpret_cast<const char*>(p.W) + ((int64_t)(pass_ * 128 + wave * 32 + fr) * p.Kp) * 2 + fh * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) wnext[kk] = *reinterpret_cast<const bf16x8*>(wsrc + kk * 32);
+    };
+    load_w(0);
+    unsigned long long tph[5] = {0, 0, 0, 0, 0};
+#define AF_STAMP(v) unsigned long long v = 0; if (AFDBG && p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); v = __builtin_readcyclecounter(); }
     for (int pass = 0; pass < npass; ++pass) {
         const int c0 = pass * 128 + wave * 32;
         const int c = c0 + fr;
+        AF_STAMP(t0)
 
-        // ---- logits for 32 channels x all frames: A = att (rows = frames), B = asp.conv weights ------
+        // ---- logits for 32 channels x all frames: A = att (rows = frames), B = asp.conv weights (prefetched during the
+        //      previous pass's moments loop) ------
         bf16x8 wf[8];
-        {
-            const char* wsrc = reinterpret_cast<const char*>(p.W) + ((int64_t)(c0 + fr) * p.Kp) * 2 + fh * 16;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) wf[kk] = *reinterpret_cast<const bf16x8*>(wsrc + kk * 32);
-        }
+        for (int kk = 0; kk < 8; ++kk) wf[kk] = wnext[kk];
         f32x16 acc[AF_MT];
 #pragma unroll
         for (int mt = 0; mt < AF_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        if (AFDBG && p.dbg) { float zz = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < AF_MT; ++mt) {
-            const int row = mt * 32 + fr;
-            const char* ap = att + row * 256;
-            const int sw = row & 15;
+            for (int kk = 0; kk < 8; ++kk) zz += static_cast<float>(wf[kk][0]);
+            asm volatile("" :: "v"(zz)); }
+        AF_STAMP(t1)
+        // k-step outer, frame tile inner: 13 independent accumulators between two MFMAs on the same one (a k-inner order
+        // chains 8 dependent MFMAs per tile), and the A fragments of step kk+1 are in flight under the MFMAs of step kk
+        {
+            const char* ap = att + fr * 256;
+            const int sw = fr & 15;                              // (mt*32 + fr) & 15
+            bf16x8 af[2][AF_MT];
+#pragma unroll
+            for (int mt = 0; mt < AF_MT; ++mt) af[0][mt] = *reinterpret_cast<const bf16x8*>(ap + mt * 8192 + ((fh ^ sw) << 4));
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + (((2 * kk + fh) ^ sw) << 4));
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[kk], acc[mt], 0, 0, 0);
+                if (kk < 7) {
+#pragma unroll
+                    for (int mt = 0; mt < AF_MT; ++mt)
+                        af[(kk + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(ap + mt * 8192 + (((2 * (kk + 1) + fh) ^ sw) << 4));
+                }
+#pragma unroll
+                for (int mt = 0; mt < AF_MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][mt], wf[kk], acc[mt], 0, 0, 0);
             }
         }
+        if (AFDBG && p.dbg) { float zz = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < AF_MT; ++mt) zz += acc[mt][0];
+            asm volatile("" :: "v"(zz)); }
+        AF_STAMP(t2)
         // acc[mt][r]: frame t = mt*32 + (r&3) + 8*(r>>2) + 4*fh, channel c (this lane).
         // softmax over t is invariant to the per-channel bias of asp.conv (constant in t), so it is never added; frames >= T
         // (tail of the last tile) are masked to -inf; exp(l - mx) = exp2(l*log2e - mx*log2e): one fma + v_exp.
@@ -125,46 +182,52 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         constexpr float L2E = 1.44269504088896340736f;
         const float nmx = -mx * L2E;
-        float se = 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < AF_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(acc[mt][r], L2E, nmx));      // exp2(-inf) = 0 for masked frames
-                acc[mt][r] = e;
-                se += e;
-            }
+        float se = 0.0f;                                  // e = exp2(...) is taken tile by tile in the moments loop below (one v_exp per logit)
+        if (AFDBG && p.dbg) asm volatile("" :: "v"(nmx));
+        AF_STAMP(t3)
         // ---- weighted first / second moments of x, slab by slab --------------------------------------------
-        float sx = 0.0f, sxx = 0.0f;
+        if (pass + 1 < npass) load_w(pass + 1);          // lands under the moments loop
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 se2 = {0.f, 0.f}, sx2 = {0.f, 0.f}, sxx2 = {0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < AF_MT; ++mt) {
-            // slot (s_idx + 6) % 7 == (s_idx - 1) % 7 was consumed in the previous iteration: restage it, then wait for slab
-            // s_idx itself (own DMAs only): at most min(6, slabs left) newer slabs may stay in flight
+            // slot (s_idx + 6) % 7 == (s_idx - 1) % 7 was consumed in the previous iteration: restage it; then make sure slab
+            // s_idx + 1 has landed (own DMAs only; 5 newer slabs stay in flight) so that its LDS reads can go out after this tile
             asm volatile("" ::: "memory");
             if (s_idx + AF_AHEAD < nslab) {
                 issue_next();
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             } else {
-                const int left = nslab - 1 - s_idx;
-                if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last six slabs of the stream
             }
-            const char* sp = slab + rd_slot * AF_SLAB + fr * 2;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr0), "+v"(xr1), "+v"(xr2), "+v"(xr3) :: "memory");
+            const u32x2 xr[4] = {xr0, xr1, xr2, xr3};
+            // two frames at a time on the packed fp32 pipe (v_pk_fma / v_pk_mul / v_pk_add); only the two v_exp are scalar
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tl = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float xv = static_cast<float>(*reinterpret_cast<const bf16_t*>(sp + tl * 64));
-                const float ex = acc[mt][r] * xv;
-                sx += ex;
-                sxx = fmaf(ex, xv, sxx);
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const uint32_t w = xr[j][h2];
+                    const f32x2 xv = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                    const f32x2 lg = {acc[mt][4 * j + 2 * h2], acc[mt][4 * j + 2 * h2 + 1]};
+                    const f32x2 z = lg * f32x2{L2E, L2E} + f32x2{nmx, nmx};
+                    const f32x2 e = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};      // exp2(-inf) = 0 for masked frames
+                    se2 += e;
+                    const f32x2 ex = e * xv;
+                    sx2 += ex;
+                    sxx2 = ex * xv + sxx2;
+                }
             }
             ++s_idx;
             if (++rd_slot == AF_NSLOT) rd_slot = 0;
+            asm volatile("" :: "v"(sx2), "v"(sxx2) : "memory");         // the tile's use of xr ends here
+            if (s_idx < nslab) read_slab(rd_slot);
         }
+        float sx = sx2.x + sx2.y, sxx = sxx2.x + sxx2.y;
+        se = se2.x + se2.y;
+        if (AFDBG && p.dbg) asm volatile("" :: "v"(sx), "v"(sxx));
+        AF_STAMP(t4)
+        if (AFDBG && p.dbg) { tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; }
         se += __shfl_xor(se, 32, 64);
         sx += __shfl_xor(sx, 32, 64);
         sxx += __shfl_xor(sxx, 32, 64);
@@ -178,6 +241,8 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
             p.pooled_bn[o + p.C + c] = fmaf(sd, p.bn_scale[p.C + c], p.bn_shift[p.C + c]);
         }
     }
+    if (AFDBG && p.dbg && tid == 0) { for (int i = 0; i < 4; ++i) p.dbg[(int64_t)b * 4 + i] = tph[i]; }
+#undef AF_STAMP
 }
 
 }  // namespace

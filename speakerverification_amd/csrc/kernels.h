@@ -147,6 +147,7 @@ struct AspFusedParams {
     float* pooled_bn = nullptr;     // (B, 2C)
     int ldx = 0, T = 0, C = 0, Kp = 0;
     float eps = 1e-12f;
+    unsigned long long* dbg = nullptr;   // tools/asp_bench: per-phase s_memtime totals of wave 0 (only read in -DSVHIP_GEMM_DEBUG builds)
 };
 bool asp_fused_supported(int T, int C, int att_channels, int Kp);
 hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream);

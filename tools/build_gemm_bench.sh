@@ -11,3 +11,6 @@ wait
 /opt/rocm/bin/hipcc $FL -c $CS/res2net.hip -o tools/res2net.dbg.o
 /opt/rocm/bin/hipcc $FL -c tools/res2_bench.hip -o tools/res2_bench.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/res2_bench.o tools/res2net.dbg.o -o tools/res2_bench
+/opt/rocm/bin/hipcc $FL -c $CS/asp_fused.hip -o tools/asp_fused.dbg.o
+/opt/rocm/bin/hipcc $FL -c tools/asp_bench.hip -o tools/asp_bench.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 tools/asp_bench.o tools/asp_fused.dbg.o -o tools/asp_bench
