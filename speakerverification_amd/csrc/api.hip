@@ -72,6 +72,7 @@ struct svhip_handle {
     ConvLayer tdnn1[3], tdnn2[3], res2[3][7];
     LinearLayer se1[3], se2[3], asp_ctx, fc;
     float* se2T[3] = {};                      // se_block.conv2 weight transposed to [128][C]
+    void *se1_bf[3] = {}, *se2T_bf[3] = {};   // bf16 copies of both SE matrices (bf16 handles: half the L2 bytes per workgroup)
     float *aspbn_scale = nullptr, *aspbn_shift = nullptr;
     float *in_w = nullptr, *in_b = nullptr;   // instance norm affine
 
@@ -491,6 +492,18 @@ int finalize_ecapa(svhip_handle* h) {
             for (int c = 0; c < C; ++c)
                 for (int n = 0; n < 128; ++n) t[(size_t)n * C + c] = w2->data[(size_t)c * 128 + n];
             if ((rc = dev_upload(h, &h->se2T[i - 1], t))) return rc;
+            if (h->bf16) {
+                const HostTensor* w1 = getw(h, p + ".se_block.conv1.conv.weight");  // (128, C, 1)
+                std::vector<uint16_t> b1v((size_t)128 * C), b2v((size_t)128 * C);
+                for (size_t k = 0; k < b1v.size(); ++k) { b1v[k] = f32_to_bf16_rne(w1->data[k]); b2v[k] = f32_to_bf16_rne(t[k]); }
+                for (int which = 0; which < 2; ++which) {
+                    void* d = nullptr;
+                    SV_HIP(h, hipMalloc(&d, b1v.size() * 2));
+                    h->allocs.push_back(d);
+                    SV_HIP(h, hipMemcpy(d, which ? b2v.data() : b1v.data(), b1v.size() * 2, hipMemcpyHostToDevice));
+                    (which ? h->se2T_bf[i - 1] : h->se1_bf[i - 1]) = d;
+                }
+            }
         }
     }
     if ((rc = make_tdnn(h, h->mfa, "mfa", 1))) return rc;
@@ -762,8 +775,9 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
             if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(H3, bf, C, B, T, C, d_mean, st); }))) return rc;
         }
         if ((rc = run(h, "se_mlp", 4.0 * B * 128 * C, [&]() {
-                 return launch_se_mlp(from_part ? nullptr : d_mean, from_part ? cs_base : nullptr, T, h->se1[i].W, h->se1[i].bias,
-                                      h->se2T[i], h->se2[i].bias, d_s2, B, C, 128, st);
+                 return launch_se_mlp(from_part ? nullptr : d_mean, from_part ? cs_base : nullptr, T,
+                                      bf ? (const void*)h->se1_bf[i] : (const void*)h->se1[i].W, h->se1[i].bias,
+                                      bf ? (const void*)h->se2T_bf[i] : (const void*)h->se2T[i], h->se2[i].bias, d_s2, bf, B, C, 128, st);
              }))) return rc;
         void* xout = off(CAT, (size_t)i * C, e);
         if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))

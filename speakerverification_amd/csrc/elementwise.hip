@@ -203,45 +203,51 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 // coalesced along C in 16-byte loads (the kernel is bound by how many of those each lane keeps in flight:
 // 1 MB of fp32 weights per workgroup out of L2).  With `part` the squeeze (mean over frames) is taken straight
 // from the column-sum partials of the pw2 GEMM epilogue (layout: colsum_finalize_kernel above).
+template <typename WT>
 __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ part, int T,
-                                                     const float* __restrict__ W1, const float* __restrict__ b1,
-                                                     const float* __restrict__ W2T, const float* __restrict__ b2,
+                                                     const WT* __restrict__ W1, const float* __restrict__ b1,
+                                                     const WT* __restrict__ W2T, const float* __restrict__ b2,
                                                      float* __restrict__ s, int B, int C, int H) {
+    constexpr int VEC = Vec16<WT>::N;                           // weights per 16-byte load: 4 fp32 / 8 bf16 (bf16 handles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* xm4 = reinterpret_cast<f32x4*>(smem);                // [C / 4]
-    float* hid = reinterpret_cast<float*>(smem) + C;            // [H]
+    float* xm = reinterpret_cast<float*>(smem);                 // [C]
+    f32x4* xm4 = reinterpret_cast<f32x4*>(smem);
+    float* hid = xm + C;                                        // [H]
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nch = C >> 2;
+    const int nch4 = C >> 2, nch = C / VEC;
     if (part) {
         const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
         const int r0 = b * T, r1 = r0 + T - 1;
         const float inv = 1.0f / (float)T;
-        for (int ch = threadIdx.x; ch < nch; ch += 256) {
+        for (int ch = threadIdx.x; ch < nch4; ch += 256) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
                 const int seg = b - (tm * 256) / T;
                 if (seg < 0 || seg > 1) continue;
 #pragma unroll
-                for (int rg = 0; rg < 8; ++rg) acc += p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch + ch];
+                for (int rg = 0; rg < 8; ++rg) acc += p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch4 + ch];
             }
             xm4[ch] = acc * inv;
         }
     } else {
         const f32x4* m4 = reinterpret_cast<const f32x4*>(mean + (int64_t)b * C);
-        for (int ch = threadIdx.x; ch < nch; ch += 256) xm4[ch] = m4[ch];
+        for (int ch = threadIdx.x; ch < nch4; ch += 256) xm4[ch] = m4[ch];
     }
     __syncthreads();
-    const f32x4* W14 = reinterpret_cast<const f32x4*>(W1);
+    const Vec16<WT>* W1v = reinterpret_cast<const Vec16<WT>*>(W1);
     for (int n0 = wave * 4; n0 < H; n0 += 16) {                 // 4 hidden units per wave per pass
         float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int ch = lane; ch < nch; ch += 64) {
-            const f32x4 x = xm4[ch];
+            float x[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x[e] = xm[ch * VEC + e];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const f32x4 w = W14[(int64_t)(n0 + u) * nch + ch];
-                a[u] = fmaf(w[0], x[0], fmaf(w[1], x[1], fmaf(w[2], x[2], fmaf(w[3], x[3], a[u]))));
+                const Vec16<WT> w = W1v[(int64_t)(n0 + u) * nch + ch];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a[u] = fmaf(w.get(e), x[e], a[u]);
             }
         }
 #pragma unroll
@@ -251,18 +257,20 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         }
     }
     __syncthreads();
-    const f32x4* W24 = reinterpret_cast<const f32x4*>(W2T);
-    for (int ch = threadIdx.x; ch < nch; ch += 256) {           // 4 output channels per thread: dot over H
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(b2 + 4 * ch), a1 = {0.f, 0.f, 0.f, 0.f};
+    const Vec16<WT>* W2v = reinterpret_cast<const Vec16<WT>*>(W2T);
+    for (int ch = threadIdx.x; ch < nch; ch += 256) {           // VEC output channels per thread: dot over H
+        float a0[VEC], a1[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { a0[e] = b2[ch * VEC + e]; a1[e] = 0.f; }
 #pragma unroll 8
         for (int n = 0; n < H; n += 2) {
-            a0 += W24[(int64_t)n * nch + ch] * hid[n];
-            a1 += W24[(int64_t)(n + 1) * nch + ch] * hid[n + 1];
-        }
-        f32x4 o;
+            const Vec16<WT> w0 = W2v[(int64_t)n * nch + ch], w1 = W2v[(int64_t)(n + 1) * nch + ch];
+            const float h0 = hid[n], h1 = hid[n + 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = 1.0f / (1.0f + expf(-(a0[e] + a1[e])));
-        *reinterpret_cast<f32x4*>(s + (int64_t)b * C + 4 * ch) = o;
+            for (int e = 0; e < VEC; ++e) { a0[e] = fmaf(w0.get(e), h0, a0[e]); a1[e] = fmaf(w1.get(e), h1, a1[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[(int64_t)b * C + ch * VEC + e] = 1.0f / (1.0f + expf(-(a0[e] + a1[e])));
     }
 }
 
@@ -447,11 +455,12 @@ hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool wit
     return hipGetLastError();
 }
 
-hipError_t launch_se_mlp(const float* mean, const float* part, int T, const float* W1, const float* b1, const float* W2T,
-                         const float* b2, float* s, int B, int C, int H, hipStream_t stream) {
+hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
+                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream) {
     const size_t lds = (size_t)(C + H) * sizeof(float);
-    if (lds > 64 * 1024 || B <= 0 || H % 16 != 0 || C % 4 != 0 || (!mean && !part)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), lds, stream, mean, part, T, W1, b1, W2T, b2, s, B, C, H);
+    if (lds > 64 * 1024 || B <= 0 || H % 16 != 0 || C % 8 != 0 || (!mean && !part)) return hipErrorInvalidValue;
+    if (w_bf16) hipLaunchKernelGGL(se_mlp_kernel<bf16_t>, dim3(B), dim3(256), lds, stream, mean, part, T, (const bf16_t*)W1, b1, (const bf16_t*)W2T, b2, s, B, C, H);
+    else hipLaunchKernelGGL(se_mlp_kernel<float>, dim3(B), dim3(256), lds, stream, mean, part, T, (const float*)W1, b1, (const float*)W2T, b2, s, B, C, H);
     return hipGetLastError();
 }
 

@@ -115,8 +115,8 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
                                 int B, int N, int K, int act, hipStream_t stream);
 // s[b, :] = sigmoid(W2 relu(W1 mean[b, :] + b1) + b2); W1 [H][C], W2T = W2 transposed [H][C]
-hipError_t launch_se_mlp(const float* mean, const float* part, int T, const float* W1, const float* b1, const float* W2T,
-                         const float* b2, float* s, int B, int C, int H, hipStream_t stream);
+hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
+                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream);
 // out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
                            bool bf16, int B, int T, int C, hipStream_t stream);
