@@ -20,8 +20,10 @@ LABELS = {"gemm_pw2_kernel": "gemm_pw2", "gemm_pw_kernel": "gemm_pw", "res2net_c
 
 
 def label(name):
-    if "gemm_pw2_kernel" in name and name.replace(" ", "").split(">(")[0].endswith("true"):
-        return "gemm_pw2_conv"                      # gemm_pw2_kernel<EPI, M16, CONV = true>
+    if "gemm_pw2_kernel" in name:                   # gemm_pw2_kernel<EPI, M16, CONV, PH4>: CONV = true is the conv-gather instance
+        args = name.replace(" ", "").split("<", 1)[-1].split(">", 1)[0].split(",")
+        if len(args) >= 3 and args[2] in ("true", "1"):
+            return "gemm_pw2_conv"
     for k, v in LABELS.items():
         if k in name:
             return v
