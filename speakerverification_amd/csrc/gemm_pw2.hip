@@ -39,7 +39,7 @@ constexpr int HA = QBM * HROWB;                 // 16 KiB
 constexpr int HSTAGE = HA + QBN * HROWB;        // 32 KiB
 constexpr int NRING = 4;
 constexpr int PW2_LDS = NRING * HSTAGE;         // 128 KiB (also holds the 256 x 256 bf16 output tile)
-constexpr int QGROUP_M = 8;
+constexpr int QGROUP_M = 12;
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
 #ifdef SVHIP_GEMM_DEBUG
@@ -74,12 +74,14 @@ __device__ __forceinline__ f32x2_t gelu_pair(f32x2_t x) {
     return x * r;
 }
 
-template <int EPI>
+// HASB = false: the bias is already in the accumulator (the four-phase loop starts its accumulators at the bias)
+template <int EPI, bool HASB = true>
 __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4& b4, const f32x4& sc4, const f32x4& sh4) {
     if (EPI == EPI_GELU) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x2_t x = {a[2 * h] + b4[2 * h], a[2 * h + 1] + b4[2 * h + 1]};
+            f32x2_t x = {a[2 * h], a[2 * h + 1]};
+            if (HASB) x += f32x2_t{b4[2 * h], b4[2 * h + 1]};
             const f32x2_t g = gelu_pair(x);
             const f32x2_t sc = {sc4[2 * h], sc4[2 * h + 1]}, sh = {sh4[2 * h], sh4[2 * h + 1]};
             const f32x2_t y = g * sc + sh;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float t = a[e] + b4[e];
+            float t = HASB ? a[e] + b4[e] : a[e];
             if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
             if (EPI == EPI_LRELU03) t = t > 0.0f ? t : 0.3f * t;
             v[e] = fmaf(t, sc4[e], sh4[e]);
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    const int qgm = (DBG2 && (p.debug & 1024)) ? 8 : (DBG2 && (p.debug & 2048)) ? 2 : QGROUP_M;
+    const int qgm = (DBG2 && (p.debug & 1024)) ? 16 : (DBG2 && (p.debug & 2048)) ? 8 : QGROUP_M;
     const int grp_t = id / (qgm * ntn);
     const int within = id - grp_t * (qgm * ntn);
     const int gm = min(qgm, ntm - grp_t * qgm);
@@ -135,9 +137,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
     if (M16) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+            if (PH4 && p.bias) {                       // acc16[i][j][e] is channel n0 + wn*64 + j*16 + 4*(lane>>4) + e of frame i*16 + (lane&15)
+                const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+                if (n < p.N) b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[M16 ? i : 0][M16 ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 8; ++i) acc16[M16 ? i : 0][M16 ? j : 0] = b0;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 a4[e] = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
-            act4<EPI>(v, a4, b4, sc4, sh4);
+            act4<EPI, !PH4>(v, a4, b4, sc4, sh4);
             typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
