@@ -1,0 +1,112 @@
+"""GPU: the headline configuration at full size (BASELINE configs[1]: ECAPA-TDNN C = 1024, bf16, 256 utterances of 2 s)
+through size-independent properties — the oracle cannot run 256 utterances in seconds — and the C ABI's error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from speakerverification_amd import _lib, synth
+from speakerverification_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def cos_rows(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.fixture(scope="module")
+def big():
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=1024), seed=1)
+    eng = Engine(model="ecapa", compute="bf16", channels=1024, max_batch=256)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    wav = synth.synth_waveforms(256, 32000, seed=20220829)
+    yield eng, sd, wav
+    eng.close()
+
+
+def test_full_batch_is_deterministic_and_finite(big):
+    eng, _, wav = big
+    a = eng.embed_wave(wav)
+    b = eng.embed_wave(wav)
+    assert a.shape == (256, 192) and np.isfinite(a).all()
+    assert np.array_equal(a, b)                                   # same launch sequence, no atomics: bit-identical
+
+
+def test_utterances_do_not_see_their_batch(big):
+    """An embedding depends on its own waveform only: permuting the batch permutes the rows, and a small batch gives the
+    same rows.  Not bit-exact by construction — the SE / ASP time sums are accumulated per 256-row GEMM tile, and an
+    utterance's tile cut moves with its position — but far inside the bf16 path's own error (cos >= 0.999 to fp32)."""
+    eng, _, wav = big
+    full = eng.embed_wave(wav)
+    perm = np.random.Generator(np.random.PCG64(9)).permutation(256)
+    shuffled = eng.embed_wave(wav[perm])
+    assert cos_rows(shuffled, full[perm]).min() >= 0.99995
+    small = eng.embed_wave(wav[:8])
+    assert cos_rows(small, full[:8]).min() >= 0.99995
+    one = eng.embed_wave(wav[100:101])
+    assert cos_rows(one, full[100:101]).min() >= 0.99995
+
+
+def test_bf16_full_batch_tracks_the_fp32_path(big):
+    """bf16 rows of the full batch vs the fp32 (1e-4-parity) path on the same waveforms, 16 utterances."""
+    eng, sd, wav = big
+    full = eng.embed_wave(wav)
+    f32 = Engine(model="ecapa", compute="f32", channels=1024, max_batch=16)
+    f32.load_state_dict(sd)
+    f32.finalize()
+    ref = f32.embed_wave(wav[:16])
+    f32.close()
+    assert cos_rows(full[:16], ref).min() >= 0.999
+    assert np.abs(full[:16] - ref).max() <= 0.03 * np.abs(ref).max()
+
+
+def test_scaling_and_silence(big):
+    """Log-mel + mean normalisation makes the network invariant to input gain; digital silence must stay finite."""
+    eng, _, wav = big
+    a = eng.embed_wave(wav[:4])
+    b = eng.embed_wave(wav[:4] * 0.25)
+    assert cos_rows(a, b).min() >= 0.999
+    z = eng.embed_wave(np.zeros((2, 32000), np.float32))
+    assert np.isfinite(z).all() and cos_rows(z[:1], z[1:]).min() >= 0.99995      # rows differ only by their tile cut
+
+
+def test_c_abi_error_behaviour():
+    """Status codes and messages of the boundary (include/svhip.h): never a crash, never a silent success."""
+    lib = _lib.load()
+    eng = Engine(model="ecapa", channels=64, max_batch=2)
+    wav = synth.synth_waveforms(3, 32000)
+    out = np.empty((3, 192), np.float32)
+    # forward before the weights are final
+    rc = lib.svhip_embed_wave(eng.h, wav.ctypes.data, 2, 32000, out.ctypes.data, 0)
+    assert rc == -3 and b"finalize" in lib.svhip_last_error(eng.h)                                  # SVHIP_ERR_STATE
+    # unknown tensor / wrong shape keep the reference's wording (model.py:730-742)
+    bad = np.zeros((3, 3), np.float32)
+    shp = (C.c_int64 * 2)(3, 3)
+    assert lib.svhip_load_tensor(eng.h, b"no.such.tensor", bad.ctypes.data, shp, 2, _lib.F32) == -1
+    assert b"is not in the model" in lib.svhip_last_error(eng.h)
+    assert lib.svhip_load_tensor(eng.h, b"fc.conv.bias", bad.ctypes.data, shp, 2, _lib.F32) == -1
+    assert b"Wrong parameter" in lib.svhip_last_error(eng.h)
+    assert lib.svhip_finalize_weights(eng.h) == -6 and b"never loaded" in lib.svhip_last_error(eng.h)   # SVHIP_ERR_MISSING
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=2))
+    eng.finalize()
+    assert lib.svhip_finalize_weights(eng.h) == -3                                                  # twice
+    # batch / length outside the handle's geometry
+    with pytest.raises(_lib.SvhipError, match="max_batch"):
+        eng.embed_wave(wav)
+    with pytest.raises(_lib.SvhipError):
+        eng.embed_wave(wav[:2, :16000])
+    assert lib.svhip_embed_wave(eng.h, None, 2, 32000, out.ctypes.data, 0) == -1                    # null pointer
+    assert lib.svhip_embed_wave(eng.h, wav.ctypes.data, 0, 32000, out.ctypes.data, 0) == -1         # empty batch
+    # ASYNC is only defined for device pointers
+    assert lib.svhip_embed_wave(eng.h, wav.ctypes.data, 2, 32000, out.ctypes.data, _lib.ASYNC) != 0
+    # the handle still works after all of that
+    good = eng.embed_wave(wav[:2])
+    assert np.isfinite(good).all()
+    # scoring argument checks
+    E = np.random.default_rng(0).standard_normal((4, 192)).astype(np.float32)
+    with pytest.raises(_lib.SvhipError):
+        eng.score_pairs(E, np.array([0, 9], np.int32), np.array([1, 2], np.int32))                  # index out of range
+    eng.close()
