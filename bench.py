@@ -203,7 +203,10 @@ def run(args, rank, world, local, dev, dist):
         if dist is not None:
             dist.barrier()
 
-    eng.profile(True)            # HIP events around every launch on the launch stream, resolved after the region
+    # HIP events bracket the dominant kernel's launches on the launch stream inside the timed region (resolved after it);
+    # the other kernels are timed in a separate profiled pass below: two events per launch on ~40 launches per step
+    # cost ~2 % of the step in queue bubbles
+    eng.profile(True, only=DOMINANT)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -216,6 +219,12 @@ def run(args, rank, world, local, dev, dist):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.profile_results()
+    eng.profile(True)            # untimed pass: every kernel bracketed, for the per-kernel table
+    for k in range(min(K, 10)):
+        eng.embed_wave(wav, out=scratch, async_=True)
+    torch.cuda.synchronize()
+    prof_all = eng.profile_results()
+    n_all = min(K, 10)
     eng.profile(False)
 
     if dist is not None:
@@ -236,10 +245,10 @@ def run(args, rank, world, local, dev, dist):
                 traffic = json.load(open(pmc_path)).get(DOMINANT, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kern = {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches_per_step": v["launches"] / K,
-                    "ms_per_step": v["ms"] / K,
+        kern = {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches_per_step": v["launches"] / n_all,
+                    "ms_per_step": v["ms"] / n_all,
                     "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
-                for k, v in prof.items()}
+                for k, v in prof_all.items()}
         total_utts = world * K * B
         line = {
             "metric": "embeddings/sec (2 s @16 kHz)", "value": total_utts / dt, "unit": "embeddings/s",
@@ -259,6 +268,8 @@ def run(args, rank, world, local, dev, dist):
                          "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_ms,
                          "launches": dom["launches"]},
             "kernels": kern,
+            "kernels_note": "per-kernel table from a separate profiled pass of %d steps (every launch bracketed); "
+                            "the roofline kernel is timed live inside the timed region" % n_all,
         }
         if world == 1 and not args.no_cpu_baseline and args.model == "ecapa":
             line["cpu_baseline"] = cpu_baseline()

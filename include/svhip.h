@@ -189,6 +189,7 @@ int svhip_load_blob(svhip_handle* h, const char* path);
  *   workload_flops: algorithmic FLOPs (2 x MACs of conv/linear layers) of one utterance. */
 int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* count);
 int svhip_profile_enable(svhip_handle* h, int32_t on);
+int svhip_profile_filter(svhip_handle* h, const char* label);   /* NULL / "": every kernel; else only this label (fewer events in the stream) */
 int svhip_profile_reset(svhip_handle* h);
 int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops);
 double svhip_workload_flops(const svhip_handle* h);

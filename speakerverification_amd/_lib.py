@@ -75,6 +75,7 @@ _SIGNATURES = {
     "svhip_load_blob": (C.c_int, [_P, C.c_char_p]),
     "svhip_get_stage": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64)]),
     "svhip_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "svhip_profile_filter": (C.c_int, [_P, C.c_char_p]),
     "svhip_profile_reset": (C.c_int, [_P]),
     "svhip_profile_get": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

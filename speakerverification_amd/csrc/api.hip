@@ -119,6 +119,7 @@ struct svhip_handle {
     // profiling: event pairs are recorded around every launch without blocking the host and
     // resolved (hipEventElapsedTime) when results are read
     bool prof = false;
+    std::string prof_filter;                  // non-empty: only launches with exactly this label are bracketed by events
     std::vector<hipEvent_t> ev_free;
     std::vector<PendingEvent> ev_pending;
     std::vector<ProfEntry> prof_entries;
@@ -193,7 +194,8 @@ void prof_collect(svhip_handle* h) {
 template <typename F>
 int run(svhip_handle* h, const char* label, double flops, F&& launch) {
     PendingEvent pe{nullptr, nullptr, -1};
-    if (h->prof) {
+    const bool prof = h->prof && (h->prof_filter.empty() || h->prof_filter == label);
+    if (prof) {
         for (size_t i = 0; i < h->prof_entries.size(); ++i)
             if (h->prof_entries[i].name == label) { pe.entry = (int)i; break; }
         if (pe.entry < 0) { h->prof_entries.push_back(ProfEntry{label}); pe.entry = (int)h->prof_entries.size() - 1; }
@@ -203,7 +205,7 @@ int run(svhip_handle* h, const char* label, double flops, F&& launch) {
     }
     hipError_t e = launch();
     if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "launch %s failed: %s", label, hipGetErrorString(e));
-    if (h->prof) {
+    if (prof) {
         (void)hipEventRecord(pe.e1, h->cur);
         h->prof_entries[pe.entry].launches += 1;
         h->prof_entries[pe.entry].flops += flops;
@@ -1432,6 +1434,7 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
 }
 
 int svhip_profile_enable(svhip_handle* h, int32_t on) { if (!h) return SVHIP_ERR_INVALID; h->prof = on != 0; return SVHIP_OK; }
+int svhip_profile_filter(svhip_handle* h, const char* label) { if (!h) return SVHIP_ERR_INVALID; h->prof_filter = label ? label : ""; return SVHIP_OK; }
 int svhip_profile_reset(svhip_handle* h) { if (!h) return SVHIP_ERR_INVALID; prof_collect(h); h->prof_entries.clear(); return SVHIP_OK; }
 int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops) {
     if (!h) return SVHIP_ERR_INVALID;

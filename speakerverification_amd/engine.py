@@ -313,7 +313,9 @@ class Engine:
         self._ck(self.lib.svhip_get_stage(self.h, name.encode(), out.ctypes.data, C.byref(n)))
         return out
 
-    def profile(self, on=True):
+    def profile(self, on=True, only=None):
+        """HIP events around every kernel launch (``only``: just the launches with that label — fewer events in the stream)."""
+        self._ck(self.lib.svhip_profile_filter(self.h, only.encode() if only else None))
         self._ck(self.lib.svhip_profile_enable(self.h, int(on)))
         if on:
             self._ck(self.lib.svhip_profile_reset(self.h))
