@@ -104,7 +104,7 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
 // PH4 = true (needs M16, !CONV): the K loop runs in 64-wide K tiles of four phases, one accumulator quadrant (64 frames x 32
 // channels, 16 MFMAs) per phase; LDS holds 2 K tiles x {X-lo, X-hi, W-lo, W-hi} half-tiles of 128 rows x 128 bytes, so every
 // global_load_lds instruction moves whole 128-byte lines (the 32-wide ring moves half lines).  See the block comment at the loop.
-template <int EPI, bool M16, bool CONV, bool PH4>
+template <int EPI, bool M16, bool CONV, int PH4>
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 a4[e] = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
-            act4<EPI, !PH4>(v, a4, b4, sc4, sh4);
+            act4<EPI, PH4 == 0>(v, a4, b4, sc4, sh4);
             typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #undef PW2_STAMP
 }
 
-template <int EPI, bool M16, bool CONV, bool PH4 = false>
+template <int EPI, bool M16, bool CONV, int PH4 = 0>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static bool attr_done = false;
@@ -562,10 +562,10 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     }
     if (m16 && !(p.debug & 512)) {                  // four-phase K tiles (default); 512 = A/B switch back to the 32-wide ring
         switch (p.act1) {
-            case ACT_NONE: return launch_inst<EPI_NONE, true, false, true>(p, stream);
-            case ACT_RELU: return launch_inst<EPI_RELU, true, false, true>(p, stream);
-            case ACT_GELU: return launch_inst<EPI_GELU, true, false, true>(p, stream);
-            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, false, true>(p, stream);
+            case ACT_NONE: return launch_inst<EPI_NONE, true, false, 1>(p, stream);
+            case ACT_RELU: return launch_inst<EPI_RELU, true, false, 1>(p, stream);
+            case ACT_GELU: return launch_inst<EPI_GELU, true, false, 1>(p, stream);
+            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, false, 1>(p, stream);
             default: return hipErrorInvalidValue;
         }
     }

@@ -22,6 +22,14 @@ __global__ void fill_f32(float* p, size_t n, uint32_t seed, float scale) {
         p[i] = ((x & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
     }
 }
+__global__ void checksum_bf16(const uint16_t* y, size_t n, double* out) {
+    double s = 0, a = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = __uint_as_float((uint32_t)y[i] << 16);
+        s += v; a += fabs((double)v) * (double)((i % 97) + 1);
+    }
+    atomicAdd(out, s); atomicAdd(out + 1, a);
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; };
@@ -74,7 +82,15 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1, st));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
-            printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+            double hcs[2] = {0, 0};
+            if (bf16 && !s.out_f32) {          // order-sensitive checksum of the output: variants of one shape must agree
+                static double* dcs = nullptr;
+                if (!dcs) CK(hipMalloc(&dcs, 16));
+                CK(hipMemsetAsync(dcs, 0, 16, st));
+                checksum_bf16<<<1024, 256, 0, st>>>((const uint16_t*)Y, (size_t)s.M * s.N, dcs);
+                CK(hipMemcpyAsync(hcs, dcs, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            }
+            printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s  cs %.6e %.6e\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, hcs[0], hcs[1]);
             if (debug & 16384) {          // stage timestamps of one launch (non-persistent pw2 kernel)
                 const int nwg = ((s.M + 255) / 256) * ((s.N + 255) / 256);
                 unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 64)); CK(hipMemset(dts, 0, (size_t)nwg * 64));
