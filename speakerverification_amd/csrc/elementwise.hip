@@ -275,22 +275,33 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
 }
 
 // ---- SE gate + residual -------------------------------------------------------------------------
+// grid (ceil(T / SE_ROWS), B), block 256: a thread keeps one 16-byte column chunk and walks SE_ROWS frames of ONE utterance,
+// so the gate s[b][c..] is loaded once per thread instead of once per output chunk (it was 2x the bytes of the output
+// through L1), and 4 frames' loads are in flight per thread.
+constexpr int SE_ROWS = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ s,
                                                        const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
-                                                       int Tn, int C, int64_t total_chunks) {
+                                                       int Tn, int C) {
     constexpr int VEC = Vec16<T>::N;
-    const int cpr = C / VEC;   // chunks per row
-    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total_chunks; id += (int64_t)gridDim.x * 256) {
-        const int64_t m = id / cpr;
-        const int c = (int)(id - m * cpr) * VEC;
-        const int b = (int)(m / Tn);
-        Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
-        Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
-        Vec16<T> o;
+    const int cpr = C / VEC;                                  // chunks per row
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * SE_ROWS, t1 = min(t0 + SE_ROWS, Tn);
+    for (int cc = threadIdx.x; cc < cpr * 4; cc += 256) {     // 4 frames side by side: thread -> (frame lane fl, chunk)
+        const int fl = cc / cpr, c = (cc - fl * cpr) * VEC;
+        float g[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), s[(int64_t)b * C + c + j], xv.get(j)));
-        *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
+        for (int j = 0; j < VEC; ++j) g[j] = s[(int64_t)b * C + c + j];
+#pragma unroll 4
+        for (int t = t0 + fl; t < t1; t += 4) {
+            const int64_t m = (int64_t)b * Tn + t;
+            const Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
+            const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), g[j], xv.get(j)));
+            *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
+        }
     }
 }
 
@@ -467,11 +478,10 @@ hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
                            bool bf16, int B, int T, int C, hipStream_t stream) {
     const int vec = bf16 ? 8 : 4;
-    if (C % vec || ldh % vec || ldx % vec || ldo % vec) return hipErrorInvalidValue;
-    const int64_t chunks = (int64_t)B * T * (C / vec);
-    dim3 grid(grid_for(chunks)), block(256);
-    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C, chunks);
-    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C, chunks);
+    if (C % vec || ldh % vec || ldx % vec || ldo % vec || B <= 0 || T <= 0) return hipErrorInvalidValue;
+    dim3 grid((T + SE_ROWS - 1) / SE_ROWS, B), block(256);
+    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C);
+    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C);
     return hipGetLastError();
 }
 
