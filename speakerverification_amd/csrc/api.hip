@@ -853,18 +853,23 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
     if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, h->rn_stats, st); }))) return rc;
     int T = h->rn_T1;
     void *x = h->rn_buf[0], *pre = h->rn_buf[1], *hb = h->rn_buf[2], *o = h->rn_buf[3], *sc = h->rn_buf[4], *xn = h->rn_buf[5];
-    if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
-             return launch_rn_sinc(d_wav, h->rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
-         }))) return rc;
     const char* stop_env = getenv("SVHIP_RN_STOP");          // developer hook: stop after N blocks, expose x as stage "rn_x"
     const int stop_after = stop_env ? atoi(stop_env) : -1;
+    if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
+             // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
+             //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
+             return launch_rn_sinc(d_wav, h->rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
+         }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
     for (int bi = 0; bi < 8; ++bi) {
         if (stop_after >= 0 && bi >= stop_after) { h->lastB = B; return SVHIP_OK; }
         svhip_handle::RnBlock& K = h->rn_blocks[bi];
         const int M = B * T;
         // out = lrelu(bn1(x))                                                         RawNet_baseline.py:222
-        if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
+        // (blocks 1..7 get it from the previous block's AFMS pass, which writes x and lrelu(bn1(x)) together)
+        if (bi == 0 || stop_after >= 0) {
+            if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
+        }
         const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
         if (K.has_shortcut) {
             if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
@@ -884,13 +889,17 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
         if ((rc = run(h, "rn_afms_fc", 2.0 * B * K.cout * K.cout, [&]() {
                  return launch_rowvec_linear(h->rn_mean, K.cout, K.afms_fc.W, K.afms_fc.bias, h->rn_s, K.cout, B, K.cout, K.cout, ACT_SIGMOID, st);
              }))) return rc;
-        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, h->rn_s, B, T, K.cout, st); }))) return rc;
+        // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
+        const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
+        const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
+        void* npre = stop_after >= 0 ? nullptr : pre;           // (the developer hook keeps the unfused sequence)
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, h->rn_s, B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
     }
     // aggregation: attentive statistics pooling                                          RawNet2_custom.py:215-224
     const int M = B * T;
-    if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, h->rn_agg_scale, h->rn_agg_shift, M, 512, 0.3f, st); }))) return rc;
+    // (pre = lrelu(bn_before_agg(x)) came out of block 7's AFMS pass)
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att0, pre, 512, hb, 128, M, ACT_LRELU001))) return rc;
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, h->rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
     if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(h->rn_logits, pre, bf, B, T, 512, h->rn_pooled, st); }))) return rc;

@@ -159,12 +159,13 @@ hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipS
 // LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
-                          hipStream_t stream);
+                          hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr);
 hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
                             float slope, hipStream_t stream);
 hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream);
 hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
-                                hipStream_t stream);
+                                hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
+                                void* pre = nullptr, float slope = 0.3f);
 hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

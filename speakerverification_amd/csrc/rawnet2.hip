@@ -66,7 +66,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict__ wav, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const void* __restrict__ filt, const float* __restrict__ bn_scale,
-                                                         const float* __restrict__ bn_shift, T* __restrict__ out, int L, int T1,
+                                                         const float* __restrict__ bn_shift, T* __restrict__ out, T* __restrict__ pre, const float* __restrict__ nscale,
+                                                         const float* __restrict__ nshift, int L, int T1,
                                                          int tiles_per_wg) {
     typedef SincCfg<T> CF;
     constexpr bool BF = sizeof(T) == 2;
@@ -160,13 +161,28 @@ __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict
                     v[e] = y > 0.0f ? y : 0.3f * y;
                 }
                 if (tp < T1) {
-                    T* o = out + ((int64_t)b * T1 + tp) * 128 + f;
+                    const int64_t oi = ((int64_t)b * T1 + tp) * 128 + f;
+                    // second output: block 0's pre-activation lrelu(bn1(x)), from x as stored (== a separate rn_bn_act pass)
+                    f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};
+                    if (pre) { nsc = *reinterpret_cast<const f32x4*>(nscale + f); nsh = *reinterpret_cast<const f32x4*>(nshift + f); }
                     if (BF) {
                         typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                         bf16x4 pk = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
-                        *reinterpret_cast<bf16x4*>(o) = pk;
+                        *reinterpret_cast<bf16x4*>(out + oi) = pk;
+                        if (pre) {
+                            bf16x4 pp;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float t = fmaf(static_cast<float>(pk[e]), nsc[e], nsh[e]); pp[e] = static_cast<bf16_t>(t > 0.0f ? t : 0.3f * t); }
+                            *reinterpret_cast<bf16x4*>(pre + oi) = pp;
+                        }
                     } else {
-                        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(out + oi) = f32x4{v[0], v[1], v[2], v[3]};
+                        if (pre) {
+                            f32x4 pp;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float t = fmaf(v[e], nsc[e], nsh[e]); pp[e] = t > 0.0f ? t : 0.3f * t; }
+                            *reinterpret_cast<f32x4*>(pre + oi) = pp;
+                        }
                     }
                 }
             }
@@ -210,9 +226,13 @@ __global__ __launch_bounds__(256) void rn_maxpool3_kernel(const T* __restrict__ 
     }
 }
 
+// AFMS gate; with `pre` the next block's pre-activation lrelu(bn1(.)) (or the aggregation BN) is written in the same pass,
+// computed from the value as stored (rounded to T), so the result equals a separate rn_bn_act over y bit for bit.
 template <typename T>
 __global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ alpha,
-                                                            const float* __restrict__ s, int Tn, int C, int64_t chunks) {
+                                                            const float* __restrict__ s, int Tn, int C, int64_t chunks,
+                                                            const float* __restrict__ nscale, const float* __restrict__ nshift,
+                                                            T* __restrict__ pre, float slope) {
     constexpr int VEC = Vec16<T>::N;
     const int cpr = C / VEC;
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < chunks; id += (int64_t)gridDim.x * 256) {
@@ -222,6 +242,15 @@ __global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict_
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.set(j, (v.get(j) + alpha[c + j]) * s[b * C + c + j]);
         *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;
+        if (pre) {
+            Vec16<T> q;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float t = fmaf(o.get(j), nscale[c + j], nshift[c + j]);
+                q.set(j, t > 0.0f ? t : slope * t);
+            }
+            *reinterpret_cast<Vec16<T>*>(pre + id * VEC) = q;
+        }
     }
 }
 
@@ -263,17 +292,17 @@ hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipS
 
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
-                          hipStream_t stream) {
-    if (T1 != (L - 250) / 3 || L < 251 + 3) return hipErrorInvalidValue;
+                          hipStream_t stream, void* pre, const float* next_scale, const float* next_shift) {
+    if (T1 != (L - 250) / 3 || L < 251 + 3 || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     const int tiles = (T1 + SINC_PT - 1) / SINC_PT;
     const int tpw = 4;                                        // pooled tiles per workgroup (amortises the filter fragments)
     dim3 grid((tiles + tpw - 1) / tpw, B), block(256);
     if (bf16)
         hipLaunchKernelGGL(rn_sinc_kernel<bf16_t>, grid, block, SincCfg<bf16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
-                           bn_shift, reinterpret_cast<bf16_t*>(out), L, T1, tpw);
+                           bn_shift, reinterpret_cast<bf16_t*>(out), reinterpret_cast<bf16_t*>(pre), next_scale, next_shift, L, T1, tpw);
     else
         hipLaunchKernelGGL(rn_sinc_kernel<float>, grid, block, SincCfg<float>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
-                           bn_shift, reinterpret_cast<float*>(out), L, T1, tpw);
+                           bn_shift, reinterpret_cast<float*>(out), reinterpret_cast<float*>(pre), next_scale, next_shift, L, T1, tpw);
     return hipGetLastError();
 }
 
@@ -298,12 +327,12 @@ hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin,
 }
 
 hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
-                                hipStream_t stream) {
+                                hipStream_t stream, const float* next_scale, const float* next_shift, void* pre, float slope) {
     const int vec = bf16 ? 8 : 4;
-    if (C % vec) return hipErrorInvalidValue;
+    if (C % vec || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     const int64_t chunks = (int64_t)B * T * (C / vec);
-    if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks);
-    else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks);
+    if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (bf16_t*)pre, slope);
+    else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks, next_scale, next_shift, (float*)pre, slope);
     return hipGetLastError();
 }
 
