@@ -79,12 +79,30 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 
     // ---- init: U = c_1, y_0 = c_0 straight to H2, first weight slab ---------------------------------
     wload(0, 0);
-    for (int c = tid; c < T * NCH; c += 512) {
-        const int row = c / NCH, ch = c % NCH;
-        const u32x4 c0 = *reinterpret_cast<const u32x4*>(H1 + (int64_t)row * p.ld + ch * 8);
-        const u32x4 c1 = *reinterpret_cast<const u32x4*>(H1 + (int64_t)row * p.ld + CW + ch * 8);
-        *reinterpret_cast<u32x4*>(H2 + (int64_t)row * p.ld + ch * 8) = c0;
-        *reinterpret_cast<u32x4*>(U + row * ROWB + ((ch ^ CF::swz(row)) << 4)) = c1;
+    {   // (loads of several row chunks in flight per thread, like the row passes below)
+        constexpr int RSTEP = 512 / NCH, RB0 = 4;
+        const int row0 = tid / NCH, ch0 = tid % NCH;
+        const uint32_t goff0 = ((uint32_t)row0 * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u;
+        const uint32_t gstep = (uint32_t)RSTEP * (uint32_t)p.ld * 2u;
+        const char* h1b = reinterpret_cast<const char*>(H1);
+        char* h2b = reinterpret_cast<char*>(H2);
+        for (int it0 = 0; it0 * RSTEP < T; it0 += RB0) {
+            u32x4 c0[RB0], c1[RB0];
+#pragma unroll
+            for (int k = 0; k < RB0; ++k)
+                if (row0 + (it0 + k) * RSTEP < T) {
+                    c0[k] = *reinterpret_cast<const u32x4*>(h1b + goff0 + (uint32_t)(it0 + k) * gstep);
+                    c1[k] = *reinterpret_cast<const u32x4*>(h1b + CW * 2 + goff0 + (uint32_t)(it0 + k) * gstep);
+                }
+#pragma unroll
+            for (int k = 0; k < RB0; ++k) {
+                const int row = row0 + (it0 + k) * RSTEP;
+                if (row < T) {
+                    *reinterpret_cast<u32x4*>(h2b + goff0 + (uint32_t)(it0 + k) * gstep) = c0[k];
+                    *reinterpret_cast<u32x4*>(U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4)) = c1[k];
+                }
+            }
+        }
     }
     wstore();
     __syncthreads();
@@ -152,17 +170,54 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
         __syncthreads();
 
         // ---- y_s -> H2 (whole rows), U <- y_s + c_{s+1} -------------------------------------------------
-        for (int c = tid; c < T * NCH; c += 512) {
-            const int row = c / NCH, ch = c % NCH;
-            char* up = U + row * ROWB + ((ch ^ CF::swz(row)) << 4);
-            const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
-            if (!(R2DBG && (p.debug & 1))) *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
-            if (s < 7 && !(R2DBG && (p.debug & 1))) {
-                const bf16x8 cn = *reinterpret_cast<const bf16x8*>(H1 + (int64_t)row * p.ld + (s + 1) * CW + ch * 8);
-                bf16x8 u;
+        // seven row chunks per thread at a time: their c_{s+1} loads are all in flight before the first is consumed (one
+        // chunk per trip exposed a full HBM round trip per trip: ~0.8 us x 13 trips x 7 stages)
+        if (R2DBG && (p.debug & 32)) {
+            for (int c = tid; c < T * NCH; c += 512) {
+                const int row = c / NCH, ch = c % NCH;
+                char* up = U + row * ROWB + ((ch ^ CF::swz(row)) << 4);
+                const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
+                *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
+                if (s < 7) {
+                    const bf16x8 cn = *reinterpret_cast<const bf16x8*>(H1 + (int64_t)row * p.ld + (s + 1) * CW + ch * 8);
+                    bf16x8 u;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cn[e]));
-                *reinterpret_cast<bf16x8*>(up) = u;
+                    for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cn[e]));
+                    *reinterpret_cast<bf16x8*>(up) = u;
+                }
+            }
+        } else {
+            constexpr int RSTEP = 512 / NCH;                        // rows per trip of the whole workgroup (32 / 64)
+            constexpr int RB = 7;                                   // row chunks per thread in flight
+            const int row0 = tid / NCH, ch0 = tid % NCH;
+            const uint32_t goff0 = ((uint32_t)row0 * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u;
+            const uint32_t gstep = (uint32_t)RSTEP * (uint32_t)p.ld * 2u;
+            const char* h1s = reinterpret_cast<const char*>(H1) + (s + 1) * CW * 2;
+            char* h2s = reinterpret_cast<char*>(H2) + s * CW * 2;
+            const bool noglob = R2DBG && (p.debug & 1);
+            for (int it0 = 0; it0 * RSTEP < T; it0 += RB) {
+                u32x4 cn[RB];
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int row = row0 + (it0 + k) * RSTEP;
+                    if (s < 7 && row < T && !noglob) cn[k] = *reinterpret_cast<const u32x4*>(h1s + goff0 + (uint32_t)(it0 + k) * gstep);
+                }
+#pragma unroll
+                for (int k = 0; k < RB; ++k) {
+                    const int row = row0 + (it0 + k) * RSTEP;
+                    if (row < T) {
+                        char* up = U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4);
+                        const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
+                        if (!noglob) *reinterpret_cast<bf16x8*>(h2s + goff0 + (uint32_t)(it0 + k) * gstep) = y;
+                        if (s < 7 && !noglob) {
+                            const bf16x8 cv = __builtin_bit_cast(bf16x8, cn[k]);
+                            bf16x8 u;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cv[e]));
+                            *reinterpret_cast<bf16x8*>(up) = u;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
