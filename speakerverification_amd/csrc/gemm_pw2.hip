@@ -418,16 +418,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     constexpr int ORB = QBN * 2;                    // 512-byte output rows
     constexpr int NGRP = M16 ? 4 : 8;               // channel groups per wave (64 channels / 16 or / 8 per group pair)
     constexpr int NROW = M16 ? 8 : 4;               // frame blocks per wave
+    // the per-channel epilogue constants of every channel group are requested up front: the fragment registers are dead here,
+    // and loading them group by group exposed one L2 round trip per group (four per tile)
+    f32x4 b4a[NGRP], sc4a[NGRP], sh4a[NGRP];
+#pragma unroll
+    for (int cg = 0; cg < NGRP; ++cg) {
+        const int n = n0 + (M16 ? (wn * 64 + cg * 16 + 4 * q4) : (wn * 64 + (cg >> 2) * 32 + 8 * (cg & 3) + 4 * fh));
+        b4a[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; sc4a[cg] = f32x4{1.f, 1.f, 1.f, 1.f}; sh4a[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+            if (PH4 == 0 && p.bias) b4a[cg] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.scale) { sc4a[cg] = *reinterpret_cast<const f32x4*>(p.scale + n); sh4a[cg] = *reinterpret_cast<const f32x4*>(p.shift + n); }
+        }
+    }
 #pragma unroll
     for (int cg = 0; cg < NGRP; ++cg) {
         const int nl = M16 ? (wn * 64 + cg * 16 + 4 * q4) : (wn * 64 + (cg >> 2) * 32 + 8 * (cg & 3) + 4 * fh);
-        const int n = n0 + nl;
-        const bool nok = n < p.N;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-        if (nok) {
-            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.scale) { sc4 = *reinterpret_cast<const f32x4*>(p.scale + n); sh4 = *reinterpret_cast<const f32x4*>(p.shift + n); }
-        }
+        const f32x4 b4 = b4a[cg], sc4 = sc4a[cg], sh4 = sh4a[cg];
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
             const int ml = M16 ? (wm * 128 + i * 16 + r16) : (wm * 128 + i * 32 + fr);
