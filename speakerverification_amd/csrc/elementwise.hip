@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = 0.0f;
     const int K4 = K >> 2;                                   // float4 chunks along K
-    for (int c = wave * 64 + lane; c < K4; c += 256) {
+#pragma unroll 2
+    for (int c = wave * 64 + lane; c < K4; c += 256) {        // two trips' 32 loads in flight
         f32x4 wv[8], xv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
