@@ -58,17 +58,14 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
 }
 
 constexpr int SINC_PT = 64;                 // pooled frames per iteration
-constexpr int SINC_POS = 3 * SINC_PT;       // conv positions per iteration
-constexpr int SINC_SAMPLES = 464;           // >= SINC_POS + 255 + 8, multiple of 8
+constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 255 + 8, multiple of 8
 
 template <typename T> struct SincCfg;
 template <> struct SincCfg<bf16_t> {
-    static constexpr int KSTEPS = 16;                       // K = 256 (251 taps zero padded) in steps of 16
     static constexpr int COPY_BYTES = SINC_SAMPLES * 2 + 32;   // +32: successive copies start 2 bank-slots apart
     static constexpr int LDS = 8 * COPY_BYTES;
 };
 template <> struct SincCfg<float> {
-    static constexpr int KSTEPS = 126;                      // K = 252 in steps of 2
     static constexpr int LDS = SINC_SAMPLES * 4;
 };
 

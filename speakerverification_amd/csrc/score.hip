@@ -329,7 +329,8 @@ hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int to
     const size_t lds = row_bytes * rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipLaunchKernelGGL(topk_stats_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), lds, stream, S, rows, K, ld, Kp, top, rpw, mu, sigma);
