@@ -172,27 +172,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         constexpr int HT = 16384;
         const char* src[4][2];
         int dsto[2];
+        int cbase[2][2] = {{0, 0}, {0, 0}}, cfrm[2][2] = {{0, 0}, {0, 0}}, cchk[2] = {0, 0};   // CONV: utterance base row, frame, chunk of the X rows
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((rho >> 1) & 7);
             dsto[jj] = (wave * 2 + jj) * 1024;
+            cchk[jj] = c;
 #pragma unroll
             for (int ty = 0; ty < 4; ++ty) {
                 if (ty < 2) {
                     const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
                     src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + c * 8) * 2;
+                    if (CONV) { const int b = m / p.T; cbase[ty][jj] = b * p.T; cfrm[ty][jj] = m - b * p.T; }
                 } else {
                     const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
                     src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
                 }
             }
         }
+        // CONV: the X half-tiles are the im2col view of a dilated 1-D convolution — chunk c of K tile kt is k = kt*64 + 8c ..:
+        // tap k / cin of frame t + (tap - taps/2) * dil (reflect or zero padded, chunks past K read the zero page)
         auto issue = [&](int ty, int kt) {
             char* base = smem + ((kt & 1) * 4 + ty) * HT;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(src[ty][jj] + (int64_t)kt * 128), (lds_void*)(base + dsto[jj]), 16, 0, 0);
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* s = src[ty][jj] + (int64_t)kt * 128;
+                if (CONV && ty < 2) {
+                    const int k = kt * 64 + cchk[jj] * 8;
+                    const int tap = k / p.cin;
+                    int tt = cfrm[ty][jj] + (tap - (p.taps >> 1)) * p.dil;
+                    bool ok = k < p.K;
+                    if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
+                    else ok = ok && tt >= 0 && tt < p.T;
+                    s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cbase[ty][jj] + tt) * p.lda + (k - tap * p.cin)) * 2
+                           : reinterpret_cast<const char*>(p.zero_page);
+                }
+                __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
+            }
         };
         auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
             if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -558,6 +575,15 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     const bool m16 = !(p.debug & 64);               // 16x16x32 by default (holds a higher clock on real data); 64 = A/B switch for tools/gemm_bench
     if (p.taps > 1) {
+        if (!(p.debug & 512)) {
+            switch (p.act1) {
+                case ACT_NONE: return launch_inst<EPI_NONE, true, true, 1>(p, stream);
+                case ACT_RELU: return launch_inst<EPI_RELU, true, true, 1>(p, stream);
+                case ACT_GELU: return launch_inst<EPI_GELU, true, true, 1>(p, stream);
+                case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, true, 1>(p, stream);
+                default: return hipErrorInvalidValue;
+            }
+        }
         switch (p.act1) {
             case ACT_NONE: return launch_inst<EPI_NONE, true, true>(p, stream);
             case ACT_RELU: return launch_inst<EPI_RELU, true, true>(p, stream);

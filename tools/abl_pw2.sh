@@ -1,1 +1,1 @@
-timeout -k 10 120 tools/gemm_bench 1 256 0,8192 1 3 | grep -E "tdnn  N1024 K1024 gelu|mfa"
+timeout -k 10 120 tools/gemm_bench 1 256 0,512 1 3 | grep -E "blk0"
