@@ -1,28 +1,24 @@
-// gemm_pw2.hip — bf16 pointwise-conv GEMM, 256 x 256 tile, role-staggered wave groups (gfx950).
+// gemm_pw2.hip — bf16 pointwise / dilated-conv GEMM, 256 x 256 tile, role-staggered wave groups (gfx950).
 //
-// Same contract as gemm_pw.hip (Y = epi(A . W^T), bf16 in / fp32 accumulate / bf16 out), built for
-// the big layers (tdnn1/tdnn2, mfa).  What is different:
+// Same contract as gemm_pw.hip (Y = epi(A . W^T), bf16 in / fp32 accumulate / bf16 out), built for the big layers
+// (blocks.0, tdnn1 / tdnn2, mfa).  Structure:
 //
-//   * K advances in HALF-steps of 32 (64 bytes per row).  The LDS holds a ring of 4 half-stages
-//     (A 16 KiB + W 16 KiB each, 128 KiB in all), filled by global_load_lds_dwordx4 three half-steps
-//     ahead of use.
-//   * the 8 waves form two groups (waves 0-3 = rows 0..127 of the tile, waves 4-7 = rows 128..255;
-//     one wave of each group per SIMD) that run the same program ONE PHASE APART:
-//         phase L(h): ds_read the 12 fragments of half-step h, issue this wave's 4 DMAs for h+3
-//         phase C(h): 16 MFMAs (32x32x16) on those fragments
-//     separated by raw s_barriers.  While one group is in L the other is in C, so on every SIMD the
-//     matrix pipe is fed by one wave while its partner pays the LDS-read / DMA-issue latency, instead
-//     of both waves stalling together (measured on the un-staggered kernel: MFMA, ds_read and DMA
-//     issue time added up instead of overlapping).
-//   * DMA completion is tracked with counted s_waitcnt vmcnt(8/4/0) placed BEFORE the barrier that
-//     precedes the first reader (LDS-DMA data is ordered for a ds_read only by the issuing wave's
-//     vmcnt followed by a barrier the reader has passed); a ring slot is refilled only after the
-//     barrier that follows its last reader.
-//   * conflict-free LDS: 64-byte rows, 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3);
-//     the DMA writes LDS lane-linear, so the XOR is applied to the per-lane SOURCE address.
-//   * epilogue identical to gemm_pw.hip: weights are the MFMA A operand, so each lane owns 4
-//     consecutive channels per register group; bias/act/BN, pack to bf16, swizzled LDS image of the
-//     256 x 256 tile, whole 512-byte rows out in 16-byte stores.
+//   * 512 threads = 8 waves, 2 (M) x 4 (N), 128 frames x 64 channels per wave, v_mfma_f32_16x16x32_bf16 with the weights as
+//     the MFMA A operand, so a lane owns 4 consecutive channels of one frame (packed 8-byte epilogue).
+//   * K advances in 64-wide K tiles of FOUR PHASES, one accumulator quadrant (64 frames x 32 channels, 16 MFMAs) per phase.
+//     LDS holds 2 K tiles x {X-lo, X-hi, W-lo, W-hi} half-tiles of 128 rows x 128 bytes (128 KiB), filled by
+//     global_load_lds_dwordx4 six phases ahead of use: every DMA instruction moves whole 128-byte lines.
+//   * the two wave groups (waves 0-3 = frames 0..127 of the tile, waves 4-7 = 128..255; one wave of each per SIMD) run the same
+//     program ONE PHASE APART: while one group reads its fragments and issues its DMAs, the other feeds the matrix pipe.
+//   * DMA completion is tracked with ONE counted s_waitcnt vmcnt per phase, placed before the raw s_barrier that precedes the
+//     first reader; a buffer is restaged two phases after its last reader (details at the loop).
+//   * conflict-free LDS: 16-byte chunk c of row rho lives at chunk c ^ ((rho >> 1) & 7); the DMA writes LDS lane-linear, so the
+//     XOR is applied to the per-lane SOURCE chunk.
+//   * CONV: the X operand is the im2col view of a dilated 1-D convolution — only the per-lane DMA source address changes.
+//   * epilogue: (bias is the accumulators' start value) act / BN affine, pack to bf16, swizzled LDS image of the 256 x 256
+//     tile, optional per-utterance column sums straight from that image, whole 512-byte rows out in 16-byte stores.
+// History of this file (git): a 32-wide K ring with half-line DMAs (-13 %), a v_mfma_f32_32x32x16 variant (-8..12 % on random
+// data: lower sustained clock), a persistent variant and a two-phase variant (both +-0) were measured and removed.
 #include "common.h"
 #include "kernels.h"
 
@@ -34,24 +30,16 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr int QBM = 256, QBN = 256;
-constexpr int HROWB = 64;                       // bytes per row per half-step (32 bf16)
-constexpr int HA = QBM * HROWB;                 // 16 KiB
-constexpr int HSTAGE = HA + QBN * HROWB;        // 32 KiB
-constexpr int NRING = 4;
-constexpr int PW2_LDS = NRING * HSTAGE;         // 128 KiB (also holds the 256 x 256 bf16 output tile)
+constexpr int HT = 16384;                       // one half-tile: 128 rows x 64 k bf16
+constexpr int PW2_LDS = 8 * HT;                 // 128 KiB (also holds the 256 x 256 bf16 output tile)
 constexpr int QGROUP_M = 12;
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
 #ifdef SVHIP_GEMM_DEBUG
-constexpr bool DBG2 = true;      // tools/gemm_bench ablations (GemmParams::debug: 1 no DMA, 2 no MFMA, 16 no fragment reads, 32 no loop barriers)
+constexpr bool DBG2 = true;      // tools/gemm_bench (GemmParams::debug): 1024 / 2048 M-tile groups of 16 / 8, 16384 stage timestamps
 #else
 constexpr bool DBG2 = false;
 #endif
-
-// chunk swizzle key of a row: conflict-free for the 32x32x16 fragment pattern ((row >> 2) & 3) and for the
-// 16x16x32 pattern (its 16-lane ds_read_b128 groups mix chunks c and c+1 of rows {a, a+12} / {a+4, a+8}: key -x & 3)
-template <bool M16> __device__ __forceinline__ int hkey(int row) { return M16 ? ((0 - (row >> 2)) & 3) : ((row >> 2) & 3); }
-template <bool M16> __device__ __forceinline__ int hswz(int row, int chunk) { return row * HROWB + ((chunk ^ hkey<M16>(row)) << 4); }
 
 // GELU for the bf16 path: x * sigmoid(x * (c0 + c1 s + c2 s^2)), s = min(x^2, 52) (the polynomial peaks at s = 52.6, so the
 // clamp keeps it monotone); coefficients are a minimax fit to 0.5 x (1 + erf(x / sqrt 2)) over [-8, 8]: |err| <= 2.6e-5 absolute,
@@ -74,14 +62,13 @@ __device__ __forceinline__ f32x2_t gelu_pair(f32x2_t x) {
     return x * r;
 }
 
-// HASB = false: the bias is already in the accumulator (the four-phase loop starts its accumulators at the bias)
-template <int EPI, bool HASB = true>
-__device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4& b4, const f32x4& sc4, const f32x4& sh4) {
+// (the accumulators start at the bias, so the activation sees the biased value directly)
+template <int EPI>
+__device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4& sc4, const f32x4& sh4) {
     if (EPI == EPI_GELU) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x2_t x = {a[2 * h], a[2 * h + 1]};
-            if (HASB) x += f32x2_t{b4[2 * h], b4[2 * h + 1]};
+            const f32x2_t x = {a[2 * h], a[2 * h + 1]};
             const f32x2_t g = gelu_pair(x);
             const f32x2_t sc = {sc4[2 * h], sc4[2 * h + 1]}, sh = {sh4[2 * h], sh4[2 * h + 1]};
             const f32x2_t y = g * sc + sh;
@@ -90,7 +77,7 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float t = HASB ? a[e] + b4[e] : a[e];
+            float t = a[e];
             if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
             if (EPI == EPI_LRELU03) t = t > 0.0f ? t : 0.3f * t;
             v[e] = fmaf(t, sc4[e], sh4[e]);
@@ -98,13 +85,7 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
     }
 }
 
-// CONV = true: the A operand is the im2col view of a dilated 1-D convolution (k = tap*cin + c reads frame
-// t + (tap - taps/2)*dil of the same utterance, reflect or zero padded; chunks with k >= K read a zero page):
-// only the per-lane DMA source address changes, the rest of the kernel is identical.
-// PH4 = true (needs M16, !CONV): the K loop runs in 64-wide K tiles of four phases, one accumulator quadrant (64 frames x 32
-// channels, 16 MFMAs) per phase; LDS holds 2 K tiles x {X-lo, X-hi, W-lo, W-hi} half-tiles of 128 rows x 128 bytes, so every
-// global_load_lds instruction moves whole 128-byte lines (the 32-wide ring moves half lines).  See the block comment at the loop.
-template <int EPI, bool M16, bool CONV, int PH4>
+template <int EPI, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -128,338 +109,199 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
+    const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};  // tools/gemm_bench (debug bit 16384): s_memtime at the stage boundaries
 #define PW2_STAMP(i) if (DBG2 && (p.debug & 16384) && p.R) ts[i] = __builtin_readcyclecounter();
     PW2_STAMP(0)
 
-    // accumulators: 32x32x16 -> acc32[4][2] (f32x16), 16x16x32 -> acc16[8][4] (f32x4); 128 registers either way
-    f32x16 acc32[M16 ? 1 : 4][M16 ? 1 : 2];
-    f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
-    if (M16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
-            if (PH4 && p.bias) {                       // acc16[i][j][e] is channel n0 + wn*64 + j*16 + 4*(lane>>4) + e of frame i*16 + (lane&15)
-                const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-                if (n < p.N) b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc16[M16 ? i : 0][M16 ? j : 0] = b0;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[M16 ? 0 : i][M16 ? 0 : j][r] = 0.0f;
-    }
-
-
-    const int fr = lane & 31, fh = lane >> 5;       // 32x32x16 fragment coordinates
-    const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
-    if constexpr (PH4) {
-        // ---- four-phase K tiles ---------------------------------------------------------------------------------------
-        // Half-tile types: 0 X-lo (frames wm*128 + 0..63 of both wave rows), 1 X-hi (+64..127), 2 W-lo (channels wn*64 + 0..31
-        // of the four wave columns), 3 W-hi (+32..63); each 128 rows x 64 k = 16 KiB, two buffers (K-tile parity) per type.
-        // Row rho of a half-tile lives at rho*128 + ((chunk ^ ((rho >> 1) & 7)) << 4): conflict-free for the ds_read_b128
-        // lane groups of the 16x16x32 fragment pattern, and the DMA (lane-linear in LDS) applies it on the source chunk.
-        // Phase g = 4k + ph reads (L) then multiplies (C):  ph 0: X-lo(k) -> quadrant (lo, W-lo)   ph 1: W-hi(k) -> (lo, hi)
-        //                                                    ph 2: X-hi(k) -> (hi, W-hi)          ph 3: W-lo(k+1) -> (hi, W-lo(k))
-        // so each half-tile is read in exactly one phase, and phase g restages the buffer read in phase g-2 with the
-        // half-tile needed in phase g+6 (issue order == need order; W-lo(0) first).  A wave waits (counted vmcnt) in phase g
-        // for what phase g+1 reads; the two wave groups run one phase apart.
-        constexpr int HT = 16384;
-        const char* src[4][2];
-        int dsto[2];
-        int cbase[2][2] = {{0, 0}, {0, 0}}, cfrm[2][2] = {{0, 0}, {0, 0}}, cchk[2] = {0, 0};   // CONV: utterance base row, frame, chunk of the X rows
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((rho >> 1) & 7);
-            dsto[jj] = (wave * 2 + jj) * 1024;
-            cchk[jj] = c;
-#pragma unroll
-            for (int ty = 0; ty < 4; ++ty) {
-                if (ty < 2) {
-                    const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
-                    src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + c * 8) * 2;
-                    if (CONV) { const int b = m / p.T; cbase[ty][jj] = b * p.T; cfrm[ty][jj] = m - b * p.T; }
-                } else {
-                    const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
-                    src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
-                }
-            }
-        }
-        // CONV: the X half-tiles are the im2col view of a dilated 1-D convolution — chunk c of K tile kt is k = kt*64 + 8c ..:
-        // tap k / cin of frame t + (tap - taps/2) * dil (reflect or zero padded, chunks past K read the zero page)
-        auto issue = [&](int ty, int kt) {
-            char* base = smem + ((kt & 1) * 4 + ty) * HT;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const char* s = src[ty][jj] + (int64_t)kt * 128;
-                if (CONV && ty < 2) {
-                    const int k = kt * 64 + cchk[jj] * 8;
-                    const int tap = k / p.cin;
-                    int tt = cfrm[ty][jj] + (tap - (p.taps >> 1)) * p.dil;
-                    bool ok = k < p.K;
-                    if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
-                    else ok = ok && tt >= 0 && tt < p.T;
-                    s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cbase[ty][jj] + tt) * p.lda + (k - tap * p.cin)) * 2
-                           : reinterpret_cast<const char*>(p.zero_page);
-                }
-                __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
-            }
-        };
-        auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
-            if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        const int nkt = p.Kp / 64;
-        const int total = 4 * nkt;                    // half-tiles of this tile's K loop
-        issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
-        if (nkt > 1) { issue(2, 1); issue(0, 1); issue(3, 1); }
-        wait_left(min(7, total) - 2);
-        __builtin_amdgcn_s_barrier();                 // W-lo(0), X-lo(0) of every wave have landed
-        PW2_STAMP(1)
-        if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
-
-        const int xoff = (wm * 64 + r16) * 128, woff = (wn * 32 + r16) * 128;
-        const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 32 + r16) >> 1) & 7;     // rho + 16 i keeps bits 1..3 of rho
-        bf16x8 xf[4][2], wlo[2][2], whi[2][2], wnx[2][2];
-        {   // W-lo(0)
-            const char* b = smem + 2 * HT;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = *reinterpret_cast<const bf16x8*>(b + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4));
-        }
-#define PW2_PHASE_END(gidx)                                                                         \
-        if (steady) {                                                                                   \
-            constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
-            const int kk_ = kt + (((gidx) + 6) >> 2);                                                   \
-            if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
-            __builtin_amdgcn_s_barrier();                                                               \
-        } else {                                                                                        \
-            const int g_ = 4 * kt + (gidx);                                                             \
-            if (7 + g_ < total) {                                                                       \
-                const int need = g_ + 6, kk = need >> 2, pp = need & 3;                                 \
-                if (pp == 0) issue(0, kk); else if (pp == 1) issue(3, kk); else if (pp == 2) issue(1, kk); else issue(2, kk + 1); \
-            }                                                                                           \
-            wait_left(min(8 + g_, total) - (g_ + 3));                                                   \
-            __builtin_amdgcn_s_barrier();                                                               \
-        }
-#define PW2_MFMA(I0, WARR, J0)                                                                      \
-        __builtin_amdgcn_s_setprio(1);                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                    acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[M16 ? (I0) + i : 0][M16 ? (J0) + j : 0], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                  \
-        __builtin_amdgcn_s_barrier();
-#define PW2_KTILE(steady_, KT_, WCUR, WNXT)                                                         \
-        {                                                                                               \
-            constexpr bool steady = (steady_);                                                          \
-            const int kt = (KT_);                                                                       \
-            const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
-            /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                    xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
-            PW2_PHASE_END(0)                                                                            \
-            PW2_MFMA(0, WCUR, 0)                                                                        \
-            /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                    whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
-            PW2_PHASE_END(1)                                                                            \
-            PW2_MFMA(0, whi, 2)                                                                         \
-            /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                    xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
-            PW2_PHASE_END(2)                                                                            \
-            PW2_MFMA(4, whi, 2)                                                                         \
-            /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
-            if (steady || kt + 1 < nkt) {                                                               \
-                const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
-                        WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
-            }                                                                                           \
-            PW2_PHASE_END(3)                                                                            \
-            PW2_MFMA(4, WCUR, 0)                                                                        \
-        }
-        int kt0 = 0;
-        for (; kt0 + 2 < nkt; ++kt0) {                  // steady state: every issue exists, five half-tiles stay in flight
-            PW2_KTILE(true, kt0, wlo, wnx)              // (two K tiles per trip with the W-lo sets swapping roles spills: slower)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
-        }
-        for (; kt0 < nkt; ++kt0) {                      // last two K tiles: issues run out, counted drain
-            PW2_KTILE(false, kt0, wlo, wnx)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
-        }
-#undef PW2_KTILE
-#undef PW2_PHASE_END
-#undef PW2_MFMA
-    } else {
-    // ---- DMA geometry: per half-step, wave w fills 16-row groups g = w, w + 8 of A and of W --------
-    const char* src[4];
-    int dst[4];
-    int cutt[2] = {0, 0}, ct[2] = {0, 0}, clc[2] = {0, 0};       // CONV: utterance base row, frame, logical chunk of the two A rows
+    // accumulators acc16[i][j][e] = channel n0 + wn*64 + j*16 + 4*q4 + e of frame m0 + wm*128 + i*16 + r16; they start at the bias
+    f32x4 acc16[8][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool isA = j < 2;
-        const int g = wave + 8 * (j & 1);
-        const int r = g * 16 + (lane >> 2);
-        const int lc = (lane & 3) ^ hkey<M16>(r);
-        if (isA) {
-            const int m = min(m0 + r, p.M - 1);
-            src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * 8) * 2;
-            dst[j] = g * 1024;
-            if (CONV) { const int b = m / p.T; cutt[j] = b * p.T; ct[j] = m - b * p.T; clc[j] = lc; }
-        } else {
-            const int n = min(n0 + r, p.Wrows - 1);
-            src[j] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + lc * 8) * 2;
-            dst[j] = HA + g * 1024;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * q4;
+            if (n < p.N) b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc16[i][j] = b0;
+    }
+
+    // ---- four-phase K tiles ---------------------------------------------------------------------------------------
+    // Half-tile types: 0 X-lo (frames wm*128 + 0..63 of both wave rows), 1 X-hi (+64..127), 2 W-lo (channels wn*64 + 0..31
+    // of the four wave columns), 3 W-hi (+32..63); each 128 rows x 64 k = 16 KiB, two buffers (K-tile parity) per type.
+    // Row rho of a half-tile lives at rho*128 + ((chunk ^ ((rho >> 1) & 7)) << 4): conflict-free for the ds_read_b128
+    // lane groups of the 16x16x32 fragment pattern, and the DMA (lane-linear in LDS) applies it on the source chunk.
+    // Phase g = 4k + ph reads (L) then multiplies (C):  ph 0: X-lo(k) -> quadrant (lo, W-lo)   ph 1: W-hi(k) -> (lo, hi)
+    //                                                    ph 2: X-hi(k) -> (hi, W-hi)          ph 3: W-lo(k+1) -> (hi, W-lo(k))
+    // so each half-tile is read in exactly one phase, and phase g restages the buffer read in phase g-2 with the
+    // half-tile needed in phase g+6 (issue order == need order; W-lo(0) first).  A wave waits (counted vmcnt) in phase g
+    // for what phase g+1 reads; the two wave groups run one phase apart.
+    const char* src[4][2];
+    int dsto[2];
+    int cbase[2][2] = {{0, 0}, {0, 0}}, cfrm[2][2] = {{0, 0}, {0, 0}}, cchk[2] = {0, 0};   // CONV: utterance base row, frame, chunk of the X rows
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((rho >> 1) & 7);
+        dsto[jj] = (wave * 2 + jj) * 1024;
+        cchk[jj] = c;
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            if (ty < 2) {
+                const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
+                src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + c * 8) * 2;
+                if (CONV) { const int b = m / p.T; cbase[ty][jj] = b * p.T; cfrm[ty][jj] = m - b * p.T; }
+            } else {
+                const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
+                src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
+            }
         }
     }
-    auto issue = [&](int h) {
-        char* base = smem + (h & (NRING - 1)) * HSTAGE;
+    // CONV: the X half-tiles are the im2col view of a dilated 1-D convolution — chunk c of K tile kt is k = kt*64 + 8c ..:
+    // tap k / cin of frame t + (tap - taps/2) * dil (reflect or zero padded, chunks past K read the zero page)
+    auto issue = [&](int ty, int kt) {
+        char* base = smem + ((kt & 1) * 4 + ty) * HT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const char* s = src[j] + (int64_t)((DBG2 && (p.debug & 4)) ? (h & 3) : h) * HROWB;
-            if (CONV && j < 2) {
-                const int k = h * 32 + clc[j] * 8;
+        for (int jj = 0; jj < 2; ++jj) {
+            const char* s = src[ty][jj] + (int64_t)kt * 128;
+            if (CONV && ty < 2) {
+                const int k = kt * 64 + cchk[jj] * 8;
                 const int tap = k / p.cin;
-                int tt = ct[j] + (tap - (p.taps >> 1)) * p.dil;
+                int tt = cfrm[ty][jj] + (tap - (p.taps >> 1)) * p.dil;
                 bool ok = k < p.K;
                 if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
                 else ok = ok && tt >= 0 && tt < p.T;
-                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cutt[j] + tt) * p.lda + (k - tap * p.cin)) * 2
+                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cbase[ty][jj] + tt) * p.lda + (k - tap * p.cin)) * 2
                        : reinterpret_cast<const char*>(p.zero_page);
             }
-            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dst[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
         }
     };
+    auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
+        if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int nkt = p.Kp / 64;
+    const int total = 4 * nkt;                    // half-tiles of this tile's K loop
+    issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
+    if (nkt > 1) { issue(2, 1); issue(0, 1); issue(3, 1); }
+    wait_left(min(7, total) - 2);
+    __builtin_amdgcn_s_barrier();                 // W-lo(0), X-lo(0) of every wave have landed
+    PW2_STAMP(1)
+    if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
 
-    const int nh = p.Kp / 32;                       // half-steps (host guarantees Kp % 64 == 0, so nh >= 2)
-    issue(0);
-    issue(1);
-    if (nh > 2) issue(2);
-    if (nh > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // half-step 0 of every wave has landed
-    if (wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one phase behind group 0
-
-    const int arow = wm * 128 + (M16 ? r16 : fr), wrow = wn * 64 + (M16 ? r16 : fr);
-    bf16x8 dbg_x[8], dbg_w[4];
-    if (DBG2) {
-        for (int i = 0; i < 8; ++i) dbg_x[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.A) + (lane + 64 * i) * 16);
-        for (int j = 0; j < 4; ++j) dbg_w[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.W) + (lane + 64 * j) * 16);
+    const int xoff = (wm * 64 + r16) * 128, woff = (wn * 32 + r16) * 128;
+    const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 32 + r16) >> 1) & 7;     // rho + 16 i keeps bits 1..3 of rho
+    bf16x8 xf[4][2], wlo[2][2], whi[2][2], wnx[2][2];
+    {   // W-lo(0)
+        const char* b = smem + 2 * HT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = *reinterpret_cast<const bf16x8*>(b + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4));
     }
-    for (int h = 0; h < nh; ++h) {
-        // ---------------- phase L(h): fragments of half-step h -> registers; DMA for h+3 ----------------
-        const char* As = smem + (h & (NRING - 1)) * HSTAGE;
-        const char* Ws = As + HA;
-        bf16x8 xf[8], wf[4];                         // 12 fragments (48 VGPRs) in both shapes
-        if (DBG2 && (p.debug & 16)) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xf[i] = dbg_x[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = dbg_w[j];
-        } else if (M16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(As + hswz<M16>(arow + i * 16, q4));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(Ws + hswz<M16>(wrow + j * 16, q4));
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xf[s * 4 + i] = *reinterpret_cast<const bf16x8*>(As + hswz<M16>(arow + i * 32, 2 * s + fh));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) wf[s * 2 + j] = *reinterpret_cast<const bf16x8*>(Ws + hswz<M16>(wrow + j * 32, 2 * s + fh));
-            }
-        }
-        if (DBG2 && (p.debug & 1)) {
-        } else if (h + 3 < nh) {
-            issue(h + 3);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // retires this wave's DMAs of half-step h+1
-        } else if (h + 2 < nh) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (!(DBG2 && (p.debug & 32))) __builtin_amdgcn_s_barrier();
-        // ---------------- phase C(h): 16 (32x32x16) or 32 (16x16x32) MFMAs -------------------------------
-        __builtin_amdgcn_s_setprio(1);
-        if (DBG2 && (p.debug & 2)) {
-        } else if (M16) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc16[M16 ? i : 0][M16 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc16[M16 ? i : 0][M16 ? j : 0], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc32[M16 ? 0 : i][M16 ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 2 + j], xf[s * 4 + i], acc32[M16 ? 0 : i][M16 ? 0 : j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (!(DBG2 && (p.debug & 32))) __builtin_amdgcn_s_barrier();
+#define PW2_PHASE_END(gidx)                                                                         \
+    if (steady) {                                                                                   \
+        constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
+        const int kk_ = kt + (((gidx) + 6) >> 2);                                                   \
+        if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                               \
+    } else {                                                                                        \
+        const int g_ = 4 * kt + (gidx);                                                             \
+        if (7 + g_ < total) {                                                                       \
+            const int need = g_ + 6, kk = need >> 2, pp = need & 3;                                 \
+            if (pp == 0) issue(0, kk); else if (pp == 1) issue(3, kk); else if (pp == 2) issue(1, kk); else issue(2, kk + 1); \
+        }                                                                                           \
+        wait_left(min(8 + g_, total) - (g_ + 3));                                                   \
+        __builtin_amdgcn_s_barrier();                                                               \
     }
+#define PW2_MFMA(I0, WARR, J0)                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                  \
+    __builtin_amdgcn_s_barrier();
+#define PW2_KTILE(steady_, KT_, WCUR, WNXT)                                                         \
+    {                                                                                               \
+        constexpr bool steady = (steady_);                                                          \
+        const int kt = (KT_);                                                                       \
+        const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
+        /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+        PW2_PHASE_END(0)                                                                            \
+        PW2_MFMA(0, WCUR, 0)                                                                        \
+        /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+        PW2_PHASE_END(1)                                                                            \
+        PW2_MFMA(0, whi, 2)                                                                         \
+        /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+        PW2_PHASE_END(2)                                                                            \
+        PW2_MFMA(4, whi, 2)                                                                         \
+        /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
+        if (steady || kt + 1 < nkt) {                                                               \
+            const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
+                    WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+        }                                                                                           \
+        PW2_PHASE_END(3)                                                                            \
+        PW2_MFMA(4, WCUR, 0)                                                                        \
     }
+    int kt0 = 0;
+    for (; kt0 + 2 < nkt; ++kt0) {                  // steady state: every issue exists, five half-tiles stay in flight
+        PW2_KTILE(true, kt0, wlo, wnx)              // (two K tiles per trip with the W-lo sets swapping roles spills: slower)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+    }
+    for (; kt0 < nkt; ++kt0) {                      // last two K tiles: issues run out, counted drain
+        PW2_KTILE(false, kt0, wlo, wnx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+    }
+#undef PW2_KTILE
+#undef PW2_PHASE_END
+#undef PW2_MFMA
     if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count
-    __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: reuse the ring
+    __builtin_amdgcn_s_barrier();                   // every wave is past its last LDS read: the ring becomes the output image
     PW2_STAMP(2)
 
-    // ---- epilogue: every lane owns 4 consecutive channels (n .. n+3) of one frame per accumulator group ----
-    //   32x32x16: acc32[i][j][4g+e] = (m = wm*128 + i*32 + fr,  n = wn*64 + j*32 + 8g + 4fh + e)
-    //   16x16x32: acc16[i][j][e]    = (m = wm*128 + i*16 + r16, n = wn*64 + j*16 + 4q4 + e)
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
     constexpr int ORB = QBN * 2;                    // 512-byte output rows
-    constexpr int NGRP = M16 ? 4 : 8;               // channel groups per wave (64 channels / 16 or / 8 per group pair)
-    constexpr int NROW = M16 ? 8 : 4;               // frame blocks per wave
-    // the per-channel epilogue constants of every channel group are requested up front: the fragment registers are dead here,
-    // and loading them group by group exposed one L2 round trip per group (four per tile)
-    f32x4 b4a[NGRP], sc4a[NGRP], sh4a[NGRP];
+    // the per-channel constants of every channel group are requested up front (the fragment registers are dead here)
+    f32x4 sc4a[4], sh4a[4];
 #pragma unroll
-    for (int cg = 0; cg < NGRP; ++cg) {
-        const int n = n0 + (M16 ? (wn * 64 + cg * 16 + 4 * q4) : (wn * 64 + (cg >> 2) * 32 + 8 * (cg & 3) + 4 * fh));
-        b4a[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; sc4a[cg] = f32x4{1.f, 1.f, 1.f, 1.f}; sh4a[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n < p.N) {
-            if (PH4 == 0 && p.bias) b4a[cg] = *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.scale) { sc4a[cg] = *reinterpret_cast<const f32x4*>(p.scale + n); sh4a[cg] = *reinterpret_cast<const f32x4*>(p.shift + n); }
-        }
+    for (int cg = 0; cg < 4; ++cg) {
+        const int n = n0 + wn * 64 + cg * 16 + 4 * q4;
+        sc4a[cg] = f32x4{1.f, 1.f, 1.f, 1.f}; sh4a[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < p.N && p.scale) { sc4a[cg] = *reinterpret_cast<const f32x4*>(p.scale + n); sh4a[cg] = *reinterpret_cast<const f32x4*>(p.shift + n); }
     }
 #pragma unroll
-    for (int cg = 0; cg < NGRP; ++cg) {
-        const int nl = M16 ? (wn * 64 + cg * 16 + 4 * q4) : (wn * 64 + (cg >> 2) * 32 + 8 * (cg & 3) + 4 * fh);
-        const f32x4 b4 = b4a[cg], sc4 = sc4a[cg], sh4 = sh4a[cg];
+    for (int cg = 0; cg < 4; ++cg) {
+        const int nl = wn * 64 + cg * 16 + 4 * q4;
 #pragma unroll
-        for (int i = 0; i < NROW; ++i) {
-            const int ml = M16 ? (wm * 128 + i * 16 + r16) : (wm * 128 + i * 32 + fr);
+        for (int i = 0; i < 8; ++i) {
+            const int ml = wm * 128 + i * 16 + r16;
             float v[4];
-            f32x4 a4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                a4[e] = M16 ? acc16[M16 ? i : 0][M16 ? cg : 0][e] : acc32[M16 ? 0 : i][M16 ? 0 : (cg >> 2)][4 * (cg & 3) + e];
-            act4<EPI, PH4 == 0>(v, a4, b4, sc4, sh4);
+            act4<EPI>(v, acc16[i][cg], sc4a[cg], sh4a[cg]);
             typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
@@ -539,17 +381,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #undef PW2_STAMP
 }
 
-template <int EPI, bool M16, bool CONV, int PH4 = 0>
+template <int EPI, bool CONV>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, M16, CONV, PH4>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, M16, CONV, PH4>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, CONV>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -573,39 +415,12 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
 
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
-    const bool m16 = !(p.debug & 64);               // 16x16x32 by default (holds a higher clock on real data); 64 = A/B switch for tools/gemm_bench
-    if (p.taps > 1) {
-        if (!(p.debug & 512)) {
-            switch (p.act1) {
-                case ACT_NONE: return launch_inst<EPI_NONE, true, true, 1>(p, stream);
-                case ACT_RELU: return launch_inst<EPI_RELU, true, true, 1>(p, stream);
-                case ACT_GELU: return launch_inst<EPI_GELU, true, true, 1>(p, stream);
-                case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, true, 1>(p, stream);
-                default: return hipErrorInvalidValue;
-            }
-        }
-        switch (p.act1) {
-            case ACT_NONE: return launch_inst<EPI_NONE, true, true>(p, stream);
-            case ACT_RELU: return launch_inst<EPI_RELU, true, true>(p, stream);
-            case ACT_GELU: return launch_inst<EPI_GELU, true, true>(p, stream);
-            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, true>(p, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (m16 && !(p.debug & 512)) {                  // four-phase K tiles (default); 512 = A/B switch back to the 32-wide ring
-        switch (p.act1) {
-            case ACT_NONE: return launch_inst<EPI_NONE, true, false, 1>(p, stream);
-            case ACT_RELU: return launch_inst<EPI_RELU, true, false, 1>(p, stream);
-            case ACT_GELU: return launch_inst<EPI_GELU, true, false, 1>(p, stream);
-            case ACT_LRELU03: return launch_inst<EPI_LRELU03, true, false, 1>(p, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
+    const bool conv = p.taps > 1;
     switch (p.act1) {
-        case ACT_NONE: return m16 ? launch_inst<EPI_NONE, true, false>(p, stream) : launch_inst<EPI_NONE, false, false>(p, stream);
-        case ACT_RELU: return m16 ? launch_inst<EPI_RELU, true, false>(p, stream) : launch_inst<EPI_RELU, false, false>(p, stream);
-        case ACT_GELU: return m16 ? launch_inst<EPI_GELU, true, false>(p, stream) : launch_inst<EPI_GELU, false, false>(p, stream);
-        case ACT_LRELU03: return m16 ? launch_inst<EPI_LRELU03, true, false>(p, stream) : launch_inst<EPI_LRELU03, false, false>(p, stream);
+        case ACT_NONE: return conv ? launch_inst<EPI_NONE, true>(p, stream) : launch_inst<EPI_NONE, false>(p, stream);
+        case ACT_RELU: return conv ? launch_inst<EPI_RELU, true>(p, stream) : launch_inst<EPI_RELU, false>(p, stream);
+        case ACT_GELU: return conv ? launch_inst<EPI_GELU, true>(p, stream) : launch_inst<EPI_GELU, false>(p, stream);
+        case ACT_LRELU03: return conv ? launch_inst<EPI_LRELU03, true>(p, stream) : launch_inst<EPI_LRELU03, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
