@@ -34,7 +34,7 @@ constexpr int HT = 16384;                       // one half-tile: 128 rows x 64 
 constexpr int PW2_LDS = 8 * HT;                 // 128 KiB (also holds the 256 x 256 bf16 output tile)
 constexpr int QGROUP_M = 12;
 
-enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4 };
+enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4, EPI_BN_LRELU03 = 5 };   // 5: affine first, then LeakyReLU(0.3)
 #ifdef SVHIP_GEMM_DEBUG
 constexpr bool DBG2 = true;      // tools/gemm_bench (GemmParams::debug): 1024 / 2048 M-tile groups of 16 / 8, 16384 stage timestamps
 #else
@@ -80,7 +80,9 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
             float t = a[e];
             if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
             if (EPI == EPI_LRELU03) t = t > 0.0f ? t : 0.3f * t;
-            v[e] = fmaf(t, sc4[e], sh4[e]);
+            t = fmaf(t, sc4[e], sh4[e]);
+            if (EPI == EPI_BN_LRELU03) t = t > 0.0f ? t : 0.3f * t;      // RawNet2: conv -> bn2 -> lrelu (act1 none, act2 lrelu)
+            v[e] = t;
         }
     }
 }
@@ -398,7 +400,8 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
-    if (!bf16 || p.out_f32 || p.bias_utt || p.act2 != ACT_NONE || p.A2 || (p.R && !(DBG2 && (p.debug & 16384)))) return false;
+    if (!bf16 || p.out_f32 || p.bias_utt || p.A2 || (p.R && !(DBG2 && (p.debug & 16384)))) return false;
+    if (p.act2 != ACT_NONE && !(p.act2 == ACT_LRELU03 && p.act1 == ACT_NONE)) return false;
     if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;      // at most one utterance boundary per 256-row tile
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
     if (p.N < 256 || p.Kp % 64 != 0 || p.N % 8 != 0 || p.lda % 8 != 0 || p.ldy % 8 != 0) return false;
@@ -416,6 +419,7 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     const bool conv = p.taps > 1;
+    if (p.act2 == ACT_LRELU03) return conv ? launch_inst<EPI_BN_LRELU03, true>(p, stream) : launch_inst<EPI_BN_LRELU03, false>(p, stream);
     switch (p.act1) {
         case ACT_NONE: return conv ? launch_inst<EPI_NONE, true>(p, stream) : launch_inst<EPI_NONE, false>(p, stream);
         case ACT_RELU: return conv ? launch_inst<EPI_RELU, true>(p, stream) : launch_inst<EPI_RELU, false>(p, stream);
