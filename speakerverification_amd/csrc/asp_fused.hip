@@ -70,21 +70,19 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
     // 32 rows x 64 B = two wave-instructions per slab
     const int nslab = npass * AF_MT;
     int is_pass = 0, is_mt = 0, is_slot = 0;          // next slab to issue
-    // lane part of the source address (row inside the tile, 16-byte piece) as 32-bit byte offsets: [q] for full tiles,
-    // [2 + q] for the last tile, whose rows are clamped to the last frame
-    uint32_t xoff[4];
+    // lane part of the source address (row inside the tile, 16-byte piece) as 32-bit byte offsets for tiles that lie inside
+    // the utterance; a tile that reaches past frame T-1 (the last one at T = 401, several for short utterances) clamps its
+    // rows to the last frame and computes them on the spot
+    uint32_t xoff[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = q * 16 + (lane >> 2);
-        xoff[q] = ((uint32_t)row * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
-        xoff[2 + q] = ((uint32_t)(min((AF_MT - 1) * 32 + row, T - 1) - (AF_MT - 1) * 32) * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
-    }
+    for (int q = 0; q < 2; ++q) xoff[q] = ((uint32_t)(q * 16 + (lane >> 2)) * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
     auto issue_next = [&]() {
-        const char* gb = reinterpret_cast<const char*>(X) + ((int64_t)is_mt * 32 * p.ldx + is_pass * 128 + wave * 32) * 2;    // uniform
-        const bool last = (is_mt + 1) * 32 > T;
+        const bool tail = (is_mt + 1) * 32 > T;                                                         // uniform
+        const char* gb = reinterpret_cast<const char*>(X) + ((int64_t)(tail ? 0 : is_mt * 32) * p.ldx + is_pass * 128 + wave * 32) * 2;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            uint32_t o = last ? xoff[2 + q] : xoff[q];
+            uint32_t o = xoff[q];
+            if (tail) o = ((uint32_t)min(is_mt * 32 + q * 16 + (lane >> 2), T - 1) * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
             asm volatile("" : "+v"(o));
             __builtin_amdgcn_global_load_lds((gbl_void*)(gb + o), (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, 0);
         }

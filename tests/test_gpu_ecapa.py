@@ -123,3 +123,22 @@ def test_input_norm_and_raw_feature_variants(golden_dir, tag, features):
     ref = g["out_" + tag]
     assert out.shape == ref.shape
     assert float(np.abs(out - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("L", [16000, 24000, 40000])
+def test_bf16_other_utterance_lengths(L):
+    """Geometries off the 2 s default take other kernel paths (attention tail with several clamped frame tiles at T = 201,
+    the un-fused Res2Net / pooling fallbacks past T = 416): the bf16 path must track the fp32 path on all of them."""
+    C, B = 512, 3
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=4)
+    wav = synth.synth_waveforms(B, L, seed=5)
+    outs = {}
+    for compute in ("f32", "bf16"):
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[compute] = eng.embed_wave(wav)
+        eng.close()
+    a, b = outs["f32"], outs["bf16"]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.isfinite(b).all() and cos.min() >= 0.999, cos
