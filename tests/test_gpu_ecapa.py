@@ -142,3 +142,22 @@ def test_bf16_other_utterance_lengths(L):
     a, b = outs["f32"], outs["bf16"]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.isfinite(b).all() and cos.min() >= 0.999, cos
+
+
+@pytest.mark.parametrize("C,L,B", [(64, 8000, 3), (128, 16000, 1), (128, 33000, 2), (256, 34000, 2), (512, 4000, 3),
+                                   (1024, 8000, 2), (1024, 33040, 1), (192, 32000, 2)])
+def test_bf16_geometry_sweep(C, L, B):
+    """Channel counts, utterance lengths and batch sizes that select every dispatch branch (GEMM kernels by N, fused /
+    unfused Res2Net by C/8 and T, fused / unfused attention tail by 3C % 128 and T, column-sum epilogue by T >= 256)."""
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=6)
+    wav = synth.synth_waveforms(B, L, seed=7)
+    outs = {}
+    for compute in ("f32", "bf16"):
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[compute] = eng.embed_wave(wav).reshape(B, -1)
+        eng.close()
+    a, b = outs["f32"], outs["bf16"]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.isfinite(b).all() and cos.min() >= 0.998, (C, L, B, cos)
