@@ -118,3 +118,30 @@ def test_device_cropping_matches_reference_semantics(eng):
         for f, a in enumerate(files):
             want = o_scoring.crop_eval(a.astype(np.float32) / 32768.0, 32000, ne, peak_normalize=False)
             assert np.array_equal(got[f], want), (f, ne)
+
+
+@pytest.mark.parametrize("N,D,P,K,top", [(1, 192, 1, 3, 2), (7, 64, 5, 64, 64), (1000, 256, 999, 300, 200), (33, 192, 64, 5, 200),
+                                         (4097, 96, 1, 201, -1)])
+def test_scoring_size_sweep(eng, N, D, P, K, top):
+    """Odd sizes through every scoring entry point (one embedding, one trial, cohorts smaller than `top`, top = -1, embedding
+    widths other than 192): results against the numpy statements, and above all no out-of-bounds access."""
+    rng = np.random.Generator(np.random.PCG64(N + D + P + K))
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    cohort = rng.standard_normal((K, D)).astype(np.float32)
+    cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
+    ia = rng.integers(0, N, P).astype(np.int32)
+    ib = rng.integers(0, N, P).astype(np.int32)
+    got = eng.score_pairs(E, ia, ib)
+    assert float(np.abs(got - np.abs((E[ia] * E[ib]).sum(1))).max()) <= 1e-5
+    M = eng.score_matrix(E[: min(N, 50)], cohort)
+    assert float(np.abs(M - E[: min(N, 50)] @ cohort.T).max()) <= 1e-4
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    S = np.sort(E @ cohort.T, axis=1)[:, ::-1]
+    kk = K + top if top < 0 else min(top, K)
+    S = S[:, :kk]
+    assert float(np.abs(mu - S.mean(1)).max()) <= 1e-4 and float(np.abs(sd - S.std(1)).max()) <= 1e-4
+    sc = eng.asnorm_pairs(E, mu, sd, ia, ib)
+    raw = (E[ia] * E[ib]).sum(1)
+    want = 0.5 * ((raw - mu[ia]) / sd[ia] + (raw - mu[ib]) / sd[ib])
+    assert float(np.abs(sc - want).max()) <= 2e-3 * max(1.0, float(np.abs(want).max()))
