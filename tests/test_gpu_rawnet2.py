@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from speakerverification_amd import synth
+from speakerverification_amd.engine import Engine
 from speakerverification_amd.models import RawNet2_custom
 
 pytestmark = pytest.mark.gpu
@@ -55,3 +56,23 @@ def test_rawnet2_rejects_other_lengths():
     m = make("f32", 1)
     with pytest.raises(ValueError):
         m(np.zeros((1, 16000), np.float32))
+
+
+@pytest.mark.parametrize("B", [1, 3, 17])
+def test_rawnet2_batch_sizes(B):
+    """Batch sizes that do not fill a GEMM tile; rows must not depend on the batch they ride in (bf16 vs fp32, and vs B = 1)."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(), seed=1)
+    wav = synth.synth_waveforms(B, 32000, seed=3)
+    outs = {}
+    for compute in ("f32", "bf16"):
+        eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[compute] = eng.embed_wave(wav).reshape(B, -1)
+        if compute == "f32" and B > 1:
+            one = eng.embed_wave(wav[:1]).reshape(1, -1)
+            assert float(np.abs(one - outs["f32"][:1]).max()) <= 1e-4 * max(1.0, float(np.abs(one).max()))
+        eng.close()
+    a, b = outs["f32"], outs["bf16"]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.isfinite(b).all() and cos.min() >= 0.99, cos
