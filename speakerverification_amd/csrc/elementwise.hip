@@ -178,15 +178,26 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     if (c >= C) return;
     const int r0 = b * T, r1 = r0 + T - 1;
     float s = 0.f, q = 0.f;
-    for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
-        const int seg = b - (tm * 256) / T;
-        if (seg < 0 || seg > 1) continue;
+    // an utterance of T >= 256 frames touches at most T / 256 + 2 tiles; three at a time so that their 24 (48) loads are all
+    // in flight (a runtime-bounded loop exposed one round trip per tile and made this tiny kernel 40 us)
+    for (int tm0 = r0 / 256; tm0 <= r1 / 256; tm0 += 3) {
+        float ps[3][8], pq[3][8];
 #pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
-            const int64_t o = ((int64_t)(tm * 8 + rg) * 2 + seg) * C + c;
-            s += part[o];
-            if (with_std) q += part[sq_stride + o];
+        for (int u = 0; u < 3; ++u) {
+            const int tm = tm0 + u;
+            const int seg = b - (tm * 256) / T;
+            const bool ok = tm <= r1 / 256 && seg >= 0 && seg <= 1;
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) {
+                const int64_t o = ((int64_t)(tm * 8 + rg) * 2 + (ok ? seg : 0)) * C + c;
+                ps[u][rg] = ok ? part[o] : 0.f;
+                pq[u][rg] = (ok && with_std) ? part[sq_stride + o] : 0.f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) { s += ps[u][rg]; q += pq[u][rg]; }
     }
     const float mean = s / (float)T;
     if (with_std) {
@@ -223,11 +234,21 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         const float inv = 1.0f / (float)T;
         for (int ch = threadIdx.x; ch < nch4; ch += 256) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
-                const int seg = b - (tm * 256) / T;
-                if (seg < 0 || seg > 1) continue;
+            for (int tm0 = r0 / 256; tm0 <= r1 / 256; tm0 += 3) {       // three tiles' 24 loads in flight (see colsum_finalize_kernel)
+                f32x4 ps[3][8];
 #pragma unroll
-                for (int rg = 0; rg < 8; ++rg) acc += p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch4 + ch];
+                for (int u = 0; u < 3; ++u) {
+                    const int tm = tm0 + u;
+                    const int seg = b - (tm * 256) / T;
+                    const bool ok = tm <= r1 / 256 && seg >= 0 && seg <= 1;
+#pragma unroll
+                    for (int rg = 0; rg < 8; ++rg)
+                        ps[u][rg] = ok ? p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch4 + ch] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int rg = 0; rg < 8; ++rg) acc += ps[u][rg];
             }
             xm4[ch] = acc * inv;
         }
