@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsvhip.so")
+LIB_PATH = os.environ.get("SVHIP_LIB_PATH") or os.path.join(HERE, "libsvhip.so")     # (override: developer A/B of two builds)
 
 OK = 0
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2

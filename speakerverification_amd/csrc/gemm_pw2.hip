@@ -162,6 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
     // CONV: the X half-tiles are the im2col view of a dilated 1-D convolution — chunk c of K tile kt is k = kt*64 + 8c ..:
     // tap k / cin of frame t + (tap - taps/2) * dil (reflect or zero padded, chunks past K read the zero page)
+    const float rcin = CONV ? 1.0f / (float)p.cin : 0.0f;
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             const char* s = src[ty][jj] + (int64_t)kt * 128;
             if (CONV && ty < 2) {
                 const int k = kt * 64 + cchk[jj] * 8;
-                const int tap = k / p.cin;
+                const int tap = (int)(((float)k + 0.5f) * rcin);          // k / cin (exact: k < 2^16, cin <= 2^10), 3 VALU ops instead of a division
                 int tt = cfrm[ty][jj] + (tap - (p.taps >> 1)) * p.dil;
                 bool ok = k < p.K;
                 if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
