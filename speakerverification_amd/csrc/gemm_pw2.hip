@@ -32,7 +32,11 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 constexpr int QBM = 256, QBN = 256;
 constexpr int HT = 16384;                       // one half-tile: 128 rows x 64 k bf16
 constexpr int PW2_LDS = 8 * HT;                 // 128 KiB (also holds the 256 x 256 bf16 output tile)
+#ifdef QGROUP_M_OVERRIDE
+constexpr int QGROUP_M = QGROUP_M_OVERRIDE;
+#else
 constexpr int QGROUP_M = 12;
+#endif
 
 enum Epi : int { EPI_NONE = 0, EPI_RELU = 1, EPI_GELU = 2, EPI_LRELU03 = 4, EPI_BN_LRELU03 = 5 };   // 5: affine first, then LeakyReLU(0.3)
 #ifdef SVHIP_GEMM_DEBUG
