@@ -110,3 +110,24 @@ def test_c_abi_error_behaviour():
     with pytest.raises(_lib.SvhipError):
         eng.score_pairs(E, np.array([0, 9], np.int32), np.array([1, 2], np.int32))                  # index out of range
     eng.close()
+
+
+def test_profile_filter_brackets_only_the_named_kernel():
+    """svhip_profile_filter: bench.py times the roofline kernel inside the timed region and nothing else."""
+    eng = Engine(model="ecapa", compute="bf16", channels=512, max_batch=8)
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=2))
+    eng.finalize()
+    wav = synth.synth_waveforms(8, 32000)
+    eng.profile(True, only="gemm_pw2")
+    eng.embed_wave(wav)
+    only = eng.profile_results()
+    assert set(only) == {"gemm_pw2"} and only["gemm_pw2"]["launches"] == 7 and only["gemm_pw2"]["ms"] > 0
+    eng.profile(True)
+    eng.embed_wave(wav)
+    every = eng.profile_results()
+    assert {"fbank", "gemm_pw2", "gemm_pw2_conv", "res2net_chain", "asp_fused", "se_apply"} <= set(every)
+    assert every["gemm_pw2"]["launches"] == 7
+    eng.profile(False)
+    eng.embed_wave(wav)
+    assert eng.profile_results() == every            # nothing recorded while profiling is off
+    eng.close()

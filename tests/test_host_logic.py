@@ -185,3 +185,23 @@ def test_two_rank_gloo_sharded_evaluation(tmp_path):
     sc, _, _ = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path="x",
                                    num_eval=2, scoring_mode="cosine")
     assert np.abs(np.array(sc) - np.array(res[0][1])).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", ["small", "ties", "distinct", "skewed"])
+def test_metrics_host_selection_matches_sklearn(case):
+    """The host half of speakerverification_amd.metrics (drop_intermediate, (0, 0) start point, precision / recall, auc) fed
+    with CPU-computed curve points must reproduce scikit-learn's roc_curve / precision_recall_curve / auc exactly — the device
+    half only supplies (fps, tps, thresholds), which tests/test_gpu_metrics.py pins separately."""
+    from sklearn import metrics as skm
+    from oracle import metrics as o_metrics
+    from speakerverification_amd import metrics as m
+    from tests.metrics_data import metrics_case
+    sc, lab = metrics_case(case)
+    fps, tps, thr = o_metrics.binary_clf_curve(lab, sc)
+    fpr, tpr, th = m._roc_curve(fps, tps, thr.astype(np.float32))
+    rf, rt, rth = skm.roc_curve(lab, sc.astype(np.float64), pos_label=1)
+    assert np.array_equal(fpr, rf) and np.array_equal(tpr, rt) and np.array_equal(th, rth)
+    pr, rc, pth = m._precision_recall_curve(fps, tps, thr.astype(np.float32))
+    sp, sr, sth = skm.precision_recall_curve(lab, sc.astype(np.float64), pos_label=1)
+    assert np.array_equal(pr, sp) and np.array_equal(rc, sr) and np.array_equal(pth, sth)
+    assert m._auc(fpr * 100, tpr) == skm.auc(rf * 100, rt)
