@@ -1,45 +1,49 @@
 #!/usr/bin/env python
 """bench.py — throughput of the speaker-embedding hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts its own N ranks (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config shard [--gpus N] [--utts-per-gpu 125000]   # BASELINE configs[4]
 
-Workload (BASELINE.json configs[1]): ECAPA-TDNN C=1024, bf16 MFMA / fp32 accumulate, batch = 256
-utterances of 2 s @ 16 kHz per step, waveforms resident in HBM, one step = fbank -> ECAPA forward
--> (256, 192) embeddings.  With N > 1 every rank embeds its own 256 utterances per step (weak
-scaling, no data-path collective) and the shard embeddings are assembled with ONE RCCL all-gather
-at the end of the timed region (reference: all_gather_object, src/model.py:400-404).
+Default workload (BASELINE.json configs[1]): ECAPA-TDNN C=1024, bf16 MFMA / fp32 accumulate, batch = 256 utterances of
+2 s @ 16 kHz per step, waveforms resident in HBM (8 distinct batches = 262 MB are rotated, so the timed loop does not
+re-read one Infinity-Cache-resident buffer), one step = fbank -> ECAPA forward -> (256, 192) embeddings.  With N > 1
+every rank embeds its own 256 utterances per step (weak scaling, no data-path collective) and the shard embeddings are
+assembled with ONE RCCL all-gather at the end of the timed region (reference: all_gather_object, src/model.py:400-404) —
+issued through the C ABI (svhip_allgather_rows) on the library's stream; torch.distributed (gloo) only carries the
+128-byte RCCL id, the barriers and the max-over-ranks of the wall time.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field contract): `value` is whole-job
-embeddings/s; `roofline` is the dominant kernel (the pointwise-conv MFMA GEMM) timed with HIP
-events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle timed on
-this box's host cores on a bounded sample (rank 0, N = 1 only); `scoring` reports trial-pairs/s.
+Prints ONE JSON line on rank 0 (field contract: README / DESIGN.md §5): `value` is whole-job embeddings/s; `roofline` is
+the dominant kernel (the pointwise-conv MFMA GEMM) timed with HIP events on the launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only); sub-records:
+`check` (the last timed step's embeddings verified against the fp32-parity path and a bitwise re-run), `scoring`
+(BASELINE configs[3] + CPU baselines), `rawnet2` (configs[2]), `ecapa_f32` (the 1e-4-parity path), `pcie` (int16 PCM over
+PCIe -> device crop -> embed), `shard` (multi-GPU: all-gather + row-sharded scoring of the gathered matrix).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from speakerverification_amd import synth  # noqa: E402
-from speakerverification_amd.engine import Engine  # noqa: E402
 
 BATCH = 256
 SAMPLES = 32000
 CHANNELS = 1024
 EMBED = 192
+NBATCH = 8                     # distinct waveform batches rotated in the timed loop (8 x 32.8 MB > the 256 MB Infinity Cache)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 PEAK_F32_TFLOPS = 157.3
-DOMINANT = "gemm_pw2"          # gemm_pw2_kernel<EPI_GELU>: tdnn1/tdnn2 x3 + mfa (the 256 x 256 bf16 pointwise-conv GEMM)
+PEAK_HBM_GBS = 8000.0
+SEED_STREAM = 20220829         # synthetic utterance stream of the embedding benches (yaml/configuration-voxceleb.yaml:15)
+SEED_SHARD = 5
 
 
 def parse():
@@ -50,9 +54,27 @@ def parse():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--model", default="ecapa", choices=["ecapa", "rawnet2"], help="ecapa = headline (configs[1]); rawnet2 = configs[2]")
+    ap.add_argument("--config", default="batch", choices=["batch", "shard"],
+                    help="batch = K steps of one batch per GPU (configs[1]/[2]); shard = configs[4]: a sharded utterance list, "
+                         "one all-gather, row-sharded scoring")
+    ap.add_argument("--utts-per-gpu", type=int, default=125000, help="--config shard: utterances per GPU (1 M / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rawnet2 / ecapa_f32 / pcie sub-records")
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a child torch.distributed.run BEFORE anything in this
+    process touches the GPU, and hand its exit code back (never measures a single GPU under an N-GPU label)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def host_cores():
@@ -74,7 +96,9 @@ def host_cores():
 def cpu_baseline(sample_utts=8, reps=3):
     """CPU oracle (oracle/: torch-CPU restatement pinned against the reference) on a bounded sample of
     the same workload: `sample_utts` waveforms through fbank + ECAPA C=1024 fp32, all host cores."""
+    import torch
     from oracle import ecapa as o_ecapa, fbank as o_fbank
+    from speakerverification_amd import synth
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = o_ecapa.to_torch_sd(synth.synth_state_dict(synth.ecapa_param_spec(C=CHANNELS), seed=1))
@@ -93,15 +117,56 @@ def cpu_baseline(sample_utts=8, reps=3):
             "sample": f"{n} x {sample_utts} utterances (2 s @ 16 kHz), fbank + ECAPA-TDNN C=1024 fp32, torch-CPU oracle, {dt:.1f} s"}
 
 
-def scoring_bench(dev):
+def scoring_cpu_baseline(E, cohort, ia, ib, top):
+    """the reference-style per-trial Python loop (utils.py:126-169 through the oracle) and a numpy batched GEMM,
+    on a bounded sample of the same trial list, on this box's host cores."""
+    import numpy as np
+    import torch
+    from oracle import scoring as o_scoring
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    res = {"cores": cores, "kind": "port"}
+    Et = torch.from_numpy(E)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0 and n < len(ia):
+        for p in range(n, min(n + 2000, len(ia))):
+            o_scoring.cosine_similarity(Et[ia[p]][None], Et[ib[p]][None])
+        n = min(n + 2000, len(ia))
+    res["cosine_per_trial_loop_trials_per_s"] = n / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 3.0 and n < len(ia):
+        for p in range(n, min(n + 200, len(ia))):
+            o_scoring.zt_norm_similarity(E[ia[p]][None], E[ib[p]][None], cohort, top=top)
+        n = min(n + 200, len(ia))
+    res["asnorm_per_trial_loop_trials_per_s"] = n / (time.perf_counter() - t0)
+    m = min(len(ia), 200_000)
+    t0 = time.perf_counter()
+    np.abs(np.einsum("pd,pd->p", E[ia[:m]], E[ib[:m]]))
+    res["cosine_numpy_batched_trials_per_s"] = m / (time.perf_counter() - t0)
+    rows = min(E.shape[0], 16384)
+    t0 = time.perf_counter()
+    S = E[:rows] @ cohort.T
+    S = -np.partition(-S, top - 1, axis=1)[:, :top]
+    S.mean(axis=1), S.std(axis=1)
+    res["asnorm_stats_numpy_rows_per_s"] = rows / (time.perf_counter() - t0)
+    res["sample"] = "per-trial loops: 2-3 s each; numpy batched: 200 k trials / 16 k rows of the same 1.2 M-trial list"
+    return res
+
+
+def scoring_bench(dev, with_cpu=True):
     """BASELINE config 4: 1.2 M synthetic 192-d embeddings, 1.2 M-trial list, cohort 5994, top 200."""
+    import numpy as np
+    import torch
+    from speakerverification_amd.engine import Engine
     assert torch.cuda.current_stream().cuda_stream != 0
     eng = Engine(model="none", device=dev.index, stream=torch.cuda.current_stream().cuda_stream)
-    N, P, K, top = 1_200_000, 1_200_000, 5994, 200
+    N, P, K, top, D = 1_200_000, 1_200_000, 5994, 200, 192
     g = torch.Generator(device=dev).manual_seed(2)
-    E = torch.randn((N, EMBED), generator=g, device=dev, dtype=torch.float32)
+    E = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32)
     eng.l2norm_(E)
-    cohort = torch.randn((K, EMBED), generator=g, device=dev, dtype=torch.float32)
+    cohort = torch.randn((K, D), generator=g, device=dev, dtype=torch.float32)
     eng.l2norm_(cohort)
     ia = torch.arange(P, device=dev, dtype=torch.int32)
     ib = torch.randperm(N, generator=g, device=dev)[:P].to(torch.int32)
@@ -120,6 +185,7 @@ def scoring_bench(dev):
     t = timed(lambda: eng.score_pairs(E, ia, ib, out))
     res["cosine_pairs_per_s"] = P / t
     res["cosine_pairs_GBps"] = P * 1540 / t / 1e9
+    res["cosine_pairs_frac_of_hbm_peak"] = P * 1540 / t / 1e9 / PEAK_HBM_GBS
     mu_sd = {}
 
     def stats():
@@ -129,12 +195,13 @@ def scoring_bench(dev):
     t_pairs = timed(lambda: eng.asnorm_pairs(E, mu, sd, ia, ib, out))
     res["asnorm_pairs_per_s"] = P / (t_stats + t_pairs)
     res["asnorm_stats_s"] = t_stats
-    res["asnorm_cohort_gemm_TFLOPs"] = 2.0 * N * K * EMBED / t_stats / 1e12
+    res["asnorm_cohort_gemm_TFLOPs"] = 2.0 * N * K * D / t_stats / 1e12
     A, Bm = E[:16384], E[16384:32768]
     dense = torch.empty((16384, 16384), device=dev, dtype=torch.float32)
     t = timed(lambda: eng.score_matrix(A, Bm, dense))
     res["dense_pairs_per_s"] = 16384 * 16384 / t
-    res["dense_TFLOPs"] = 2.0 * 16384 * 16384 * EMBED / t / 1e12
+    res["dense_TFLOPs"] = 2.0 * 16384 * 16384 * D / t / 1e12
+    res["dense_frac_of_f32_mfma_peak"] = res["dense_TFLOPs"] / PEAK_F32_TFLOPS
     # verification metrics over the same 1.2 M-trial list (EER / minDCF inputs; host arrays in, PCIe included)
     sc_host = out.cpu().numpy()
     lab_host = (np.arange(P) % 2).astype(np.int32)
@@ -142,113 +209,320 @@ def scoring_bench(dev):
     res["min_dcf_trials_per_s"] = P / t
     t = timed(lambda: eng.roc_points(sc_host, lab_host))
     res["roc_points_trials_per_s"] = P / t
-    res["config"] = {"embeddings": N, "trials": P, "cohort": K, "top": top, "dim": EMBED}
+    res["config"] = {"embeddings": N, "trials": P, "cohort": K, "top": top, "dim": D}
+    if with_cpu:
+        res["cpu_baseline"] = scoring_cpu_baseline(E[:200_000].cpu().numpy(), cohort.cpu().numpy(),
+                                                   np.arange(200_000), np.random.default_rng(4).permutation(200_000), top)
     eng.close()
     return res
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no GPU visible); the product path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-
-    # one torch stream carries everything (library kernels, RCCL all-gather, HIP events)
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        run(args, rank, world, local, dev, dist)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def run(args, rank, world, local, dev, dist):
-    B, K, W = args.batch, args.steps, args.warmup
-    global EMBED, DOMINANT
-    if args.compute == "f32" and args.model == "ecapa":
-        DOMINANT = "gemm_pw"
-    if args.model == "rawnet2":
-        EMBED, DOMINANT = 320, "gemm_conv"
-        eng = Engine(model="rawnet2", compute=args.compute, embed_dim=EMBED, max_batch=B, samples=SAMPLES, device=local,
-                     stream=torch.cuda.current_stream().cuda_stream)
-        eng.load_state_dict(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=EMBED), seed=1))
+def make_engine(model, compute, B, local, embed=None):
+    import torch
+    from speakerverification_amd import synth
+    from speakerverification_amd.engine import Engine
+    st = torch.cuda.current_stream().cuda_stream
+    if model == "rawnet2":
+        eng = Engine(model="rawnet2", compute=compute, embed_dim=embed or 320, max_batch=B, samples=SAMPLES, device=local, stream=st)
+        eng.load_state_dict(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=embed or 320), seed=1))
     else:
-        eng = Engine(model="ecapa", compute=args.compute, channels=CHANNELS, embed_dim=EMBED, max_batch=B,
-                     samples=SAMPLES, device=local, stream=torch.cuda.current_stream().cuda_stream)
+        eng = Engine(model="ecapa", compute=compute, channels=CHANNELS, embed_dim=embed or EMBED, max_batch=B,
+                     samples=SAMPLES, device=local, stream=st)
         eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=CHANNELS), seed=1))
     eng.finalize()
+    return eng
 
-    # synthetic waveforms, resident in HBM before the timed region (rank-dependent seed)
-    wav = torch.from_numpy(synth.synth_waveforms(B, SAMPLES, seed=20220829 + rank)).to(dev)
-    shard = torch.empty((K * B, EMBED), device=dev, dtype=torch.float32)   # this rank's embeddings
-    gathered = torch.empty((world * K * B, EMBED), device=dev, dtype=torch.float32) if world > 1 else shard
-    scratch = torch.empty((B, EMBED), device=dev, dtype=torch.float32)
 
-    for _ in range(W):
-        eng.embed_wave(wav, out=scratch, async_=True)
+def dominant_label(model, compute):
+    if model == "rawnet2":
+        return "gemm_conv"
+    return "gemm_pw2" if compute == "bf16" else "gemm_pw"
+
+
+def roofline_of(prof, label, compute):
+    peak = PEAK_BF16_TFLOPS if compute == "bf16" else PEAK_F32_TFLOPS
+    dom = prof.get(label, {"ms": 0.0, "launches": 0, "flops": 0.0})
+    avg_ms = dom["ms"] / max(1, dom["launches"])
+    achieved = (dom["flops"] / max(1, dom["launches"])) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    traffic, src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(label, {}).get("hbm_bytes_per_launch")
+            src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 x2 fetch correction; not re-measured in this run)"
+        except Exception:
+            traffic = None
+    return {"kernel": label, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": dom["launches"]}
+
+
+def embed_loop(eng, wavs, K, W, B, shard, label, barrier=lambda: None):
+    """W warm-up + K timed steps over the rotating waveform batches; the dominant kernel's launches are bracketed by HIP
+    events on the launch stream inside the timed region (resolved after it)."""
+    import torch
+    scratch = torch.empty((B, eng.embed_dim), device=shard.device, dtype=torch.float32)
+    for w in range(W):
+        eng.embed_wave(wavs[w % len(wavs)], out=scratch, async_=True)
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # HIP events bracket the dominant kernel's launches on the launch stream inside the timed region (resolved after it);
-    # the other kernels are timed in a separate profiled pass below: two events per launch on ~40 launches per step
-    # cost ~2 % of the step in queue bubbles
-    eng.profile(True, only=DOMINANT)
+    eng.profile(True, only=label)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
-        eng.embed_wave(wav, out=shard[k * B:(k + 1) * B], async_=True)
-    if dist is not None:
-        dist.all_gather_into_tensor(gathered, shard)       # the path's single exchange step (RCCL over xGMI)
+        eng.embed_wave(wavs[k % len(wavs)], out=shard[k * B:(k + 1) * B], async_=True)
+    return t0
+
+
+def kernel_table(eng, wavs, B, n_steps, dev):
+    import torch
+    scratch = torch.empty((B, eng.embed_dim), device=dev, dtype=torch.float32)
+    eng.profile(True)            # untimed pass: every kernel bracketed, for the per-kernel table
+    for k in range(n_steps):
+        eng.embed_wave(wavs[k % len(wavs)], out=scratch, async_=True)
     torch.cuda.synchronize()
-    barrier()
+    prof_all = eng.profile_results()
+    eng.profile(False)
+    return {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches_per_step": v["launches"] / n_steps,
+                "ms_per_step": v["ms"] / n_steps,
+                "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
+            for k, v in prof_all.items()}
+
+
+def sub_bench(model, compute, B, local, dev, wavs, steps=10, warmup=2):
+    """a smaller record of the same shape for the other configurations (rawnet2 = configs[2]; ecapa f32 = the 1e-4-parity path)"""
+    import torch
+    eng = make_engine(model, compute, B, local)
+    label = dominant_label(model, compute)
+    shard = torch.empty((steps * B, eng.embed_dim), device=dev, dtype=torch.float32)
+    t0 = embed_loop(eng, wavs, steps, warmup, B, shard, label)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.profile_results()
-    eng.profile(True)            # untimed pass: every kernel bracketed, for the per-kernel table
-    for k in range(min(K, 10)):
-        eng.embed_wave(wav, out=scratch, async_=True)
-    torch.cuda.synchronize()
-    prof_all = eng.profile_results()
-    n_all = min(K, 10)
-    eng.profile(False)
+    rec = {"value": steps * B / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "batch": B,
+           "dtype": compute, "finite": bool(torch.isfinite(shard).all().item()),
+           "whole_path_TFLOPs": eng.flops_per_utterance * steps * B / dt / 1e12,
+           "roofline": roofline_of(prof, label, compute)}
+    kt = kernel_table(eng, wavs, B, min(steps, 5), dev)
+    rec["launches_per_step"] = sum(v["launches_per_step"] for v in kt.values())
+    rec["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "TFLOPs": v["TFLOPs"]} for k, v in kt.items()}
+    eng.close()
+    return rec
 
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+
+def pcie_bench(eng, dev, B):
+    """PCIe-inclusive rate: decoded 16-bit PCM on the host -> int16 over PCIe -> device crop (svhip_crop_pcm16) -> embed.
+    (Never `value`: BASELINE's metric is quoted on HBM-resident waveforms.)"""
+    import numpy as np
+    import torch
+    from speakerverification_amd.engine import Engine, TRANSFER_STATS
+    rng = np.random.Generator(np.random.PCG64(11))
+    files = [np.clip(rng.standard_normal(48000) * 3276.8, -32768, 32767).astype(np.int16) for _ in range(B)]   # 3 s files, 1 crop each
+    crop_eng = Engine(model="none", device=dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    crops = torch.empty((B, SAMPLES), device=dev, dtype=torch.float32)
+    out = torch.empty((B, eng.embed_dim), device=dev, dtype=torch.float32)
+    h0 = TRANSFER_STATS["h2d_bytes"]
+    reps = 5
+    for it in range(reps + 1):
+        if it == 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        crop_eng.crop_pcm16(files, 1, SAMPLES, out=crops)
+        eng.embed_wave(crops, out=out, async_=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    crop_eng.close()
+    return {"value": B / dt, "unit": "embeddings/s", "ms_per_step": dt * 1e3, "batch": B,
+            "h2d_bytes_per_step": (TRANSFER_STATS["h2d_bytes"] - h0) / (reps + 1),
+            "note": "per step: 256 x 3 s int16 files host->device (pageable memory, synchronous), device crop, embed"}
+
+
+def verify_last_step(eng, wav_last, emb_last, local, dev):
+    """the timed loop's LAST step: (a) bitwise equal to a re-run of the same batch (no race / stale buffer); (b) 8 of its rows
+    against the exact-fp32-MFMA engine (the 1e-4-parity path): cosine and max error relative to the embedding scale."""
+    import torch
+    rerun = torch.empty_like(emb_last)
+    eng.embed_wave(wav_last, out=rerun, async_=True)
+    torch.cuda.synchronize()
+    rec = {"bitwise_rerun": bool(torch.equal(rerun, emb_last)), "finite": bool(torch.isfinite(emb_last).all().item())}
+    if eng.compute == "bf16" and eng.model == "ecapa":
+        f32 = make_engine("ecapa", "f32", 8, local)
+        ref = torch.empty((8, eng.embed_dim), device=dev, dtype=torch.float32)
+        f32.embed_wave(wav_last[:8].contiguous(), out=ref, async_=True)
+        torch.cuda.synchronize()
+        f32.close()
+        got = emb_last[:8]
+        cos = torch.nn.functional.cosine_similarity(got, ref, dim=1)
+        rec["rows_checked"] = 8
+        rec["min_cosine_vs_f32_path"] = float(cos.min().item())
+        rec["max_err_over_scale"] = float(((got - ref).abs().max() / ref.abs().max()).item())
+        rec["ok"] = rec["bitwise_rerun"] and rec["finite"] and rec["min_cosine_vs_f32_path"] >= 0.999 and rec["max_err_over_scale"] <= 0.03
+    else:
+        rec["ok"] = rec["bitwise_rerun"] and rec["finite"]
+    return rec
+
+
+class Ranks:
+    """control plane of a multi-rank run: torch.distributed (gloo) for the RCCL id, barriers and the max over ranks;
+    the data-path collective is RCCL under the C ABI (LibComm on an Engine)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.launched = "WORLD_SIZE" in os.environ        # under a launcher the multi-rank code path runs even at world size 1
+        if self.launched:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                       # nothing above touched the GPU
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); the product path has no CPU fallback")
+    ranks = Ranks(args)
+    torch.cuda.set_device(ranks.local)
+    dev = torch.device("cuda", ranks.local)
+    # one torch stream carries everything (library kernels, RCCL all-gather, HIP events)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        if args.config == "shard":
+            run_shard(args, ranks, dev)
+        else:
+            run_batch(args, ranks, dev)
+    ranks.close()
+
+
+def synth_batches(eng, n_batches, B, first_utt, dev, seed=SEED_STREAM):
+    """n_batches distinct (B, L) waveform batches of the synthetic utterance stream, generated in HBM (svhip_synth_waveforms)"""
+    import torch
+    wavs = []
+    for j in range(n_batches):
+        w = torch.empty((B, SAMPLES), device=dev, dtype=torch.float32)
+        eng.synth_waveforms(seed, first_utt + j * B, B, SAMPLES, out=w, async_=True)
+        wavs.append(w)
+    torch.cuda.synchronize()
+    return wavs
+
+
+def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True):
+    """after embedding: ONE all-gather of the (n_local, D) block per rank, then config-4-style scoring of the gathered matrix,
+    row-sharded by enrol index: rank r scores the trials (i, pi(i)) with i in its block, and computes the AS-norm cohort
+    statistics of its own rows (gathered with a second, small all-gather of (n_local, 2))."""
+    import torch
+    from speakerverification_amd import distributed as sv_dist
+    world, rank = ranks.world, ranks.rank
+    D = shard.shape[1]
+    rec = {}
+    gathered = torch.empty((world * n_local, D), device=dev, dtype=torch.float32)
+    ranks.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if comm is not None:
+        eng.allgather_rows(shard, out=gathered, async_=True)
+    else:
+        gathered.copy_(shard)
+    torch.cuda.synchronize()
+    rec["allgather_ms"] = ranks.max((time.perf_counter() - t0) * 1e3)
+    rec["allgather_bytes_per_rank"] = n_local * D * 4
+    rec["allgather_carrier"] = "svhip_allgather_rows (RCCL under the C ABI)" if comm is not None else "none (1 GPU: local copy)"
+    rec["gathered_rows"] = world * n_local
+    lo = rank * n_local
+    own_block_ok = bool(torch.equal(gathered[lo:lo + n_local], shard))
+    rec["own_block_intact"] = own_block_ok
+    if not do_scoring:
+        return rec, gathered
+    N = world * n_local
+    K, top = 5994, 200
+    g = torch.Generator(device=dev).manual_seed(3)
+    cohort = torch.randn((K, D), generator=g, device=dev, dtype=torch.float32)
+    eng.l2norm_(cohort)
+    gp = torch.Generator(device=dev).manual_seed(4)
+    perm = torch.randperm(N, generator=gp, device=dev).to(torch.int32)             # the same permutation on every rank
+    ia = torch.arange(lo, lo + n_local, device=dev, dtype=torch.int32)              # this rank's trials: enrol index in its block
+    ib = perm[lo:lo + n_local].contiguous()
+    out = torch.empty(n_local, device=dev, dtype=torch.float32)
+    ranks.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.l2norm_(gathered)
+    eng.score_pairs(gathered, ia, ib, out)
+    torch.cuda.synchronize()
+    t_cos = ranks.max(time.perf_counter() - t0)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    mu, sd = eng.asnorm_stats(gathered[lo:lo + n_local], cohort, top)               # row-sharded cohort GEMM + top-k
+    stats_loc = torch.stack([mu, sd], dim=1).contiguous()
+    stats_all = torch.empty((N, 2), device=dev, dtype=torch.float32)
+    if comm is not None:
+        eng.allgather_rows(stats_loc, out=stats_all, async_=True)
+    else:
+        stats_all.copy_(stats_loc)
+    mu_all, sd_all = stats_all[:, 0].contiguous(), stats_all[:, 1].contiguous()
+    eng.asnorm_pairs(gathered, mu_all, sd_all, ia, ib, out)
+    torch.cuda.synchronize()
+    t_as = ranks.max(time.perf_counter() - t0)
+    rec.update({"trials": N, "cohort": K, "top": top, "cosine_s": t_cos, "cosine_trials_per_s": N / t_cos,
+                "asnorm_s": t_as, "asnorm_trials_per_s": N / t_as, "scores_finite": bool(torch.isfinite(out).all().item()),
+                "scoring": "row-sharded by enrol index; stats of own rows + one (n_local, 2) all-gather"})
+    return rec, gathered
+
+
+def run_batch(args, ranks, dev):
+    import torch
+    from speakerverification_amd import distributed as sv_dist
+    B, K, W = args.batch, args.steps, args.warmup
+    rank, world, local = ranks.rank, ranks.world, ranks.local
+    label = dominant_label(args.model, args.compute)
+    eng = make_engine(args.model, args.compute, B, local)
+    embed = eng.embed_dim
+    comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+
+    # synthetic waveforms, resident in HBM before the timed region: NBATCH distinct batches per rank, rotated
+    wavs = synth_batches(eng, NBATCH, B, rank * NBATCH * B, dev)
+    shard = torch.empty((K * B, embed), device=dev, dtype=torch.float32)   # this rank's embeddings
+    gathered = torch.empty((world * K * B, embed), device=dev, dtype=torch.float32) if comm is not None else shard
+
+    t0 = embed_loop(eng, wavs, K, W, B, shard, label, ranks.barrier)
+    if comm is not None:
+        eng.allgather_rows(shard, out=gathered, async_=True)       # the path's single exchange step (RCCL over xGMI)
+    torch.cuda.synchronize()
+    ranks.barrier()
+    torch.cuda.synchronize()
+    dt = ranks.max(time.perf_counter() - t0)
+    prof = eng.profile_results()
+    eng.profile(False)
+    check = verify_last_step(eng, wavs[(K - 1) % NBATCH], shard[(K - 1) * B:K * B], local, dev)
+    shard_rec = None
+    if comm is not None:
+        shard_rec, _ = shard_tail(eng, comm, ranks, shard, dev, K * B)
+    n_all = min(K, 10)
+    kern = kernel_table(eng, wavs, B, n_all, dev) if rank == 0 else {}
 
     if rank == 0:
-        ok = bool(torch.isfinite(shard).all().item())
-        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_TFLOPS
-        dom = prof.get(DOMINANT, {"ms": 0.0, "launches": 0, "flops": 0.0})
-        avg_ms = dom["ms"] / max(1, dom["launches"])
-        achieved = (dom["flops"] / max(1, dom["launches"])) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(DOMINANT, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        kern = {k: {"avg_ms": v["ms"] / max(1, v["launches"]), "launches_per_step": v["launches"] / n_all,
-                    "ms_per_step": v["ms"] / n_all,
-                    "TFLOPs": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
-                for k, v in prof_all.items()}
         total_utts = world * K * B
         line = {
             "metric": "embeddings/sec (2 s @16 kHz)", "value": total_utts / dt, "unit": "embeddings/s",
@@ -259,27 +533,88 @@ def run(args, rank, world, local, dev, dist):
                                     "(BASELINE configs[1]), HBM-resident waveforms -> 192-d embeddings") if args.model == "ecapa" else
                                    ("RawNet2 sinc front-end + 8 residual blocks + ASP, batch=256 x 2 s @ 16 kHz per GPU per step "
                                     "(BASELINE configs[2]), HBM-resident waveforms -> 320-d embeddings"),
-                       "batch_per_gpu": B, "samples": SAMPLES, "frames": eng.frames, "embed_dim": EMBED,
-                       "collective": "one all_gather_into_tensor of the shard embeddings" if world > 1 else "none"},
-            "finite": ok,
+                       "batch_per_gpu": B, "samples": SAMPLES, "frames": eng.frames, "embed_dim": embed,
+                       "waveform_batches_rotated": NBATCH, "waveform_bytes_resident": NBATCH * B * SAMPLES * 4,
+                       "collective": "one svhip_allgather_rows (RCCL) of the shard embeddings inside the timed region" if comm is not None else "none"},
+            "finite": check["finite"], "check": check,
             "whole_path_TFLOPs": eng.flops_per_utterance * total_utts / dt / 1e12,
             "flops_per_utterance": eng.flops_per_utterance,
-            "roofline": {"kernel": DOMINANT, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "avg_launch_ms": avg_ms,
-                         "launches": dom["launches"]},
+            "roofline": roofline_of(prof, label, args.compute),
             "kernels": kern,
             "kernels_note": "per-kernel table from a separate profiled pass of %d steps (every launch bracketed); "
                             "the roofline kernel is timed live inside the timed region" % n_all,
         }
-        if world == 1 and not args.no_cpu_baseline and args.model == "ecapa":
-            line["cpu_baseline"] = cpu_baseline()
-        else:
-            line["cpu_baseline"] = None
+        if shard_rec is not None:
+            line["shard"] = shard_rec
+        line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline and args.model == "ecapa") else None
         if world == 1 and not args.no_scoring and args.model == "ecapa":
             try:
-                line["scoring"] = scoring_bench(dev)
+                line["scoring"] = scoring_bench(dev, with_cpu=not args.no_cpu_baseline)
             except Exception as e:  # scoring is reported next to, not inside, the headline
                 line["scoring"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras and args.model == "ecapa" and args.compute == "bf16":
+            for name, fn in (("rawnet2", lambda: sub_bench("rawnet2", "bf16", B, local, dev, wavs)),
+                             ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
+                             ("pcie", lambda: pcie_bench(eng, dev, B))):
+                try:
+                    line[name] = fn()
+                except Exception as e:
+                    line[name] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    eng.close()
+
+
+def run_shard(args, ranks, dev):
+    """BASELINE configs[4] / SURVEY §8d config 5: a synthetic utterance list sharded in contiguous blocks (n_local per GPU, generated
+    on the device from the counter-based stream — no waveform crosses PCIe), embedded in batches of 256, ONE all-gather of the
+    (n_local, 192) fp32 block per rank, then config-4-style scoring of the gathered matrix, row-sharded by enrol index."""
+    import torch
+    from speakerverification_amd import distributed as sv_dist
+    B = args.batch
+    rank, world, local = ranks.rank, ranks.world, ranks.local
+    n_local = args.utts_per_gpu
+    label = dominant_label(args.model, args.compute)
+    eng = make_engine(args.model, args.compute, B, local)
+    comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+    shard = torch.empty((n_local, eng.embed_dim), device=dev, dtype=torch.float32)
+    wav = [torch.empty((B, SAMPLES), device=dev, dtype=torch.float32) for _ in range(2)]
+    first = rank * n_local
+    for w in range(args.warmup):
+        eng.synth_waveforms(SEED_SHARD, first, B, SAMPLES, out=wav[0], async_=True)
+        eng.embed_wave(wav[0], out=shard[:B], async_=True)
+    torch.cuda.synchronize()
+    eng.profile(True, only=label)
+    ranks.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 0
+    for u0 in range(0, n_local, B):
+        n = min(B, n_local - u0)
+        buf = wav[steps & 1]
+        eng.synth_waveforms(SEED_SHARD, first + u0, n, SAMPLES, out=buf[:n], async_=True)     # generated in HBM, same stream
+        eng.embed_wave(buf[:n], out=shard[u0:u0 + n], async_=True)
+        steps += 1
+    torch.cuda.synchronize()
+    ranks.barrier()
+    torch.cuda.synchronize()
+    dt = ranks.max(time.perf_counter() - t0)
+    prof = eng.profile_results()
+    eng.profile(False)
+    rec, _ = shard_tail(eng, comm, ranks, shard, dev, n_local)
+    if rank == 0:
+        total = world * n_local
+        line = {"metric": "embeddings/sec (2 s @16 kHz)", "value": total / dt, "unit": "embeddings/s", "n_gpus": world,
+                "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
+                "config": {"workload": "ECAPA-TDNN C=1024 bf16, synthetic utterance list sharded across the GPUs (BASELINE configs[4]: "
+                                       "125 000 x 2 s @ 16 kHz per GPU = 1 M on 8), waveforms generated on the device (Philox stream, inside "
+                                       "the timed region), one RCCL all-gather of embeddings, then row-sharded cosine + AS-norm scoring",
+                           "utterances_per_gpu": n_local, "batch": B, "embed_dim": eng.embed_dim},
+                "embed_seconds": dt, "finite": bool(torch.isfinite(shard).all().item()),
+                "whole_path_TFLOPs": eng.flops_per_utterance * total / dt / 1e12,
+                "roofline": roofline_of(prof, label, args.compute), "shard": rec,
+                "end_to_end_seconds": dt + rec["allgather_ms"] * 1e-3 + rec.get("cosine_s", 0.0) + rec.get("asnorm_s", 0.0),
+                "cpu_baseline": None}
         print(json.dumps(line), flush=True)
     eng.close()
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SVHIP_ABI_VERSION 1
+#define SVHIP_ABI_VERSION 2
 
 typedef struct svhip_handle svhip_handle;
 
@@ -179,6 +179,30 @@ int svhip_blob_close(svhip_blob* b);
 const char* svhip_blob_last_error(void);
 int svhip_load_blob(svhip_handle* h, const char* path);
 
+/* Multi-GPU exchange.  Replaces the reference's `torch.distributed.all_gather_object` of per-rank
+ * feature dicts (src/model.py:400-411): one process per GPU, utterances sharded in contiguous blocks, ONE RCCL all-gather
+ * of the dense (rows, D) fp32 block per rank on the handle's stream — embed -> gather -> score stays on the device.
+ *   comm_unique_id : rank 0 draws the 128-byte RCCL id; the host ships it to the other ranks by any side channel
+ *                    (speakerverification_amd/distributed.py: the torch.distributed store).  Errors: svhip_comm_last_error().
+ *   comm_init      : ncclCommInitRank on the handle's device (collective: every rank of `world` must call it).
+ *   allgather_rows : out (world * rows, D) <- every rank's local (rows, D); rank r's block lands at out + r * rows * D.
+ *                    All ranks pass the same `rows` (pad the last block).  Pointers follow `flags`.
+ *   comm_destroy   : also called by svhip_destroy.
+ * RCCL is bound at the first svhip_comm_* call (dlopen librccl.so.1); without it these return SVHIP_ERR_UNSUPPORTED. */
+#define SVHIP_COMM_ID_BYTES 128
+int svhip_comm_unique_id(void* id_out);
+int svhip_comm_init(svhip_handle* h, const void* id, int32_t rank, int32_t world);
+int svhip_comm_rank(const svhip_handle* h, int32_t* rank, int32_t* world);
+int svhip_allgather_rows(svhip_handle* h, const float* local, int64_t rows, int32_t D, float* out, int32_t flags);
+int svhip_comm_destroy(svhip_handle* h);
+const char* svhip_comm_last_error(void);
+
+/* Synthetic workload generator (nothing in the reference corresponds — its evaluation reads files):
+ * utterances [first_utt, first_utt + B) of the counter-based stream `seed` (Philox4x32-10 + Box-Muller, 0.1 * N(0,1)
+ * clipped to [-1, 1]), (B, L) fp32, L % 4 == 0.  A pure function of (seed, utterance, sample): every rank of a sharded
+ * run generates exactly its own block without moving waveforms over PCIe.  oracle/synthwave.py restates it. */
+int svhip_synth_waveforms(svhip_handle* h, uint64_t seed, int64_t first_utt, int32_t B, int32_t L, float* wav_out, int32_t flags);
+
 /* Introspection used by tests and bench.py (not part of the reference's surface).
  *   get_stage    : copy an intermediate activation of the LAST forward to host as fp32, frame-major
  *                  (B, T, C).  Names: "input","blocks.0".."blocks.3","mfa","asp","asp_bn" (ECAPA).
@@ -193,6 +217,7 @@ int svhip_profile_filter(svhip_handle* h, const char* label);   /* NULL / "": ev
 int svhip_profile_reset(svhip_handle* h);
 int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops);
 double svhip_workload_flops(const svhip_handle* h);
+int svhip_selftest(void);   /* host-only self checks (per-device launch-attribute bookkeeping); 0 = ok, no GPU needed */
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ OK = 0
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
 F32, BF16, I64 = 0, 1, 2
 IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
+COMM_ID_BYTES = 128
 
 
 class SvhipUnavailable(RuntimeError):
@@ -73,6 +74,13 @@ _SIGNATURES = {
     "svhip_blob_close": (C.c_int, [_P]),
     "svhip_blob_last_error": (C.c_char_p, []),
     "svhip_load_blob": (C.c_int, [_P, C.c_char_p]),
+    "svhip_comm_unique_id": (C.c_int, [_P]),
+    "svhip_comm_init": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "svhip_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "svhip_allgather_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
+    "svhip_comm_destroy": (C.c_int, [_P]),
+    "svhip_comm_last_error": (C.c_char_p, []),
+    "svhip_synth_waveforms": (C.c_int, [_P, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_get_stage": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64)]),
     "svhip_profile_enable": (C.c_int, [_P, C.c_int32]),
     "svhip_profile_filter": (C.c_int, [_P, C.c_char_p]),
@@ -80,6 +88,7 @@ _SIGNATURES = {
     "svhip_profile_get": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "svhip_workload_flops": (C.c_double, [_P]),
+    "svhip_selftest": (C.c_int, []),
 }
 
 _lib = None

@@ -28,6 +28,19 @@ def read_wav(path):
         return a.astype(np.float32), sr
 
 
+def read_pcm16(path, sample_rate=None):
+    """16-bit mono PCM WAV -> int16 samples (what svhip_crop_pcm16 consumes: scaled by 1/32768 on the device, exactly
+    soundfile's float32 conversion), or None when the file is anything else (the caller then takes the host path)."""
+    from scipy.io import wavfile
+    try:
+        sr, a = wavfile.read(str(path), mmap=False)
+    except Exception:
+        return None
+    if a.dtype != np.int16 or a.ndim != 1 or a.size == 0:
+        return None
+    return a
+
+
 def normalize_audio_amp(signal):
     """wav_conversion.py:35-41"""
     if np.issubdtype(signal.dtype, np.integer):

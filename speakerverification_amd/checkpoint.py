@@ -132,8 +132,20 @@ def read_blob(path):
         lib.svhip_blob_close(b)
 
 
+FUSION_MODELS = {"Raw_ECAPA_sinc_asp": (("ECAPA_TDNN.", "ECAPA_TDNN", ".ecapa"), ("rawnet2v2.", "RawNet2_custom", ".rawnet2"))}
+
+
+def fusion_blob_paths(dst, model="Raw_ECAPA_sinc_asp"):
+    """the two branch blobs a fusion checkpoint converts to: (ECAPA path, RawNet2 path)"""
+    return tuple(str(dst) + suffix for _, _, suffix in FUSION_MODELS[model])
+
+
 def convert_checkpoint(src, dst, model) -> int:
-    """Reference checkpoint file (torch pickle) or state dict -> blob at ``dst``.  Returns the number of tensors written."""
+    """Reference checkpoint file (torch pickle) or state dict -> blob at ``dst``.  Returns the number of tensors written.
+
+    A fusion checkpoint (``model='Raw_ECAPA_sinc_asp'``: keys ``__S__.ECAPA_TDNN.*`` / ``__S__.rawnet2v2.*``,
+    Raw_ECAPA_sinc_asp.py:22-28) becomes one blob per branch, ``dst + '.ecapa'`` and ``dst + '.rawnet2'`` — a handle is one
+    network, and ``Raw_ECAPA.load_blob(dst)`` reads the pair back."""
     if isinstance(src, (str, bytes)) or hasattr(src, "__fspath__"):
         import torch  # host-side only: the one place a pickle is read
         state = torch.load(src, map_location="cpu")     # the reference's 'cpu:0' is rejected by current torch (DESIGN.md §2)
@@ -142,6 +154,18 @@ def convert_checkpoint(src, dst, model) -> int:
     else:
         state = src
     sd = embedding_state_dict(state)
+    if model in FUSION_MODELS:
+        total = 0
+        for prefix, branch, suffix in FUSION_MODELS[model]:
+            sub = OrderedDict((k[len(prefix):], v) for k, v in sd.items() if k.startswith(prefix))
+            if not sub:
+                raise ValueError(f"{model}: the checkpoint holds no '{prefix}*' tensors")
+            write_blob(str(dst) + suffix, branch, sub)
+            total += len(sub)
+        return total
+    if any(k.startswith(("ECAPA_TDNN.", "rawnet2v2.")) for k in sd):
+        raise ValueError("this is a fusion checkpoint (ECAPA_TDNN.* / rawnet2v2.* keys): convert it with "
+                         "model='Raw_ECAPA_sinc_asp' (one blob per branch)")
     write_blob(dst, model, sd)
     return len(sd)
 
@@ -150,7 +174,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("src")
     ap.add_argument("dst")
-    ap.add_argument("--model", default="ECAPA_TDNN", help="reference model name (ECAPA_TDNN, RawNet2_custom)")
+    ap.add_argument("--model", default="ECAPA_TDNN", help="reference model name (ECAPA_TDNN, RawNet2_custom, Raw_ECAPA_sinc_asp)")
     a = ap.parse_args(argv)
     n = convert_checkpoint(a.src, a.dst, a.model)
     print(f"{a.dst}: {n} tensors")

@@ -124,6 +124,7 @@ struct svhip_handle {
     std::vector<PendingEvent> ev_pending;
     std::vector<ProfEntry> prof_entries;
     double flops_per_utt = 0;
+    void* comm = nullptr;                     // RCCL communicator state, owned by comm.hip
 };
 
 namespace {
@@ -924,6 +925,21 @@ int finish(svhip_handle* h, int flags) {
 
 }  // namespace
 
+namespace svhip {
+hipStream_t handle_stream(svhip_handle* h) { return h->stream; }
+int handle_device(const svhip_handle* h) { return h->cfg.device; }
+void handle_set_error(svhip_handle* h, const char* msg) { h->err = msg ? msg : ""; }
+void*& handle_comm(svhip_handle* h) { return h->comm; }
+int handle_run(svhip_handle* h, const char* label, const std::function<hipError_t()>& launch) {
+    const std::string keep = h->err;             // a failing launch may have left a more specific message
+    h->err.clear();
+    h->cur = h->stream;
+    const int rc = run(h, label, 0, [&]() { return launch(); });
+    if (rc && !keep.empty() && h->err.empty()) h->err = keep;
+    return rc;
+}
+}  // namespace svhip
+
 // =====================================================================================================
 extern "C" {
 
@@ -992,6 +1008,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
 int svhip_destroy(svhip_handle* h) {
     if (!h) return SVHIP_OK;
     (void)hipSetDevice(h->cfg.device);
+    if (h->comm) (void)svhip_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     prof_collect(h);
@@ -1010,7 +1027,8 @@ int svhip_synchronize(svhip_handle* h) {
 }
 
 int svhip_load_tensor(svhip_handle* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype) {
-    if (!h || !name || (!data && ndim > 0)) return SVHIP_ERR_INVALID;
+    if (!h || !name || !shape || ndim < 0 || ndim > 4) return SVHIP_ERR_INVALID;
+    if (!data) SV_FAIL(h, SVHIP_ERR_INVALID, "null data for %s (a 0-d tensor still holds one element)", name);
     if (h->finalized) SV_FAIL(h, SVHIP_ERR_STATE, "weights already finalized");
     std::map<std::string, std::vector<int64_t>> spec;
     model_spec(h->cfg, spec);
@@ -1171,6 +1189,28 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
     cleanup();
     if (rc) return rc;
     if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "crop copy-out failed: %s", hipGetErrorString(e));
+    return SVHIP_OK;
+}
+
+int svhip_synth_waveforms(svhip_handle* h, uint64_t seed, int64_t first_utt, int32_t B, int32_t L, float* wav_out, int32_t flags) {
+    if (!h || !wav_out || B <= 0 || L <= 0 || first_utt < 0) return SVHIP_ERR_INVALID;
+    if (L % 4 != 0) SV_FAIL(h, SVHIP_ERR_INVALID, "L=%d must be a multiple of 4", L);
+    if ((flags & SVHIP_ASYNC) && !(flags & SVHIP_OUT_DEVICE)) SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs device pointers");
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    float* d_out = wav_out;
+    void* tmp = nullptr;
+    if (!(flags & SVHIP_OUT_DEVICE)) {
+        SV_HIP(h, hipMalloc(&tmp, (size_t)B * L * 4));
+        d_out = reinterpret_cast<float*>(tmp);
+    }
+    h->cur = h->stream;
+    int rc = run(h, "synth_wave", 0, [&]() { return launch_synth_wave(d_out, seed, first_utt, B, L, h->stream); });
+    hipError_t e = hipSuccess;
+    if (!rc && tmp) e = hipMemcpyAsync(wav_out, d_out, (size_t)B * L * 4, hipMemcpyDeviceToHost, h->stream);
+    if (tmp || !(flags & SVHIP_ASYNC)) { const hipError_t e2 = hipStreamSynchronize(h->stream); if (e == hipSuccess) e = e2; }
+    if (tmp) (void)hipFree(tmp);
+    if (rc) return rc;
+    SV_HIP(h, e);
     return SVHIP_OK;
 }
 
@@ -1457,5 +1497,18 @@ int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap
     return SVHIP_OK;
 }
 double svhip_workload_flops(const svhip_handle* h) { return h ? h->flops_per_utt : 0.0; }
+
+// host-only self checks (no GPU needed): the per-device one-time flag every LDS-hungry launcher keeps
+int svhip_selftest(void) {
+    svhip::DeviceOnce once;
+    for (int d = -1; d < 66; ++d) if (once.done(d)) return 1;                 // nothing marked yet, out-of-range ordinals never are
+    once.mark(0);
+    if (!once.done(0) || once.done(1) || once.done(63)) return 2;            // device 0 set up says nothing about device 1
+    once.mark(5); once.mark(63); once.mark(64); once.mark(-3);                // out-of-range marks are ignored
+    if (!once.done(5) || !once.done(63) || once.done(64) || once.done(-3) || once.done(4)) return 3;
+    once.mark(0);
+    if (!once.done(0) || once.mask.load() != ((1ull << 0) | (1ull << 5) | (1ull << 63))) return 4;
+    return 0;
+}
 
 }  // extern "C"

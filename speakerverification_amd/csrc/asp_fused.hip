@@ -251,13 +251,8 @@ bool asp_fused_supported(int T, int C, int att_channels, int Kp) {
 
 hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream) {
     if (!asp_fused_supported(p.T, p.C, 128, p.Kp) || B <= 0 || p.ldx % 8 != 0) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(asp_fused_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(asp_fused_kernel), AF_LDS)) return e;
     hipLaunchKernelGGL(asp_fused_kernel, dim3(B), dim3(256), AF_LDS, stream, p);
     return hipGetLastError();
 }

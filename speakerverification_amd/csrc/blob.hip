@@ -161,10 +161,16 @@ int svhip_blob_open(const char* path, svhip_blob** out) {
         const Entry& e = b->tab[i];
         const size_t es = dtype_size((int32_t)e.dtype);
         if (!es || e.ndim > 4) return bad("tensor " + std::to_string(i) + ": bad dtype / rank");
-        uint64_t numel = 1;
-        for (int d = 0; d < 4; ++d) { if (e.shape[d] < 0) return bad("negative dimension"); numel *= (uint64_t)e.shape[d]; }
-        if (numel * es != e.nbytes) return bad("tensor " + std::to_string(i) + ": size does not match its shape");
-        if ((uint64_t)e.name_off + e.name_len > b->bytes || e.data_off + e.nbytes > b->bytes || (e.data_off & 63)) return bad("tensor " + std::to_string(i) + ": out of bounds");
+        // overflow-safe: a crafted table must not wrap u64 arithmetic into an in-bounds-looking range (FNV-1a is no integrity guarantee)
+        uint64_t numel = 1, want = 0;
+        for (int d = 0; d < 4; ++d) {
+            if (e.shape[d] < 0) return bad("negative dimension");
+            if (__builtin_mul_overflow(numel, (uint64_t)e.shape[d], &numel)) return bad("tensor " + std::to_string(i) + ": shape overflows");
+        }
+        if (__builtin_mul_overflow(numel, (uint64_t)es, &want) || want != e.nbytes) return bad("tensor " + std::to_string(i) + ": size does not match its shape");
+        const uint64_t total = b->bytes;
+        if (e.name_off > total || e.name_len > total - e.name_off || e.data_off > total || e.nbytes > total - e.data_off || (e.data_off & 63))
+            return bad("tensor " + std::to_string(i) + ": out of bounds");
         b->names[i].assign(reinterpret_cast<const char*>(b->base + e.name_off), e.name_len);
     }
     *out = b;

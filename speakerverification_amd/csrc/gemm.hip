@@ -256,13 +256,8 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     dim3 grid(ntm * ntn), block(256);
     const size_t lds = 4 * TILE_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {   // 64 KiB of dynamic LDS per workgroup
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, CONV, HAS_A2, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce attr;         // 64 KiB of dynamic LDS per workgroup, raised once per device
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_kernel<T, CONV, HAS_A2, EPI>), (int)lds)) return e;
     hipLaunchKernelGGL((gemm_kernel<T, CONV, HAS_A2, EPI>), grid, block, lds, stream, p);
     return hipGetLastError();
 }

@@ -302,13 +302,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
 template <typename T, int EPI, bool OUT_F32, int BN, bool CONV>
 hipError_t launch_inst2(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + PBM - 1) / PBM, ntn = (p.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<BN>::LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>), TileCfg<BN>::LDS)) return e;
     hipLaunchKernelGGL((gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>), dim3(ntm * ntn), dim3(512), TileCfg<BN>::LDS, stream, p);
     return hipGetLastError();
 }

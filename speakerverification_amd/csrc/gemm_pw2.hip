@@ -391,13 +391,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 template <int EPI, bool CONV>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, CONV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PW2_LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, CONV>), PW2_LDS)) return e;
     hipLaunchKernelGGL((gemm_pw2_kernel<EPI, CONV>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
 }

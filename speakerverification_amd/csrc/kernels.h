@@ -3,7 +3,42 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <functional>
+
+struct svhip_handle;
+
 namespace svhip {
+
+// ---------------------------------------------------------------------------------------------
+// Handle accessors for the translation units that do not see the handle's definition (api.hip owns it)
+// ---------------------------------------------------------------------------------------------
+hipStream_t handle_stream(svhip_handle* h);
+int handle_device(const svhip_handle* h);
+void handle_set_error(svhip_handle* h, const char* msg);
+void*& handle_comm(svhip_handle* h);            // opaque slot owned by comm.hip
+// profiling-aware launch (the same event bracketing api.hip's own launches get); returns an svhip_status
+int handle_run(svhip_handle* h, const char* label, const std::function<hipError_t()>& launch);
+
+// ---------------------------------------------------------------------------------------------
+// One-time per-DEVICE setup flag.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function on the
+// CURRENT device only, so a launcher that raises a kernel's LDS limit keeps one bit per device ordinal (a process may
+// own handles on several GPUs).  Lock-free: two threads racing on the same device both set the (idempotent) attribute.
+// ---------------------------------------------------------------------------------------------
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1u); }
+    void mark(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+inline hipError_t set_max_dynamic_lds(DeviceOnce& once, const void* fn, int bytes) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (once.done(dev)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) once.mark(dev);
+    return e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Tiled MFMA GEMM with fused conv-gather prologue and bias/activation/BN epilogue.
@@ -167,6 +202,9 @@ hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* 
                                 hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
                                 void* pre = nullptr, float slope = 0.3f);
 hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
+
+// synthetic waveforms from a counter-based RNG (synth.hip): out (B, L) fp32 = utterances [first_utt, first_utt + B) of the stream `seed`
+hipError_t launch_synth_wave(float* out, uint64_t seed, int64_t first_utt, int B, int L, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Scoring

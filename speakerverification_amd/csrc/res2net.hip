@@ -226,13 +226,8 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 
 template <int CW>
 hipError_t launch_cw(const Res2Params& p, int B, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(res2net_chain_kernel<CW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, R2Cfg<CW>::LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(res2net_chain_kernel<CW>), R2Cfg<CW>::LDS)) return e;
     hipLaunchKernelGGL(res2net_chain_kernel<CW>, dim3(B), dim3(512), R2Cfg<CW>::LDS, stream, p);
     return hipGetLastError();
 }

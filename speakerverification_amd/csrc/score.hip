@@ -327,12 +327,8 @@ hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int to
     if (rpw < 1) return hipErrorInvalidValue;          // K > 38400: not supported by the LDS-resident selection
     if (rpw > 4) rpw = 4;
     const size_t lds = row_bytes * rpw;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(topk_stats_kernel), 160 * 1024)) return e;
     hipLaunchKernelGGL(topk_stats_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(256), lds, stream, S, rows, K, ld, Kp, top, rpw, mu, sigma);
     return hipGetLastError();
 }

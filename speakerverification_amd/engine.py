@@ -22,13 +22,27 @@ def _is_torch(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+# bytes that crossed PCIe through this module since import (host buffers handed to / filled by the library); tests use it
+# to assert WHAT travels (e.g. int16 PCM instead of fp32 crops), bench.py to report PCIe-inclusive rates
+TRANSFER_STATS = {"h2d_bytes": 0, "d2h_bytes": 0}
+
+
+def _count(inputs=(), outputs=()):
+    for b in inputs:
+        if not b.device:
+            TRANSFER_STATS["h2d_bytes"] += b.nbytes
+    for b in outputs:
+        if not b.device:
+            TRANSFER_STATS["d2h_bytes"] += b.nbytes
+
+
 class _Buf:
     """Pointer view of a numpy array (host) or a torch tensor (host or device)."""
 
     def __init__(self, x, dtype, writable=False):
         self.keep = x
         if _is_torch(x):
-            tdt = {np.float32: torch.float32, np.int32: torch.int32}[dtype]
+            tdt = {np.float32: torch.float32, np.int32: torch.int32, np.int16: torch.int16, np.int64: torch.int64}[dtype]
             if x.dtype != tdt or not x.is_contiguous():
                 if writable:
                     raise ValueError("output tensors must be contiguous and of the right dtype")
@@ -36,6 +50,7 @@ class _Buf:
                 self.keep = x
             self.device = x.is_cuda
             self.ptr = x.data_ptr()
+            self.nbytes = x.numel() * x.element_size()
         else:
             a = np.asarray(x)
             if a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
@@ -45,6 +60,7 @@ class _Buf:
             self.keep = a
             self.device = False
             self.ptr = a.ctypes.data
+            self.nbytes = a.nbytes
 
 
 class Engine:
@@ -170,6 +186,7 @@ class Engine:
             out = self._out(wav, (B, self.n_mels, self.frames))
         i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
         self._order_after_torch(i, o, async_=async_)
+        _count([i], [o])
         self._ck(self.lib.svhip_fbank(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
@@ -181,6 +198,7 @@ class Engine:
             out = self._out(feat, (B, self.embed_dim))
         i, o = _Buf(feat, np.float32), _Buf(out, np.float32, writable=True)
         self._order_after_torch(i, o, async_=async_)
+        _count([i], [o])
         self._ck(self.lib.svhip_embed_features(self.h, i.ptr, B, T, o.ptr, self._flags(i, o, async_)))
         return out
 
@@ -190,19 +208,73 @@ class Engine:
             out = self._out(wav, (B, self.embed_dim))
         i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
         self._order_after_torch(i, o, async_=async_)
+        _count([i], [o])
         self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
-    def crop_pcm16(self, pcm_list, num_eval, L=32000):
+    def crop_pcm16(self, pcm_list, num_eval, L=32000, out=None):
         """list of 1-D int16 arrays (decoded files) -> (len(list) * num_eval, L) fp32 eval-mode crops, cropped on
-        the device (int16 travels over PCIe; reference semantics of loadWAV for 16-bit files)."""
+        the device (int16 travels over PCIe; reference semantics of loadWAV for 16-bit files).  With ``out`` a CUDA
+        tensor the crops stay in HBM (the embed call then takes them as a device pointer: no fp32 crop crosses PCIe)."""
         lens = np.asarray([len(a) for a in pcm_list], dtype=np.int32)
         offs = np.zeros(len(pcm_list), dtype=np.int64)
         offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
         pcm = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int16) for a in pcm_list]))
-        out = np.empty((len(pcm_list) * num_eval, L), dtype=np.float32)
+        n = len(pcm_list) * num_eval
+        if out is None:
+            out = np.empty((n, L), dtype=np.float32)
+        elif tuple(out.shape) != (n, L):
+            raise ValueError(f"out must be ({n}, {L})")
+        o = _Buf(out, np.float32, writable=True)
+        self._order_after_torch(o)
+        TRANSFER_STATS["h2d_bytes"] += pcm.nbytes + offs.nbytes + lens.nbytes
+        _count([], [o])
         self._ck(self.lib.svhip_crop_pcm16(self.h, pcm.ctypes.data, pcm.size, offs.ctypes.data, lens.ctypes.data, len(pcm_list),
-                                           int(num_eval), int(L), out.ctypes.data, 0))
+                                           int(num_eval), int(L), o.ptr, _lib.OUT_DEVICE if o.device else 0))
+        return out
+
+    def synth_waveforms(self, seed, first_utt, B, L=None, out=None, async_=False):
+        """utterances [first_utt, first_utt + B) of the counter-based synthetic stream ``seed`` (svhip_synth_waveforms)."""
+        L = int(L or self.samples)
+        if out is None:
+            out = np.empty((B, L), dtype=np.float32)
+        o = _Buf(out, np.float32, writable=True)
+        self._order_after_torch(o, async_=async_)
+        _count([], [o])
+        flags = (_lib.OUT_DEVICE if o.device else 0) | (_lib.ASYNC if async_ else 0)
+        self._ck(self.lib.svhip_synth_waveforms(self.h, int(seed), int(first_utt), int(B), L, o.ptr, flags))
+        return out
+
+    # ---- multi-GPU exchange (RCCL under the C ABI) -------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = lib.svhip_comm_unique_id(buf)
+        if rc != _lib.OK:
+            raise _lib.SvhipError(rc, (lib.svhip_comm_last_error() or b"?").decode())
+        return buf.raw
+
+    def comm_init(self, id_bytes: bytes, rank: int, world: int):
+        if len(id_bytes) != _lib.COMM_ID_BYTES:
+            raise ValueError("the RCCL unique id is %d bytes" % _lib.COMM_ID_BYTES)
+        self._ck(self.lib.svhip_comm_init(self.h, C.create_string_buffer(id_bytes, _lib.COMM_ID_BYTES), int(rank), int(world)))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def allgather_rows(self, local, out=None, async_=False):
+        """(rows, D) fp32 block of every rank -> (world * rows, D) on every rank: ONE RCCL all-gather on the handle's stream."""
+        rows, D = local.shape
+        world = getattr(self, "comm_world", None)
+        if world is None:
+            raise RuntimeError("comm_init has not been called on this Engine")
+        if out is None:
+            out = self._out(local, (world * rows, D))
+        i, o = _Buf(local, np.float32), _Buf(out, np.float32, writable=True)
+        if tuple(out.shape) != (world * rows, D):
+            raise ValueError(f"out must be ({world * rows}, {D})")
+        self._order_after_torch(i, o, async_=async_)
+        _count([i], [o])
+        self._ck(self.lib.svhip_allgather_rows(self.h, i.ptr, rows, D, o.ptr, self._flags(i, o, async_)))
         return out
 
     # ---- scoring ---------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ import numpy as np
 
 from . import distributed as sv_dist
 from . import scoring
-from .audio import loadWAV
+from .audio import loadWAV, read_pcm16
 from .engine import _is_torch
 
 try:
@@ -154,7 +154,9 @@ class ModelHandling:
         self.criterion = self.__model__.module.criterion["name"]
         self.gpu = gpu
         self.device = f"{device}:{gpu}"
-        self.embed_batch = int(kwargs.get("embed_batch", 64))      # crops per device call
+        self.embed_batch = int(kwargs.get("embed_batch", 256))     # crops per device call (cross-file batching)
+        self.device_crop = bool(kwargs.get("device_crop", True))   # 16-bit PCM files: crop on the device (svhip_crop_pcm16)
+        self._libcomm = None                                       # RCCL communicator under the C ABI (distributed eval)
 
     # ---- training-only surface ---------------------------------------------------------------------------
     def fit(self, *a, **k):
@@ -173,41 +175,83 @@ class ModelHandling:
             outs.append(o.reshape(-1, o.shape[-1]))
         return np.concatenate(outs, 0)
 
+    def _device_path_ok(self, num_eval):
+        """the device crop -> embed path needs fixed-length crops, a GPU, and a model that takes raw waveforms on the device"""
+        if not self.device_crop or num_eval <= 0 or torch is None or not torch.cuda.is_available():
+            return False
+        enc = self.__model__.module
+        S = getattr(enc, "__S__", None)
+        if S is None:
+            return False
+        if enc.features == "raw":
+            return callable(getattr(S, "forward", None)) and getattr(S, "accepts_device_wave", False)
+        return hasattr(S, "embed_wave") and enc._fusable()
+
     def _embed_files(self, files, num_eval):
         """crops of several files travel in one batch (the reference runs one file per forward,
-        src/model.py:386-394).  Returns {file: (num_eval, nOut)} via a dense (n_files, num_eval, nOut) block."""
-        feats = None
-        pending, owners = [], []
+        src/model.py:386-394).  Returns a dense (n_files, num_eval, nOut) float32 block.
 
-        def flush():
+        16-bit PCM files take the device path: the int16 samples are uploaded once, `svhip_crop_pcm16` cuts the eval-mode
+        crops (audio_loader.py:110-150) straight into an HBM buffer, and the embed call consumes that buffer as a device
+        pointer in batches of `embed_batch` crops across files — no fp32 crop crosses PCIe; only embeddings come back.
+        Other sources (float / 24-bit files, ndarrays, num_eval == 0) keep the host path (loadWAV)."""
+        feats = None
+        max_audio = int(self.audio_spec["sentence_len"] * self.audio_spec["sample_rate"])
+        use_dev = self._device_path_ok(num_eval)
+        pending, owners = [], []            # host path: fp32 crops
+        pcm_pending, pcm_owners = [], []    # device path: int16 files
+
+        def store(idx_n, emb):
             nonlocal feats
-            if not pending:
-                return
-            emb = self._embed_crops(np.concatenate(pending, 0))
             if feats is None:
                 feats = np.zeros((len(files), max(1, num_eval), emb.shape[-1]), np.float32)
             pos = 0
-            for idx, n in owners:
+            for idx, n in idx_n:
                 feats[idx, :n] = emb[pos:pos + n]
                 pos += n
-            pending.clear()
-            owners.clear()
+
+        def flush():
+            if pending:
+                store(owners, self._embed_crops(np.concatenate(pending, 0)))
+                pending.clear()
+                owners.clear()
+
+        def flush_pcm():
+            if not pcm_pending:
+                return
+            eng = scoring.scoring_engine(self.gpu)
+            n = len(pcm_pending) * num_eval
+            crops = torch.empty((n, max_audio), dtype=torch.float32, device=f"cuda:{self.gpu}")
+            eng.crop_pcm16(pcm_pending, num_eval, max_audio, out=crops)
+            outs = []
+            for i in range(0, n, self.embed_batch):
+                o = self.__model__.forward(crops[i:i + self.embed_batch])
+                outs.append(o.reshape(-1, o.shape[-1]))
+            emb = torch.cat(outs, 0).cpu().numpy() if len(outs) > 1 else outs[0].cpu().numpy()
+            store(pcm_owners, emb)
+            pcm_pending.clear()
+            pcm_owners.clear()
 
         for idx, f in enumerate(files):
+            pcm = read_pcm16(f, self.audio_spec["sample_rate"]) if (use_dev and isinstance(f, (str, Path))) else None
+            if pcm is not None:
+                pcm_pending.append(pcm)
+                pcm_owners.append((idx, num_eval))
+                if len(pcm_pending) * num_eval >= self.embed_batch:
+                    flush_pcm()
+                continue
             audio = loadWAV(f, self.audio_spec, evalmode=True, augment=False, augment_options=[], num_eval=num_eval,
                             random_chunk=False)
             if num_eval == 0:                       # whole file: variable length, one forward per file
                 flush()
-                emb = self._embed_crops(audio)
-                if feats is None:
-                    feats = np.zeros((len(files), 1, emb.shape[-1]), np.float32)
-                feats[idx, :1] = emb
+                store([(idx, 1)], self._embed_crops(audio))
                 continue
             pending.append(audio)
             owners.append((idx, audio.shape[0]))
             if sum(n for _, n in owners) >= self.embed_batch:
                 flush()
         flush()
+        flush_pcm()
         return feats
 
     def embed_utterance(self, source, num_eval=20, normalize=False):
@@ -228,11 +272,19 @@ class ModelHandling:
             scoring.scoring_engine(self.gpu).l2norm_(flat)                  # F.normalize(p=2, dim=1), model.py:421-423
             feats = flat.reshape(feats.shape)
         if cohorts_path is None:
-            # model.py:425-431: F.pairwise_distance(ref (n,D,1), com (1,D,n)) takes the 2-norm over the LAST
-            # axis of the broadcast (n, D, n) difference, i.e. over the crops of `com`; score = -mean(dist)
-            r, c = feats[ia].astype(np.float64), feats[ib].astype(np.float64)          # (P, n, D)
-            d = r[:, :, :, None] - np.transpose(c, (0, 2, 1))[:, None, :, :] + 1e-6   # (P, n, D, n)
-            return (-np.sqrt((d * d).sum(-1)).mean(axis=(1, 2))).astype(np.float32)
+            # model.py:425-431: F.pairwise_distance(ref (n,D,1), com (1,D,n)) takes the 2-norm over the LAST axis of the
+            # broadcast (n, D, n) difference, i.e. over the crops j of `com`: dist[i,d] = sqrt(sum_j (r[i,d] + eps - c[j,d])^2),
+            # score = -mean(dist).  Expanded: n a^2 - 2 a sum_j c_j + sum_j c_j^2 with a = r + eps, which needs O(P n D)
+            # memory instead of the O(P n D n) broadcast (a 580 k-trial validation list would need ~180 GB that way).
+            out = np.empty(len(ia), np.float32)
+            n = feats.shape[1]
+            for p0 in range(0, len(ia), 4096):
+                a = feats[ia[p0:p0 + 4096]].astype(np.float64) + 1e-6                   # (P, n, D)
+                c = feats[ib[p0:p0 + 4096]].astype(np.float64)
+                s1, s2 = c.sum(axis=1)[:, None, :], (c * c).sum(axis=1)[:, None, :]
+                q = n * a * a - 2.0 * a * s1 + s2
+                out[p0:p0 + 4096] = -np.sqrt(np.maximum(q, 0.0)).mean(axis=(1, 2))
+            return out
         if scoring_mode == "norm":
             return scoring.score_trials(feats, ia, ib, "norm", cohorts=cohorts, top=200, device=self.gpu)
         if scoring_mode == "cosine":
@@ -256,33 +308,59 @@ class ModelHandling:
         rank, world = sv_dist.rank_world() if distributed else (0, 1)
         lo, hi, _ = sv_dist.shard_bounds(len(setfiles), rank, world)
         local = self._embed_files(setfiles[lo:hi], num_eval)
-        if world > 1:
+        if distributed and sv_dist.is_distributed():
             nOut = self.__model__.module.model["nOut"]
             if local is None:
                 local = np.zeros((0, max(1, num_eval), nOut), np.float32)
-            t = torch.from_numpy(local)
-            if torch.distributed.get_backend() == "nccl":
-                t = t.cuda(self.gpu)
-            feats = sv_dist.all_gather_rows(t, len(setfiles)).cpu().numpy()      # ONE collective (reference: all_gather_object)
+            feats = self._gather_rows(local, len(setfiles))            # ONE collective (reference: all_gather_object)
         else:
             feats = local
         all_scores, all_labels, all_trials = [], [], []
-        if rank == 0:
-            index = {str(Path(f)): i for i, f in enumerate(setfiles)}
-            index.update({f: i for i, f in enumerate(setfiles)})
-            ia, ib = [], []
-            for line in lines[start_index:]:
-                data = line.strip().split(determinator) if determinator == "," else line.split()
-                if len(data) < 3:
-                    continue
-                data = data[-3:]
-                ia.append(index[data[1]])
-                ib.append(index[data[2]])
-                all_labels.append(int(data[0]))
-                all_trials.append(data[1] + " " + data[2])
-            s = self._score(feats, np.asarray(ia, np.int32), np.asarray(ib, np.int32), scoring_mode, cohorts, cohorts_path)
+        index = {str(Path(f)): i for i, f in enumerate(setfiles)}
+        index.update({f: i for i, f in enumerate(setfiles)})
+        ia, ib = [], []
+        for line in lines[start_index:]:
+            data = line.strip().split(determinator) if determinator == "," else line.split()
+            if len(data) < 3:
+                continue
+            data = data[-3:]
+            ia.append(index[data[1]])
+            ib.append(index[data[2]])
+            all_labels.append(int(data[0]))
+            all_trials.append(data[1] + " " + data[2])
+        ia, ib = np.asarray(ia, np.int32), np.asarray(ib, np.int32)
+        if kwargs.get("shard_scoring") and world > 1:
+            # row-sharded scoring: every rank scores the trials whose enrol file sits in its block; the
+            # P floats are then assembled with a second, small all-gather
+            mine = sv_dist.trial_rows_of_rank(ia, len(setfiles), rank, world)
+            s_loc = self._score(feats, ia[mine], ib[mine], scoring_mode, cohorts, cohorts_path)
+            counts = [len(sv_dist.trial_rows_of_rank(ia, len(setfiles), r, world)) for r in range(world)]
+            per = max(1, max(counts))
+            pad = np.zeros((per, 1), np.float32)
+            pad[:len(s_loc), 0] = s_loc
+            allp = self._gather_rows(pad, per * world, exact=True).reshape(world, per)
+            if rank == 0:
+                s = np.empty(len(ia), np.float32)
+                for r in range(world):
+                    s[sv_dist.trial_rows_of_rank(ia, len(setfiles), r, world)] = allp[r, :counts[r]]
+                all_scores = [float(v) for v in s]
+        elif rank == 0:
+            s = self._score(feats, ia, ib, scoring_mode, cohorts, cohorts_path)
             all_scores = [float(v) for v in s]
+        if rank != 0:
+            return [], [], []
         return all_scores, all_labels, all_trials
+
+    def _gather_rows(self, local: np.ndarray, n_total: int, exact=False) -> np.ndarray:
+        """the path's exchange step.  On GPUs: RCCL under the C ABI (svhip_allgather_rows on the scoring engine's stream;
+        torch.distributed only ships the RCCL id once).  Without a GPU (gloo CPU tests): torch.distributed all_gather_into_tensor.
+        exact=True: every rank passes exactly n_total / world rows."""
+        rank, world = sv_dist.rank_world()
+        if torch is not None and torch.cuda.is_available():
+            if self._libcomm is None:
+                self._libcomm = sv_dist.LibComm(scoring.scoring_engine(self.gpu), rank, world)
+            return self._libcomm.all_gather_rows(np.ascontiguousarray(local, np.float32), n_total)
+        return sv_dist.all_gather_rows(torch.from_numpy(np.ascontiguousarray(local)), n_total).numpy()
 
     def testFromList(self, test_list="evaluation_test.txt", thresh_score=0.5, distributed=False, dataloader_options=None,
                      cohorts_path=None, num_eval=10, scoring_mode="norm", output_file=None):

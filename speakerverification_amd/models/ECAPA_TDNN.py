@@ -16,7 +16,7 @@ class ECAPA_TDNN(HipModule):
 
     def __init__(self, input_size=80, lin_neurons=192, activation=None, channels=(1024, 1024, 1024, 1024, 3072),
                  kernel_sizes=(5, 3, 3, 3, 1), dilations=(1, 2, 3, 4, 1), attention_channels=128, res2net_scale=8,
-                 se_channels=128, input_norm=False, global_context=True, device=None, compute=None, max_batch=64,
+                 se_channels=128, input_norm=False, global_context=True, device=None, compute=None, max_batch=None,
                  **kwargs):
         channels = list(channels)
         C = channels[0]
@@ -38,9 +38,15 @@ class ECAPA_TDNN(HipModule):
         compute = compute or kwargs.get("hip_compute", "f32")
         hop = kwargs.get("hop_length", 80)
         self._hop = hop
+        # the mel front-end of the fused waveform path takes the same keywords the reference's feature factory reads
+        # from the config (models/FeatureExtraction/feature.py:66-71), so an overriding YAML changes both consistently
+        fe = {k: kwargs[k] for k in ("sr", "n_fft", "win_length", "fmin", "fmax", "pre_emphasis") if k in kwargs}
+        if kwargs.get("window", "hamming") != "hamming":
+            raise NotImplementedError("only the hamming window of feature.py:68 is built")
+        max_batch = int(max_batch or kwargs.get("embed_batch", 256))
         super().__init__(synth.ecapa_param_spec(C=C, n_mels=n_mels, nOut=lin_neurons, input_norm=self.input_norm),
                          dict(channels=C, n_mels=n_mels, embed_dim=lin_neurons, log_input=self.log_input,
-                              input_norm=self.input_norm, hop_length=hop),
+                              input_norm=self.input_norm, hop_length=hop, **fe),
                          device=device if device is not None else kwargs.get("device"), compute=compute,
                          max_batch=max_batch)
 
@@ -50,13 +56,13 @@ class ECAPA_TDNN(HipModule):
         if x.ndim != 3:
             raise ValueError(f"expected (batch, n_mels, frames), got {tuple(x.shape)}")
         T = x.shape[2]
-        eng = self._get_engine((T - 1) * self._hop)
-        return self._squeeze(self._batched(eng.embed_features, x))
+        eng = self._get_engine((T - 1) * self._hop, batch=x.shape[0])
+        return self._squeeze(self._batched(eng.embed_features, x, eng.max_batch))
 
     def embed_wave(self, wav):
         """fused waveform -> embedding (fbank + forward in one library call)"""
-        eng = self._get_engine(wav.shape[1])
-        return self._squeeze(self._batched(eng.embed_wave, wav))
+        eng = self._get_engine(wav.shape[1], batch=wav.shape[0])
+        return self._squeeze(self._batched(eng.embed_wave, wav, eng.max_batch))
 
 
 def MainModel(nOut=512, **kwargs):

@@ -17,7 +17,7 @@ class RawNet2(HipModule):
     model_kind = "rawnet2"
 
     def __init__(self, nOut=512, front_proc="sinc", aggregate="gru", att_dim=128, audio_spec=None, device=None,
-                 compute=None, max_batch=32, **kwargs):
+                 compute=None, max_batch=None, **kwargs):
         if front_proc != "sinc" or aggregate != "asp" or att_dim != 128:
             raise NotImplementedError("only front_proc='sinc', aggregate='asp', att_dim=128 is built "
                                       "(the variant of Raw_ECAPA_sinc_asp.py:26-28)")
@@ -26,6 +26,7 @@ class RawNet2(HipModule):
             raise NotImplementedError("the sinc front-end is built for sample_rate 16000 (RawNet2_custom.py:55-63)")
         self.nb_samp = int(audio_spec["sentence_len"] * audio_spec["sample_rate"])      # LayerNorm(nb_samp), :58-60
         compute = compute or kwargs.get("hip_compute", "f32")
+        max_batch = int(max_batch or kwargs.get("embed_batch", 256))
         super().__init__(synth.rawnet2_param_spec(nOut=nOut, nb_samp=self.nb_samp, att_dim=att_dim),
                          dict(embed_dim=nOut), device=device if device is not None else kwargs.get("device"),
                          compute=compute, max_batch=max_batch)

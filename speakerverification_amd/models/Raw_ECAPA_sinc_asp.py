@@ -26,6 +26,8 @@ except Exception:  # pragma: no cover
 
 
 class Raw_ECAPA:
+    accepts_device_wave = True      # both branches take CUDA tensors as raw device pointers
+
     def __init__(self, nOut=512, **kwargs):
         kw = dict(kwargs)
         kw.pop("channels", None)
@@ -66,6 +68,12 @@ class Raw_ECAPA:
         m1 = self.ECAPA_TDNN.load_state_dict(e, strict=strict)
         m2 = self.rawnet2v2.load_state_dict(r, strict=strict)
         return m1, m2
+
+    def load_blob(self, path):
+        """the pair of branch blobs checkpoint.convert_checkpoint(..., model='Raw_ECAPA_sinc_asp') wrote for `path`"""
+        from .. import checkpoint
+        p_ecapa, p_rawnet2 = checkpoint.fusion_blob_paths(path)
+        return self.ECAPA_TDNN.load_blob(p_ecapa), self.rawnet2v2.load_blob(p_rawnet2)
 
     def forward(self, x):
         out1 = self.ECAPA_TDNN.embed_wave(x)          # compute_features + ECAPA_TDNN (Raw_ECAPA_sinc_asp.py:41-44)

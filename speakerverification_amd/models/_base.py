@@ -29,8 +29,10 @@ class HipModule:
     180,209-210,235,332,712): forward/__call__, to, eval, train, parameters, state_dict, load_state_dict."""
 
     model_kind = "ecapa"
+    accepts_device_wave = True      # forward / embed_wave take CUDA tensors as raw device pointers (no host copy)
+    ENGINE_CACHE = 3                # handles kept alive at once (one per input geometry)
 
-    def __init__(self, spec, engine_kwargs, device=None, compute="f32", max_batch=64, seed=0):
+    def __init__(self, spec, engine_kwargs, device=None, compute="f32", max_batch=256, seed=0):
         from .. import synth
         self._spec = OrderedDict((n, tuple(s)) for n, s in spec)
         self._sd = synth.synth_state_dict(spec, seed=seed)        # random init, like a fresh nn.Module
@@ -38,8 +40,8 @@ class HipModule:
         self._compute = compute
         self._max_batch = int(max_batch)
         self._device = _device_index(device)
-        self._engine = None
-        self._engine_key = None
+        self._engines = OrderedDict()           # key -> Engine, most recently used last
+        self._primary = None                    # the geometry (samples) that gets the full max_batch workspace
         self.training = False
 
     # ---- nn.Module look-alikes --------------------------------------------------------------------
@@ -102,33 +104,51 @@ class HipModule:
 
     # ---- engine management ----------------------------------------------------------------------------
     def _drop_engine(self):
-        if self._engine is not None:
-            self._engine.close()
-        self._engine = None
-        self._engine_key = None
+        for eng in self._engines.values():
+            eng.close()
+        self._engines.clear()
+        self._primary = None
 
-    def _get_engine(self, samples, stream=None):
-        key = (samples, self._device, self._compute, stream)
-        if self._engine is None or self._engine_key != key:
-            self._drop_engine()
-            eng = Engine(model=self.model_kind, compute=self._compute, max_batch=self._max_batch, samples=samples,
+    @property
+    def _engine(self):
+        """the most recently used handle (tests read stage tensors / profiles from it)"""
+        return next(reversed(self._engines.values())) if self._engines else None
+
+    def _get_engine(self, samples, stream=None, batch=None):
+        """One handle per input geometry.  The FIRST geometry seen (the fixed-length crops of evaluation) gets the full
+        `max_batch` workspace; any other length (whole-file evaluation, num_eval == 0: one forward per file, every file its
+        own length) gets a workspace sized for the rows of that call, and at most ENGINE_CACHE handles stay alive — a
+        one-minute file no longer allocates a max_batch x 10^4-frame workspace, and a repeated length is not rebuilt."""
+        if self._primary is None:
+            self._primary = samples
+        mb = self._max_batch if samples == self._primary else max(1, min(self._max_batch, int(batch or 1)))
+        key = (samples, self._device, self._compute, stream, mb)
+        eng = self._engines.get(key)
+        if eng is None:
+            while len(self._engines) >= self.ENGINE_CACHE:
+                victim = next((k for k in self._engines if k[0] != self._primary), next(iter(self._engines)))
+                self._engines.pop(victim).close()
+            eng = Engine(model=self.model_kind, compute=self._compute, max_batch=mb, samples=samples,
                          device=self._device, stream=stream, **self._engine_kwargs)
             eng.load_state_dict(self._sd)
             eng.finalize()
-            self._engine, self._engine_key = eng, key
-        return self._engine
+            self._engines[key] = eng
+        else:
+            self._engines.move_to_end(key)
+        return eng
 
     @staticmethod
     def _squeeze(out):
         """the reference ends forward with x.squeeze() (ECAPA_TDNN.py:500, RawNet2_custom.py:226)"""
         return out.squeeze() if _is_torch(out) else np.squeeze(out)
 
-    def _batched(self, fn, x):
+    def _batched(self, fn, x, max_batch=None):
         """run fn over chunks of at most max_batch rows and concatenate"""
         B = x.shape[0]
-        if B <= self._max_batch:
+        mb = max_batch or self._max_batch
+        if B <= mb:
             return fn(x)
-        parts = [fn(x[i:i + self._max_batch]) for i in range(0, B, self._max_batch)]
+        parts = [fn(x[i:i + mb]) for i in range(0, B, mb)]
         return torch.cat(parts, 0) if _is_torch(parts[0]) else np.concatenate(parts, 0)
 
     def __call__(self, x, *a, **k):

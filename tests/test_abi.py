@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.svhip_abi_version() == 1
+    assert lib.svhip_abi_version() == 2
 
 
 def test_default_config_matches_reference_defaults():
@@ -61,3 +61,23 @@ def test_no_cpu_fallback():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_per_device_launch_attribute_bookkeeping():
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device; the launchers keep one flag bit per device
+    ordinal (csrc/kernels.h DeviceOnce).  svhip_selftest exercises that bookkeeping on the host."""
+    assert _lib.load().svhip_selftest() == 0
+    src = os.path.join(ROOT, "speakerverification_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith(".hip"):
+            text = open(os.path.join(src, f)).read()
+            assert "static bool attr" not in text, f        # no process-wide flags left
+            if "hipFuncSetAttribute" in text:
+                raise AssertionError(f"{f}: raise LDS limits through set_max_dynamic_lds (per-device)")
+
+
+def test_comm_entry_points_fail_cleanly_without_a_handle():
+    lib = _lib.load()
+    assert lib.svhip_comm_init(None, None, 0, 1) == -1
+    assert lib.svhip_allgather_rows(None, None, 0, 0, None, 0) == -1
+    assert lib.svhip_comm_destroy(None) == -1

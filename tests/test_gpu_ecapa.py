@@ -58,6 +58,11 @@ def test_ecapa_full_fp32_matches_reference(golden_dir, C):
     err = float(np.abs(out - ref).max())
     # tolerance: 1e-4 of the embedding scale (north_star: within 1e-4 fp32; embeddings here are O(100))
     assert err <= 1e-4 * max(1.0, scale), (err, scale)
+    # and ABSOLUTE 1e-4 on what scoring consumes: the L2-normalised embeddings (F.normalize, src/model.py:421-423)
+    nrm = lambda a: a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+    err_n = float(np.abs(nrm(out) - nrm(ref)).max())
+    print(f"C={C}: max|d_emb| = {err:.3e} (scale {scale:.1f}, relative {err / scale:.2e}); L2-normalised abs err {err_n:.3e}")
+    assert err_n <= 1e-4, err_n
     # stage checksums captured from the reference
     for n in STAGES:
         cs = g["cs_" + n]

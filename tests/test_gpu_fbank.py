@@ -48,6 +48,21 @@ def test_fbank_edges_and_device(eng):
     assert float(np.abs(got - ref).max()) <= 2e-6 * float(np.abs(ref).max())
 
 
+def test_fbank_matches_frozen_fixture(eng, golden_dir):
+    """the HIP front-end against the COMMITTED definition of record (tests/golden/fbank.npz), not the live oracle"""
+    import os
+    from oracle.make_fbank_fixture import impulse_wave
+    g = np.load(os.path.join(golden_dir, "fbank.npz"))
+    for name, wav in (("white", synth.synth_waveforms(1)), ("speech", synth.synth_speechlike(1)), ("impulse", impulse_wave())):
+        got = eng.fbank(wav)
+        ref = g[name + "_f64"]
+        peak = np.abs(ref).max(axis=(1, 2), keepdims=True)
+        assert float((np.abs(got - ref) / peak).max()) <= 2e-6, name
+        if name != "impulse":        # (an impulse leaves most frames at exactly zero power: log(1e-6) differences are meaningless there)
+            lg = o_fbank.log_mean_norm(torch.from_numpy(got).double()).numpy()
+            assert float(np.abs(lg - g[name + "_logmel_f64"]).max()) <= 1e-4, name
+
+
 @pytest.mark.parametrize("kind", ["white", "speechlike"])
 def test_fbank_bf16x3_split_path(kind):
     """bf16-compute handles run the DFT as hi/lo-split bf16 MFMAs (3 products): stated tolerance

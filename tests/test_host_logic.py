@@ -123,6 +123,44 @@ def test_test_from_list_and_prepare(fake_engine, tmp_path):
     assert np.abs(cohort[0] - exp0).max() < 1e-5
 
 
+def test_pairwise_distance_scoring_is_closed_form_and_memory_bounded(fake_engine, tmp_path):
+    """cohorts_path=None scoring (model.py:425-431, F.pairwise_distance over the broadcast (n, D, n) difference)
+    must equal the reference's per-trial value and must not materialise the (P, n, D, n) broadcast."""
+    import tracemalloc
+    import torch.nn.functional as F
+    mh, emb, spec = _make_handler(tmp_path)
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_files, n, D = 40, 10, 192
+    feats = rng.standard_normal((n_files, n, D)).astype(np.float32)
+    ia = rng.integers(0, n_files, 64).astype(np.int32)
+    ib = rng.integers(0, n_files, 64).astype(np.int32)
+    ib[:4] = ia[:4]                                   # a file against itself: the cancellation-prone case
+    got = mh._score(feats.copy(), ia, ib, "cosine", None, None)
+    fn = F.normalize(torch.from_numpy(feats).reshape(-1, D), p=2, dim=1).reshape(n_files, n, D)
+    want = [float(-torch.mean(F.pairwise_distance(fn[a].unsqueeze(-1), fn[b].unsqueeze(-1).transpose(0, 2)))) for a, b in zip(ia, ib)]
+    assert np.abs(got - np.array(want, np.float32)).max() < 2e-6
+    big = 60000                                       # the broadcast form would need 60000 * 10 * 192 * 10 * 8 B = 9.2 GB per temporary
+    ia2 = rng.integers(0, n_files, big).astype(np.int32)
+    ib2 = rng.integers(0, n_files, big).astype(np.int32)
+    tracemalloc.start()
+    out = mh._score(feats.copy(), ia2, ib2, "cosine", None, None)
+    _, peak = tracemalloc.get_traced_memory()
+    tracemalloc.stop()
+    assert out.shape == (big,) and np.isfinite(out).all()
+    assert peak < 1.5e9, peak
+
+
+def test_trial_rows_partition_the_list():
+    rng = np.random.Generator(np.random.PCG64(9))
+    for n, w in ((10, 3), (1000, 8), (7, 8)):
+        ia = rng.integers(0, n, 500)
+        rows = [sv_dist.trial_rows_of_rank(ia, n, r, w) for r in range(w)]
+        assert sorted(np.concatenate(rows).tolist()) == list(range(500))
+        for r in range(w):
+            lo, hi, _ = sv_dist.shard_bounds(n, r, w)
+            assert ((ia[rows[r]] >= lo) & (ia[rows[r]] < hi)).all()
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 9, 1000):
         for w in (1, 2, 3, 8):
@@ -153,7 +191,10 @@ def _gloo_worker(rank, world, port, tmp, q):
         mh, emb, spec = _make_handler(tmp)
         sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=True, dataloader_options={}, cohorts_path="x",
                                           num_eval=2, scoring_mode="cosine")
-        q.put((rank, ok1, sc, lab))
+        # 3. row-sharded scoring: every rank scores the trials of its enrol block, rank 0 assembles them
+        sc2, _, _ = mh.evaluateFromList(listfilename=trial_path, distributed=True, dataloader_options={}, cohorts_path="x",
+                                        num_eval=2, scoring_mode="cosine", shard_scoring=True)
+        q.put((rank, ok1, sc, lab, sc2))
     finally:
         dist.destroy_process_group()
 
@@ -170,13 +211,14 @@ def test_two_rank_gloo_sharded_evaluation(tmp_path):
         p.start()
     res = {}
     for _ in range(2):
-        rank, ok1, sc, lab = q.get(timeout=120)
-        res[rank] = (ok1, sc, lab)
+        rank, ok1, sc, lab, sc2 = q.get(timeout=120)
+        res[rank] = (ok1, sc, lab, sc2)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][0] and res[1][0]
     assert len(res[0][1]) == 28 and res[1][1] == []             # rank 0 scores, other ranks return empty lists
+    assert res[1][3] == [] and np.abs(np.array(res[0][3]) - np.array(res[0][1])).max() < 1e-6   # row-sharded == rank-0 scoring
     # single-process answer must match
     files, trial_path, lines = make_e2e_files(str(tmp_path / "single"))  if os.makedirs(tmp_path / "single", exist_ok=True) is None else None
     eng = fakes.FakeScoringEngine()
