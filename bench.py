@@ -64,6 +64,21 @@ def parse():
     return ap.parse_args()
 
 
+class quiet_stdout:
+    """fd-level stdout -> stderr while communicators come up: RCCL and gloo print banners on stdout, and stdout must carry
+    exactly ONE JSON line"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` outside a launcher: start the N ranks as a child torch.distributed.run BEFORE anything in this
     process touches the GPU, and hand its exit code back (never measures a single GPU under an N-GPU label)."""
@@ -375,7 +390,8 @@ class Ranks:
         self.launched = "WORLD_SIZE" in os.environ        # under a launcher the multi-rank code path runs even at world size 1
         if self.launched:
             import torch.distributed as dist
-            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            with quiet_stdout():
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
             self.dist = dist
 
     def barrier(self):
@@ -499,7 +515,8 @@ def run_batch(args, ranks, dev):
     label = dominant_label(args.model, args.compute)
     eng = make_engine(args.model, args.compute, B, local)
     embed = eng.embed_dim
-    comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+    with quiet_stdout():
+        comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
 
     # synthetic waveforms, resident in HBM before the timed region: NBATCH distinct batches per rank, rotated
     wavs = synth_batches(eng, NBATCH, B, rank * NBATCH * B, dev)
@@ -575,7 +592,8 @@ def run_shard(args, ranks, dev):
     n_local = args.utts_per_gpu
     label = dominant_label(args.model, args.compute)
     eng = make_engine(args.model, args.compute, B, local)
-    comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+    with quiet_stdout():
+        comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
     shard = torch.empty((n_local, eng.embed_dim), device=dev, dtype=torch.float32)
     wav = [torch.empty((B, SAMPLES), device=dev, dtype=torch.float32) for _ in range(2)]
     first = rank * n_local

@@ -94,6 +94,8 @@ struct svhip_handle {
     void* rn_buf[6] = {};                 // activation ping-pong buffers
     float* rn_scratch = nullptr;
     float *rn_stats = nullptr, *rn_mean = nullptr, *rn_s = nullptr, *rn_logits = nullptr, *rn_pooled = nullptr;
+    float* rn_part = nullptr;             // fused 128-channel blocks: per-tile column sums (B, ntiles, 128)
+    int num_cu = 256;
     int rn_T1 = 0;
     const void* rn_dbg_x = nullptr; int rn_dbg_T = 0, rn_dbg_C = 0;   // SVHIP_RN_STOP developer hook (tests)
 
@@ -642,9 +644,10 @@ int alloc_workspace(svhip_handle* h) {
             h->rn_buf[i] = q;
         }
         if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_part, B * (size_t)(rn_block128_ntiles(h->rn_T1) + 1) * 4 * 128))) return rc;
         if ((rc = dev_alloc(h, &h->rn_mean, B * 512))) return rc;
         if ((rc = dev_alloc(h, &h->rn_scratch, B * 16 * 512))) return rc;
-        if ((rc = dev_alloc(h, &h->rn_s, B * 512))) return rc;
+        if ((rc = dev_alloc(h, &h->rn_s, B * 512 * 2))) return rc;
         int tf = h->rn_T1;
         for (int i = 0; i < 6; ++i) tf /= 3;                      // six max_pool1d(3) stages follow the front-end
         if (tf < 1) SV_FAIL(h, SVHIP_ERR_INVALID, "utterance too short for RawNet2 (%d samples)", c.samples);
@@ -862,13 +865,49 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
              return launch_rn_sinc(d_wav, h->rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
          }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
-    for (int bi = 0; bi < 8; ++bi) {
-        if (stop_after >= 0 && bi >= stop_after) { h->lastB = B; return SVHIP_OK; }
+    // bf16: the 128 -> 128 pooled blocks (layer1, layer2) each run as ONE fused kernel + the AFMS gate kernel; the gate of
+    // block i is applied by block i + 1 on the way in (or by the rn_afms_apply pass in front of the first GEMM block)
+    int first = 0;
+    const bool fuse_ok = bf && stop_after < 0 && !getenv("SVHIP_RN_UNFUSED");
+    const float *g_alpha = nullptr, *g_gate = nullptr;          // pending gate of the previous fused block
+    const void* xin = x;
+    for (; fuse_ok && first < 8; ++first) {
+        svhip_handle::RnBlock& K = h->rn_blocks[first];
+        if (!rn_block128_supported(K.cin, K.cout, T, K.downsample, K.has_shortcut, K.conv1.Kp, K.conv2.Kp)) break;
+        RnBlock128Params bp;
+        bp.xin = reinterpret_cast<const bf16_t*>(xin);
+        bp.alpha = g_alpha; bp.gate = g_gate;
+        bp.bn1_scale = K.bn1_scale; bp.bn1_shift = K.bn1_shift;
+        bp.W1 = reinterpret_cast<const bf16_t*>(K.conv1.W); bp.bn2_scale = K.conv1.scale; bp.bn2_shift = K.conv1.shift;
+        bp.W2 = reinterpret_cast<const bf16_t*>(K.conv2.W);
+        void* dst = (first & 1) ? hb : o;                        // ping-pong: never the buffer being read
+        bp.opool = reinterpret_cast<bf16_t*>(dst);
+        bp.colsum = h->rn_part;
+        bp.B = B; bp.T = T; bp.Tout = T / 3; bp.ntiles = rn_block128_ntiles(T);
+        const double fl = (double)B * T * (K.conv1.flops_per_row + K.conv2.flops_per_row);
+        if ((rc = run(h, "rn_block128", fl, [&]() { return launch_rn_block128(bp, h->num_cu, st); }))) return rc;
+        float* gate = h->rn_s + (size_t)(first & 1) * B * 512;   // two gate buffers: block i + 1 reads i's while writing its own
+        if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
+                 return launch_rn_afms_gate(h->rn_part, rn_block128_nparts(B, bp.T, h->num_cu), B, K.cout, bp.Tout, K.afms_fc.W, K.afms_fc.bias, gate, st);
+             }))) return rc;
+        T /= 3;
+        xin = dst;
+        g_alpha = K.alpha; g_gate = gate;
+    }
+    if (first > 0) {
+        // x = (o + alpha) * gate and, in the same pass, the next consumer's lrelu(bn(x))
+        svhip_handle::RnBlock& Kp = h->rn_blocks[first - 1];
+        const float* nsc = first < 8 ? h->rn_blocks[first].bn1_scale : h->rn_agg_scale;
+        const float* nsh = first < 8 ? h->rn_blocks[first].bn1_shift : h->rn_agg_shift;
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, x, bf, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
+        h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = Kp.cout;
+    }
+    for (int bi = first; bi < 8; ++bi) {
         svhip_handle::RnBlock& K = h->rn_blocks[bi];
         const int M = B * T;
         // out = lrelu(bn1(x))                                                         RawNet_baseline.py:222
         // (blocks 1..7 get it from the previous block's AFMS pass, which writes x and lrelu(bn1(x)) together)
-        if (bi == 0 || stop_after >= 0) {
+        if ((bi == 0 && first == 0) || stop_after >= 0) {
             if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
         }
         const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
@@ -988,6 +1027,10 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         h->own_stream = true;
     }
     h->cur = h->stream;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->num_cu = ncu;
+    }
     {
         const char* le = getenv("SVHIP_LANES");            // 1 or 2 (default 2 for ECAPA): half-batches on two streams
         h->lanes = le ? atoi(le) : 1;                      // measured +3.7 % with 2 lanes, but per-kernel timings then overlap; default 1

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <functional>
 
+#include "common.h"
+
 struct svhip_handle;
 
 namespace svhip {
@@ -201,6 +203,32 @@ hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin,
 hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
                                 hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
                                 void* pre = nullptr, float slope = 0.3f);
+// Fused 128 -> 128 pooled RawNetBasicBlock (rn_block128.hip, bf16): previous block's AFMS gate on the way in, BN + LeakyReLU,
+// conv1 + BN + LeakyReLU, conv2 + identity shortcut, max_pool1d(3), per-tile column sums of the pooled output.
+struct RnBlock128Params {
+    const bf16_t* xin = nullptr;         // (B, T, 128): the stage input before the previous block's gate
+    const float* alpha = nullptr;        // [128] previous block's AFMS alpha, or null (first block)
+    const float* gate = nullptr;         // (B, 128) previous block's AFMS sigmoid(fc(mean)), or null
+    const float* bn1_scale = nullptr;    // [128] folded bn1
+    const float* bn1_shift = nullptr;
+    const bf16_t* W1 = nullptr;          // packed [128][384], k = tap * 128 + c
+    const float* bn2_scale = nullptr;    // [128] folded bn2 (conv1's epilogue)
+    const float* bn2_shift = nullptr;
+    const bf16_t* W2 = nullptr;
+    bf16_t* opool = nullptr;             // (B, T / 3, 128)
+    float* colsum = nullptr;             // (B, rn_block128_nparts(B, T, num_cu), 128) partial sums of opool over pooled frames
+    int B = 0, T = 0, Tout = 0, ntiles = 0;
+    int per_wg = 0, nseg = 0;            // filled by the launcher: items per workgroup, workgroups that can share an utterance
+    unsigned long long* dbg = nullptr;   // tools/rb_bench: per-workgroup phase cycle totals (only read in -DSVHIP_GEMM_DEBUG builds)
+    int debug = 0;                       // tools/rb_bench ablations (debug builds): 1 no fragment reads, 2 no MFMA, 4 no conversion, 8 no pool
+};
+int rn_block128_ntiles(int T);
+int rn_block128_nparts(int B, int T, int num_cu);
+bool rn_block128_supported(int cin, int cout, int T, bool downsample, bool has_shortcut, int Kp1, int Kp2);
+hipError_t launch_rn_block128(const RnBlock128Params& p, int num_cu, hipStream_t stream);
+// AFMS gate from partial column sums: s (B, C) = sigmoid(fc(sum(part) / Tn)); part (B, nparts, C), W [C][C] fp32
+hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* W, const float* bias, float* s,
+                               hipStream_t stream);
 hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
 
 // synthetic waveforms from a counter-based RNG (synth.hip): out (B, L) fp32 = utterances [first_utt, first_utt + B) of the stream `seed`
