@@ -84,6 +84,7 @@ struct svhip_handle {
         ConvLayer conv1, conv2, shortcut;       // conv1 carries bn2 as its epilogue
         float* alpha = nullptr;
         LinearLayer afms_fc;
+        float* afms_fcT = nullptr;              // fc weight transposed [cin][cout] (the gate kernel reads consecutive outputs per wave)
     };
     RnBlock rn_blocks[8];
     float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
@@ -611,6 +612,13 @@ int finalize_rawnet2(svhip_handle* h) {
             if (B.has_shortcut && (rc = make_conv(h, B.shortcut, p + ".shortcut.0.weight", "", "", 1))) return rc;
             if ((rc = upload_f32(h, p + ".afms.alpha", &B.alpha))) return rc;
             if ((rc = make_linear(h, B.afms_fc, p + ".afms.fc.weight", p + ".afms.fc.bias"))) return rc;
+            {
+                const HostTensor* fw = getw(h, p + ".afms.fc.weight");                  // (planes, planes)
+                std::vector<float> t((size_t)planes * planes);
+                for (int n = 0; n < planes; ++n)
+                    for (int c = 0; c < planes; ++c) t[(size_t)c * planes + n] = fw->data[(size_t)n * planes + c];
+                if ((rc = dev_upload(h, &B.afms_fcT, t))) return rc;
+            }
             fl += (double)T * (B.conv1.flops_per_row + B.conv2.flops_per_row + (B.has_shortcut ? B.shortcut.flops_per_row : 0.0));
             fl += 2.0 * planes * planes;
             if (B.downsample) T /= 3;
@@ -888,7 +896,7 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
         if ((rc = run(h, "rn_block128", fl, [&]() { return launch_rn_block128(bp, h->num_cu, st); }))) return rc;
         float* gate = h->rn_s + (size_t)(first & 1) * B * 512;   // two gate buffers: block i + 1 reads i's while writing its own
         if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
-                 return launch_rn_afms_gate(h->rn_part, rn_block128_nparts(B, bp.T, h->num_cu), B, K.cout, bp.Tout, K.afms_fc.W, K.afms_fc.bias, gate, st);
+                 return launch_rn_afms_gate(h->rn_part, rn_block128_nparts(B, bp.T, h->num_cu), B, K.cout, bp.Tout, K.afms_fcT, K.afms_fc.bias, gate, st);
              }))) return rc;
         T /= 3;
         xin = dst;
@@ -926,8 +934,8 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
         }
         // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
         if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, h->rn_mean, st, h->rn_scratch, 16); }))) return rc;
-        if ((rc = run(h, "rn_afms_fc", 2.0 * B * K.cout * K.cout, [&]() {
-                 return launch_rowvec_linear(h->rn_mean, K.cout, K.afms_fc.W, K.afms_fc.bias, h->rn_s, K.cout, B, K.cout, K.cout, ACT_SIGMOID, st);
+        if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
+                 return launch_rn_afms_gate(h->rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, h->rn_s, st);
              }))) return rc;
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;

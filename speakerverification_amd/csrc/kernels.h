@@ -226,8 +226,8 @@ int rn_block128_ntiles(int T);
 int rn_block128_nparts(int B, int T, int num_cu);
 bool rn_block128_supported(int cin, int cout, int T, bool downsample, bool has_shortcut, int Kp1, int Kp2);
 hipError_t launch_rn_block128(const RnBlock128Params& p, int num_cu, hipStream_t stream);
-// AFMS gate from partial column sums: s (B, C) = sigmoid(fc(sum(part) / Tn)); part (B, nparts, C), W [C][C] fp32
-hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* W, const float* bias, float* s,
+// AFMS gate from partial column sums: s (B, C) = sigmoid(fc(sum(part) / Tn)); part (B, nparts, C), WT = fc weight TRANSPOSED [C][C] fp32
+hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* WT, const float* bias, float* s,
                                hipStream_t stream);
 hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
 

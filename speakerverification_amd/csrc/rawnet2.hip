@@ -71,7 +71,7 @@ template <> struct SincCfg<float> {
 
 // filters: bf16: [128][256] bf16 (k contiguous); fp32: [128][252] fp32.
 template <typename T>
-__global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict__ wav, const float* __restrict__ stats,
+__global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict__ wav, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const void* __restrict__ filt, const float* __restrict__ bn_scale,
                                                          const float* __restrict__ bn_shift, T* __restrict__ out, T* __restrict__ pre, const float* __restrict__ nscale,
@@ -82,18 +82,25 @@ __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // n-tile: filters wave*32 .. +31
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // fp32: wave = n-tile (filters wave*32 .. +31), both position groups.  bf16: wave = (filter half nf, position group gw):
+    // 64 filters x 32 pooled positions, so every operand fragment read from LDS feeds TWO MFMAs — with one filter block per
+    // wave the kernel sat on the LDS read port (1 KiB per MFMA from 8 waves = 256 B/clk per CU): 0.91 ms -> see DESIGN.md
+    const int nf = wave & 1, gw = wave >> 1;
     const int fr = lane & 31, fh = lane >> 5;
     const float mean = stats[2 * b], inv = stats[2 * b + 1];
     const float* __restrict__ x = wav + (int64_t)b * L;
 
     // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand)
-    bf16x8 wfb[BF ? 16 : 1];
+    bf16x8 wfb[BF ? 2 : 1][BF ? 16 : 1];
     float wff[BF ? 1 : 126];
     if (BF) {
-        const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(wave * 32 + fr) * 256 * 2 + fh * 16;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) wfb[kk] = *reinterpret_cast<const bf16x8*>(w + kk * 32);
+        for (int blk = 0; blk < 2; ++blk) {
+            const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(nf * 64 + blk * 32 + fr) * 256 * 2 + fh * 16;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) wfb[blk][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 32);
+        }
     } else {
         const float* w = reinterpret_cast<const float*>(filt) + (int64_t)(wave * 32 + fr) * 252 + fh;
 #pragma unroll
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict
         }
         __syncthreads();
 
+        // acc[a][j]: fp32: a = position group g (filters of this wave); bf16: a = filter block of this wave's half (position group gw)
         f32x16 acc[2][3];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -129,17 +137,16 @@ __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict
                 for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
         if (BF) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 3; ++j) {
+                const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
+                const char* base = smem + (s & 7) * (CF::LDS / 8) + ((s >> 3) + fh) * 16;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int s = 3 * (32 * g + fr) + j;                      // conv position inside the tile
-                    const char* base = smem + (s & 7) * (CF::LDS / 8) + ((s >> 3) + fh) * 16;
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
-                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[kk], xf, acc[g][j], 0, 0, 0);
-                    }
+                for (int kk = 0; kk < 16; ++kk) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[0][kk], xf, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[1][kk], xf, acc[1][j], 0, 0, 0);
                 }
+            }
         } else {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -154,10 +161,10 @@ __global__ __launch_bounds__(256, 1) void rn_sinc_kernel(const float* __restrict
         // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 filters per group
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int tp = tp0 + 32 * g + fr;
+            const int tp = tp0 + 32 * (BF ? gw : g) + fr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f = wave * 32 + 8 * q + 4 * fh;
+                const int f = (BF ? nf * 64 + g * 32 : wave * 32) + 8 * q + 4 * fh;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_scale + f);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(bn_shift + f);
                 float v[4];

@@ -406,36 +406,50 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
 }
 
 // AFMS gate: s[b, n] = sigmoid(bias[n] + sum_c W[n, c] * mean[b, c]), mean = (sum of the partial column sums) / Tn
-// (RawNet_baseline.py:64-66).  One workgroup per utterance; the partial rows are summed by 256 / C thread groups with eight
-// loads in flight each, then wave = output, lanes over c (coalesced weight rows).
-__global__ __launch_bounds__(256) void rn_afms_gate_kernel(const float* __restrict__ part, int nparts, int C, float inv_T,
-                                                           const float* __restrict__ W, const float* __restrict__ bias,
+// (RawNet_baseline.py:64-66): a (B x C) x (C x C) product too small for the GEMM kernels and, done one utterance per workgroup,
+// bound by re-reading the weight matrix per utterance (40 us).  Workgroup = 16 outputs x 16 utterances: both operand slices are
+// staged in LDS with every load in flight at once (WT = the fc weight transposed, so a slice is 64-byte row pieces), then
+// thread = (output, utterance) runs the dot product out of LDS.
+constexpr int GATE_N = 16, GATE_U = 16;
+__global__ __launch_bounds__(256) void rn_afms_gate_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_T,
+                                                           const float* __restrict__ WT, const float* __restrict__ bias,
                                                            float* __restrict__ s) {
-    __shared__ float acc_s[4][512];
-    __shared__ float mean[512];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int groups = C >= 256 ? 1 : 256 / C;                   // C = 128: two groups of 128 threads split the partial rows
-    const int g = tid / C, c0 = tid - g * C;
-    for (int c = c0; c < C; c += 256) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* wl = gsm;                       // [C][GATE_N]
+    float* mt = gsm + C * GATE_N;          // [C][GATE_U]
+    const int n0 = blockIdx.x * GATE_N, b0 = blockIdx.y * GATE_U, tid = threadIdx.x;
+    // weight slice: 4 lanes x 16 bytes per c row, 64 rows per pass
+    {
+        const int q = tid & 3, r = tid >> 2;
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = r + 64 * i;
+            v[i] = c < C ? *reinterpret_cast<const f32x4*>(WT + (int64_t)c * C + n0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = r + 64 * i;
+            if (c < C) *reinterpret_cast<f32x4*>(wl + c * GATE_N + 4 * q) = v[i];
+        }
+    }
+    // mean slice, transposed to [c][u]: consecutive threads read consecutive c of one partial row
+    for (int i = tid; i < C * GATE_U; i += 256) {
+        const int u = i / C, c = i - u * C;
         float a = 0.0f;
-        const float* src = part + (int64_t)b * nparts * C + c;
+        if (b0 + u < B) {
+            const float* src = part + (int64_t)(b0 + u) * nparts * C + c;
 #pragma unroll 8
-        for (int t = (C >= 256 ? 0 : g); t < nparts; t += groups) a += src[(int64_t)t * C];
-        acc_s[C >= 256 ? 0 : g][c] = a;
+            for (int t = 0; t < nparts; ++t) a += src[(int64_t)t * C];
+        }
+        mt[c * GATE_U + u] = a * inv_T;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a = acc_s[0][c];
-        for (int k = 1; k < groups; ++k) a += acc_s[k][c];
-        mean[c] = a * inv_T;
-    }
-    __syncthreads();
-    for (int n = wave; n < C; n += 4) {
-        float a = 0.0f;
-        for (int c = lane; c < C; c += 64) a = fmaf(W[(int64_t)n * C + c], mean[c], a);
-        a = wave_sum(a);
-        if (lane == 0) s[(int64_t)b * C + n] = 1.0f / (1.0f + expf(-(a + bias[n])));
-    }
+    const int n = tid & 15, u = tid >> 4;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) acc = fmaf(wl[c * GATE_N + n], mt[c * GATE_U + u], acc);
+    if (b0 + u < B) s[(int64_t)(b0 + u) * C + n0 + n] = 1.0f / (1.0f + expf(-(acc + bias[n0 + n])));
 }
 
 }  // namespace
@@ -481,10 +495,12 @@ hipError_t launch_rn_block128(const RnBlock128Params& p_in, int num_cu, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* W, const float* bias, float* s,
+hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* WT, const float* bias, float* s,
                                hipStream_t stream) {
-    if (!part || !W || !bias || !s || C > 512 || C % 64 != 0 || (C < 256 && 256 % C != 0) || nparts <= 0 || Tn <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rn_afms_gate_kernel, dim3(B), dim3(256), 0, stream, part, nparts, C, 1.0f / (float)Tn, W, bias, s);
+    if (!part || !WT || !bias || !s || C > 512 || C % 64 != 0 || nparts <= 0 || Tn <= 0 || B <= 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)C * (GATE_N + GATE_U) * sizeof(float);       // <= 64 KiB
+    hipLaunchKernelGGL(rn_afms_gate_kernel, dim3(C / GATE_N, (B + GATE_U - 1) / GATE_U), dim3(256), lds, stream, part, nparts, B, C,
+                       1.0f / (float)Tn, WT, bias, s);
     return hipGetLastError();
 }
 
