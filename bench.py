@@ -324,6 +324,34 @@ def sub_bench(model, compute, B, local, dev, wavs, steps=10, warmup=2):
     return rec
 
 
+def multi_stream_bench(model, compute, B, local, dev, wavs, n_streams=3, steps=30):
+    """serving pattern: `n_streams` engines on their own streams take alternate batches, so the small, under-filled kernels of one
+    batch run beside the big ones of another (RawNet2's late blocks are grids of 86 - 400 workgroups).  Reported next to the
+    single-stream number, never instead of it."""
+    import torch
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    engs, outs = [], []
+    for st in streams:
+        with torch.cuda.stream(st):
+            engs.append(make_engine(model, compute, B, local))
+            outs.append(torch.empty((B, engs[-1].embed_dim), device=dev, dtype=torch.float32))
+    torch.cuda.synchronize()
+    dt = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            i = k % n_streams
+            with torch.cuda.stream(streams[i]):
+                engs[i].embed_wave(wavs[k % len(wavs)], out=outs[i], async_=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ok = all(bool(torch.isfinite(o).all().item()) for o in outs)
+    for e in engs:
+        e.close()
+    return {"value": steps * B / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3, "streams": n_streams, "steps": steps, "finite": ok}
+
+
 def pcie_bench(eng, dev, B):
     """PCIe-inclusive rate: decoded 16-bit PCM on the host -> int16 over PCIe -> device crop (svhip_crop_pcm16) -> embed.
     (Never `value`: BASELINE's metric is quoted on HBM-resident waveforms.)"""
@@ -376,6 +404,42 @@ def verify_last_step(eng, wav_last, emb_last, local, dev):
     return rec
 
 
+def make_comm(eng, ranks):
+    """RCCL communicator under the C ABI; if RCCL cannot come up on this node the run still completes over the gloo group
+    (host round trip) and says so in `allgather_carrier`."""
+    if not ranks.launched:
+        return None, "none (1 GPU, no launcher)"
+    from speakerverification_amd import distributed as sv_dist
+    try:
+        if os.environ.get("SVHIP_BENCH_NO_RCCL"):       # developer hook: rehearse the fallback (e.g. 2 ranks on ONE GPU, which RCCL refuses)
+            raise RuntimeError("SVHIP_BENCH_NO_RCCL is set")
+        with quiet_stdout():
+            comm = sv_dist.LibComm(eng, ranks.rank, ranks.world)
+        ok = 1
+    except Exception as e:  # noqa: BLE001 - any failure to bring RCCL up
+        comm, ok = None, 0
+        print(f"[bench] rank {ranks.rank}: RCCL communicator failed ({e!r}); falling back to gloo", file=sys.stderr)
+    if ranks.min(ok) == 0:          # all ranks must agree on the carrier
+        if comm is not None:
+            eng.lib.svhip_comm_destroy(eng.h)
+        return None, "torch.distributed gloo all_gather (RCCL communicator could not be created on this node)"
+    return comm, "svhip_allgather_rows (RCCL under the C ABI)"
+
+
+def gather_rows(eng, comm, ranks, local, out):
+    """the path's exchange step: RCCL on the engine's stream, or (fallback) gloo through host memory"""
+    import torch
+    if comm is not None:
+        eng.allgather_rows(local, out=out, async_=True)
+    elif ranks.dist is not None and ranks.world > 1:
+        torch.cuda.synchronize()
+        host = torch.empty((ranks.world * local.shape[0], local.shape[1]), dtype=torch.float32)
+        ranks.dist.all_gather_into_tensor(host, local.cpu())
+        out.copy_(host)
+    else:
+        out.copy_(local)
+
+
 class Ranks:
     """control plane of a multi-rank run: torch.distributed (gloo) for the RCCL id, barriers and the max over ranks;
     the data-path collective is RCCL under the C ABI (LibComm on an Engine)."""
@@ -383,7 +447,7 @@ class Ranks:
     def __init__(self, args):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local = int(os.environ.get("SVHIP_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # (override: developer rehearsals on one GPU)
         self.dist = None
         if self.world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
@@ -397,6 +461,14 @@ class Ranks:
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
+
+    def min(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
 
     def max(self, x: float) -> float:
         if self.dist is None:
@@ -444,7 +516,7 @@ def synth_batches(eng, n_batches, B, first_utt, dev, seed=SEED_STREAM):
     return wavs
 
 
-def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True):
+def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True, carrier=""):
     """after embedding: ONE all-gather of the (n_local, D) block per rank, then config-4-style scoring of the gathered matrix,
     row-sharded by enrol index: rank r scores the trials (i, pi(i)) with i in its block, and computes the AS-norm cohort
     statistics of its own rows (gathered with a second, small all-gather of (n_local, 2))."""
@@ -457,14 +529,11 @@ def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True):
     ranks.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if comm is not None:
-        eng.allgather_rows(shard, out=gathered, async_=True)
-    else:
-        gathered.copy_(shard)
+    gather_rows(eng, comm, ranks, shard, gathered)
     torch.cuda.synchronize()
     rec["allgather_ms"] = ranks.max((time.perf_counter() - t0) * 1e3)
     rec["allgather_bytes_per_rank"] = n_local * D * 4
-    rec["allgather_carrier"] = "svhip_allgather_rows (RCCL under the C ABI)" if comm is not None else "none (1 GPU: local copy)"
+    rec["allgather_carrier"] = carrier
     rec["gathered_rows"] = world * n_local
     lo = rank * n_local
     own_block_ok = bool(torch.equal(gathered[lo:lo + n_local], shard))
@@ -493,10 +562,7 @@ def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True):
     mu, sd = eng.asnorm_stats(gathered[lo:lo + n_local], cohort, top)               # row-sharded cohort GEMM + top-k
     stats_loc = torch.stack([mu, sd], dim=1).contiguous()
     stats_all = torch.empty((N, 2), device=dev, dtype=torch.float32)
-    if comm is not None:
-        eng.allgather_rows(stats_loc, out=stats_all, async_=True)
-    else:
-        stats_all.copy_(stats_loc)
+    gather_rows(eng, comm, ranks, stats_loc, stats_all)
     mu_all, sd_all = stats_all[:, 0].contiguous(), stats_all[:, 1].contiguous()
     eng.asnorm_pairs(gathered, mu_all, sd_all, ia, ib, out)
     torch.cuda.synchronize()
@@ -515,17 +581,16 @@ def run_batch(args, ranks, dev):
     label = dominant_label(args.model, args.compute)
     eng = make_engine(args.model, args.compute, B, local)
     embed = eng.embed_dim
-    with quiet_stdout():
-        comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+    comm, carrier = make_comm(eng, ranks)
 
     # synthetic waveforms, resident in HBM before the timed region: NBATCH distinct batches per rank, rotated
     wavs = synth_batches(eng, NBATCH, B, rank * NBATCH * B, dev)
     shard = torch.empty((K * B, embed), device=dev, dtype=torch.float32)   # this rank's embeddings
-    gathered = torch.empty((world * K * B, embed), device=dev, dtype=torch.float32) if comm is not None else shard
+    gathered = torch.empty((world * K * B, embed), device=dev, dtype=torch.float32) if ranks.launched else shard
 
     t0 = embed_loop(eng, wavs, K, W, B, shard, label, ranks.barrier)
-    if comm is not None:
-        eng.allgather_rows(shard, out=gathered, async_=True)       # the path's single exchange step (RCCL over xGMI)
+    if ranks.launched:
+        gather_rows(eng, comm, ranks, shard, gathered)             # the path's single exchange step (RCCL over xGMI)
     torch.cuda.synchronize()
     ranks.barrier()
     torch.cuda.synchronize()
@@ -534,8 +599,8 @@ def run_batch(args, ranks, dev):
     eng.profile(False)
     check = verify_last_step(eng, wavs[(K - 1) % NBATCH], shard[(K - 1) * B:K * B], local, dev)
     shard_rec = None
-    if comm is not None:
-        shard_rec, _ = shard_tail(eng, comm, ranks, shard, dev, K * B)
+    if ranks.launched:
+        shard_rec, _ = shard_tail(eng, comm, ranks, shard, dev, K * B, carrier=carrier)
     n_all = min(K, 10)
     kern = kernel_table(eng, wavs, B, n_all, dev) if rank == 0 else {}
 
@@ -552,7 +617,7 @@ def run_batch(args, ranks, dev):
                                     "(BASELINE configs[2]), HBM-resident waveforms -> 320-d embeddings"),
                        "batch_per_gpu": B, "samples": SAMPLES, "frames": eng.frames, "embed_dim": embed,
                        "waveform_batches_rotated": NBATCH, "waveform_bytes_resident": NBATCH * B * SAMPLES * 4,
-                       "collective": "one svhip_allgather_rows (RCCL) of the shard embeddings inside the timed region" if comm is not None else "none"},
+                       "collective": ("one all-gather of the shard embeddings inside the timed region: " + carrier) if ranks.launched else "none"},
             "finite": check["finite"], "check": check,
             "whole_path_TFLOPs": eng.flops_per_utterance * total_utts / dt / 1e12,
             "flops_per_utterance": eng.flops_per_utterance,
@@ -571,6 +636,7 @@ def run_batch(args, ranks, dev):
                 line["scoring"] = {"error": repr(e)}
         if world == 1 and not args.no_extras and args.model == "ecapa" and args.compute == "bf16":
             for name, fn in (("rawnet2", lambda: sub_bench("rawnet2", "bf16", B, local, dev, wavs)),
+                             ("rawnet2_3_streams", lambda: multi_stream_bench("rawnet2", "bf16", B, local, dev, wavs)),
                              ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:
@@ -592,8 +658,7 @@ def run_shard(args, ranks, dev):
     n_local = args.utts_per_gpu
     label = dominant_label(args.model, args.compute)
     eng = make_engine(args.model, args.compute, B, local)
-    with quiet_stdout():
-        comm = sv_dist.LibComm(eng, rank, world) if ranks.launched else None
+    comm, carrier = make_comm(eng, ranks)
     shard = torch.empty((n_local, eng.embed_dim), device=dev, dtype=torch.float32)
     wav = [torch.empty((B, SAMPLES), device=dev, dtype=torch.float32) for _ in range(2)]
     first = rank * n_local
@@ -618,7 +683,7 @@ def run_shard(args, ranks, dev):
     dt = ranks.max(time.perf_counter() - t0)
     prof = eng.profile_results()
     eng.profile(False)
-    rec, _ = shard_tail(eng, comm, ranks, shard, dev, n_local)
+    rec, _ = shard_tail(eng, comm, ranks, shard, dev, n_local, carrier=carrier)
     if rank == 0:
         total = world * n_local
         line = {"metric": "embeddings/sec (2 s @16 kHz)", "value": total / dt, "unit": "embeddings/s", "n_gpus": world,
