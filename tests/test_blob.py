@@ -102,3 +102,70 @@ def test_model_handling_reads_blobs_on_the_host(tmp_path):
     with pytest.raises(ValueError):
         checkpoint.write_blob(p, "rawnet2", sd)
         m.load_blob(p)
+
+
+def test_fusion_checkpoint_converts_to_one_blob_per_branch(tmp_path):
+    """the production model (Raw_ECAPA_sinc_asp, keys __S__.ECAPA_TDNN.* / __S__.rawnet2v2.*) has a blob path:
+    one blob per branch; a fusion state dict handed to a single-network conversion is refused with a clear message."""
+    e = synth.synth_state_dict(synth.ecapa_param_spec(C=64), seed=5)
+    r = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=6)
+    state = {"module.__S__.ECAPA_TDNN." + k: torch.from_numpy(np.asarray(v)) for k, v in e.items()}
+    state.update({"module.__S__.rawnet2v2." + k: torch.from_numpy(np.asarray(v)) for k, v in r.items()})
+    state["module.__L__.weight"] = torch.zeros(3)
+    state["module.compute_features.0.flipped_filter"] = torch.zeros(1, 1, 2)
+    dst = tmp_path / "fusion.svhip"
+    n = checkpoint.convert_checkpoint(state, dst, "Raw_ECAPA_sinc_asp")
+    assert n == len(e) + len(r)
+    p_e, p_r = checkpoint.fusion_blob_paths(dst)
+    mid_e, back_e = checkpoint.read_blob(p_e)
+    mid_r, back_r = checkpoint.read_blob(p_r)
+    assert (mid_e, mid_r) == (_lib.MODEL_ECAPA, _lib.MODEL_RAWNET2)
+    assert list(back_e) == list(e) and list(back_r) == list(r)
+    assert all(np.array_equal(back_r[k], np.asarray(v)) for k, v in r.items())
+    with pytest.raises(ValueError, match="fusion checkpoint"):
+        checkpoint.convert_checkpoint(state, tmp_path / "x.svhip", "ECAPA_TDNN")
+    with pytest.raises(ValueError, match="holds no"):
+        checkpoint.convert_checkpoint({"module.__S__." + k: v for k, v in e.items()}, tmp_path / "y.svhip", "Raw_ECAPA_sinc_asp")
+
+
+def test_crafted_table_cannot_wrap_the_bounds_check(tmp_path):
+    """u64 + u64 / shape products in the table checks must not wrap.  The checksum is no integrity guarantee, so the
+    test re-computes it (csrc/blob.hip: four-lane FNV-1a over everything after the 64-byte header) after corrupting an entry."""
+    M = 0xFFFFFFFFFFFFFFFF
+    prime = 0x100000001b3
+
+    def checksum(b):
+        h = [0xcbf29ce484222325, 0x84222325cbf29ce4, 0x9ce484222325cbf2, 0x2325cbf29ce48422]
+        i = 0
+        while i + 32 <= len(b):
+            for lane in range(4):
+                w = int.from_bytes(b[i + 8 * lane:i + 8 * lane + 8], "little")
+                h[lane] = ((h[lane] ^ w) * prime) & M
+            i += 32
+        r = 0xcbf29ce484222325
+        for lane in range(4):
+            r = ((r ^ h[lane]) * prime) & M
+        for x in b[i:]:
+            r = ((r ^ x) * prime) & M
+        return r
+
+    p = tmp_path / "w.svhip"
+    checkpoint.write_blob(p, "ECAPA_TDNN", {"a": np.arange(8, dtype=np.float32)})
+    raw = bytearray(p.read_bytes())
+    assert int.from_bytes(raw[32:40], "little") == checksum(raw[64:])        # header: checksum at byte 32, payload from byte 64
+    ent = 64                                                                  # entry 0: data_off at +48, nbytes at +56, shape[0] at +16
+    assert int.from_bytes(raw[ent + 56:ent + 64], "little") == 32 and int.from_bytes(raw[ent + 16:ent + 24], "little") == 8
+    cases = {
+        "nbytes wraps data_off + nbytes": [(ent + 56, 2 ** 64 - 64)],
+        "shape product wraps to the stored size": [(ent + 16, 2 ** 62 + 8)],              # (2^62 + 8) * 4 bytes == 32 mod 2^64
+        "data_off beyond the file": [(ent + 48, 2 ** 63)],
+    }
+    for why, edits in cases.items():
+        bad = bytearray(raw)
+        for off, val in edits:
+            bad[off:off + 8] = val.to_bytes(8, "little")
+        bad[32:40] = checksum(bad[64:]).to_bytes(8, "little")
+        p.write_bytes(bytes(bad))
+        with pytest.raises(_lib.SvhipError) as ei:
+            checkpoint.read_blob(p)
+        assert "checksum" not in str(ei.value), (why, str(ei.value))          # rejected by the table checks, not by luck

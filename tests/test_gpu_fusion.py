@@ -32,3 +32,30 @@ def test_fusion_matches_reference(golden_dir):
     rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
     assert float(np.abs(on - rn).max()) <= 1e-4
     assert m(x[:1]).shape == (512,)
+
+
+def test_fusion_blob_and_whole_file_engine_cache(tmp_path):
+    """the production model through the blob path (one blob per branch) equals the state-dict path bit for bit; whole-file
+    evaluation (a new length per call) keeps the fixed-length handle and at most ENGINE_CACHE handles alive."""
+    from speakerverification_amd import checkpoint
+    from speakerverification_amd.models import ECAPA_TDNN
+    sd = {"__S__.ECAPA_TDNN." + k: v for k, v in synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=1).items()}
+    sd.update({"__S__.rawnet2v2." + k: v for k, v in synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1).items()})
+    dst = tmp_path / "fusion.svhip"
+    checkpoint.convert_checkpoint(sd, dst, "Raw_ECAPA_sinc_asp")
+    a = Raw_ECAPA_sinc_asp.MainModel(nOut=512, embed_batch=4, **KW)
+    a.load_state_dict({k[len("__S__."):]: v for k, v in sd.items()})
+    b = Raw_ECAPA_sinc_asp.MainModel(nOut=512, embed_batch=4, **KW)
+    b.load_blob(dst)
+    x = synth.synth_waveforms(3, 32000, seed=7)
+    assert np.array_equal(a(x), b(x))
+    # engine cache: fixed-length crops first, then three whole files of different lengths, then the crops again
+    m = ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192], embed_batch=8)
+    e0 = m.embed_wave(synth.synth_waveforms(8, 32000, seed=1))
+    primary = m._engine
+    for L in (40000, 48000, 56000, 64000):
+        out = m.embed_wave(synth.synth_waveforms(1, L, seed=2))
+        assert out.shape == (192,) and m._engine.max_batch == 1         # a workspace for ONE utterance of that length
+        assert len(m._engines) <= m.ENGINE_CACHE
+    e1 = m.embed_wave(synth.synth_waveforms(8, 32000, seed=1))
+    assert m._engine is primary and np.array_equal(e0, e1)              # the fixed-length handle survived and was not rebuilt

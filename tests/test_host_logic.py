@@ -247,3 +247,18 @@ def test_metrics_host_selection_matches_sklearn(case):
     sp, sr, sth = skm.precision_recall_curve(lab, sc.astype(np.float64), pos_label=1)
     assert np.array_equal(pr, sp) and np.array_equal(rc, sr) and np.array_equal(pth, sth)
     assert m._auc(fpr * 100, tpr) == skm.auc(rf * 100, rt)
+
+
+def test_front_end_keywords_reach_the_fused_waveform_path():
+    """a config that overrides the mel front-end (feature.py:66-71 keywords) must change the fused
+    ECAPA waveform path too — the keywords are forwarded to the engine — and an unsupported window is refused."""
+    from speakerverification_amd.models import ECAPA_TDNN
+    m = ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192], n_mels=80, features="melspectrogram",
+                             sr=16000, n_fft=400, win_length=400, hop_length=160, fmin=20.0, fmax=7600.0, pre_emphasis=False)
+    kw = m._engine_kwargs
+    assert (kw["sr"], kw["n_fft"], kw["win_length"], kw["hop_length"], kw["fmin"], kw["fmax"], kw["pre_emphasis"]) == \
+           (16000, 400, 400, 160, 20.0, 7600.0, False)
+    assert m._max_batch == 256
+    assert ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192], embed_batch=32)._max_batch == 32
+    with pytest.raises(NotImplementedError):
+        ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192], window="hann")
