@@ -52,9 +52,9 @@ struct svhip_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t cur = nullptr;                // stream the launch helpers enqueue on (main stream or a lane)
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
-    hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};
-    int lanes = 1;                            // 2: the ECAPA forward runs as two half-batches on two streams
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // [lane] done events, [4] = fork point
+    int lanes = 1;                            // > 1: the forward runs as that many batch slices on as many streams
     bool bf16 = false;
     bool finalized = false;
     std::string err;
@@ -185,7 +185,7 @@ hipEvent_t prof_event(svhip_handle* h) {
 void prof_collect(svhip_handle* h) {
     if (h->ev_pending.empty()) return;
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; ++i) if (h->lane_stream[i]) (void)hipStreamSynchronize(h->lane_stream[i]);
+    for (int i = 0; i < 4; ++i) if (h->lane_stream[i]) (void)hipStreamSynchronize(h->lane_stream[i]);
     for (auto& pe : h->ev_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) h->prof_entries[pe.entry].ms += ms;
@@ -837,9 +837,9 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     int rc = SVHIP_OK;
     if (h->lanes == 2 && B >= 64) {
         const int B0 = (B / 2 + 3) & ~3;
-        SV_HIP(h, hipEventRecord(h->lane_ev[2], h->stream));
+        SV_HIP(h, hipEventRecord(h->lane_ev[4], h->stream));
         for (int l = 0; l < 2 && !rc; ++l) {
-            SV_HIP(h, hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[2], 0));
+            SV_HIP(h, hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[4], 0));
             h->cur = h->lane_stream[l];
             rc = ecapa_forward_part(h, d_feat, l == 0 ? 0 : B0, l == 0 ? B0 : B - B0);
             h->cur = h->stream;
@@ -855,22 +855,33 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     return rc;
 }
 
-// RawNet2.forward (models/RawNet2_custom.py:161-227) on device-resident waveforms (B, L)
-int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
+// RawNet2.forward (models/RawNet2_custom.py:161-227) on device-resident waveforms (B, L), utterances [b0, b0 + B) of the call,
+// enqueued on h->cur.  Every workspace buffer is per-utterance contiguous, so a batch slice is an offset into each.
+int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B) {
     const svhip_config& c = h->cfg;
     const bool bf = h->bf16;
-    hipStream_t st = h->stream;
-    const int L = c.samples;
+    hipStream_t st = h->cur;
+    const int L = c.samples, e = h->esz;
+    const size_t per_utt = (size_t)h->rn_T1 * 128;                 // elements of the largest activation of one utterance
+    const float* d_wav = d_wav_all + (size_t)b0 * L;
+    float* rn_stats = h->rn_stats + (size_t)b0 * 2;
+    float* rn_mean = h->rn_mean + (size_t)b0 * 512;
+    float* rn_scratch = h->rn_scratch + (size_t)b0 * 16 * 512;
+    float* rn_part = h->rn_part + (size_t)b0 * (rn_block128_ntiles(h->rn_T1) + 1) * 4 * 128;
+    float* rn_gate[2] = {h->rn_s + (size_t)b0 * 512, h->rn_s + ((size_t)c.max_batch + b0) * 512};
+    float* rn_pooled = h->rn_pooled + (size_t)b0 * 1024;
+    float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     int rc;
-    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, h->rn_stats, st); }))) return rc;
+    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st); }))) return rc;
     int T = h->rn_T1;
-    void *x = h->rn_buf[0], *pre = h->rn_buf[1], *hb = h->rn_buf[2], *o = h->rn_buf[3], *sc = h->rn_buf[4], *xn = h->rn_buf[5];
+    void *x = off(h->rn_buf[0], b0 * per_utt, e), *pre = off(h->rn_buf[1], b0 * per_utt, e), *hb = off(h->rn_buf[2], b0 * per_utt, e),
+         *o = off(h->rn_buf[3], b0 * per_utt, e), *sc = off(h->rn_buf[4], b0 * per_utt, e), *xn = off(h->rn_buf[5], b0 * per_utt, e);
     const char* stop_env = getenv("SVHIP_RN_STOP");          // developer hook: stop after N blocks, expose x as stage "rn_x"
     const int stop_after = stop_env ? atoi(stop_env) : -1;
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
-             return launch_rn_sinc(d_wav, h->rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
+             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
          }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
     // bf16: the 128 -> 128 pooled blocks (layer1, layer2) each run as ONE fused kernel + the AFMS gate kernel; the gate of
@@ -890,13 +901,13 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
         bp.W2 = reinterpret_cast<const bf16_t*>(K.conv2.W);
         void* dst = (first & 1) ? hb : o;                        // ping-pong: never the buffer being read
         bp.opool = reinterpret_cast<bf16_t*>(dst);
-        bp.colsum = h->rn_part;
+        bp.colsum = rn_part;
         bp.B = B; bp.T = T; bp.Tout = T / 3; bp.ntiles = rn_block128_ntiles(T);
         const double fl = (double)B * T * (K.conv1.flops_per_row + K.conv2.flops_per_row);
         if ((rc = run(h, "rn_block128", fl, [&]() { return launch_rn_block128(bp, h->num_cu, st); }))) return rc;
-        float* gate = h->rn_s + (size_t)(first & 1) * B * 512;   // two gate buffers: block i + 1 reads i's while writing its own
+        float* gate = rn_gate[first & 1];                        // two gate buffers: block i + 1 reads i's while writing its own
         if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
-                 return launch_rn_afms_gate(h->rn_part, rn_block128_nparts(B, bp.T, h->num_cu), B, K.cout, bp.Tout, K.afms_fcT, K.afms_fc.bias, gate, st);
+                 return launch_rn_afms_gate(rn_part, rn_block128_nparts(B, bp.T, h->num_cu), B, K.cout, bp.Tout, K.afms_fcT, K.afms_fc.bias, gate, st);
              }))) return rc;
         T /= 3;
         xin = dst;
@@ -933,15 +944,15 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
             y = hb;
         }
         // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
-        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, h->rn_mean, st, h->rn_scratch, 16); }))) return rc;
+        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, rn_mean, st, rn_scratch, 16); }))) return rc;
         if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
-                 return launch_rn_afms_gate(h->rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, h->rn_s, st);
+                 return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
              }))) return rc;
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
         void* npre = stop_after >= 0 ? nullptr : pre;           // (the developer hook keeps the unfused sequence)
-        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, h->rn_s, B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
     }
@@ -949,13 +960,40 @@ int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
     const int M = B * T;
     // (pre = lrelu(bn_before_agg(x)) came out of block 7's AFMS pass)
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att0, pre, 512, hb, 128, M, ACT_LRELU001))) return rc;
-    if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, h->rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
-    if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(h->rn_logits, pre, bf, B, T, 512, h->rn_pooled, st); }))) return rc;
+    float* rn_logits = h->rn_logits + (size_t)b0 * T * 512;
+    if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
+    if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(rn_logits, pre, bf, B, T, 512, rn_pooled, st); }))) return rc;
     if ((rc = run(h, "rn_fc", 2.0 * B * h->rn_fc.N * h->rn_fc.K, [&]() {
-             return launch_rowvec_linear(h->rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, h->d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st);
+             return launch_rowvec_linear(rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st);
          }))) return rc;
-    h->lastB = B;
     return SVHIP_OK;
+}
+
+// whole batch: one slice, or `lanes` slices on as many streams, so that the small and under-filled kernels of one slice (the late
+// blocks are grids of 86 - 400 workgroups, the AFMS passes are latency-bound) run beside the big ones of another
+int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
+    int rc = SVHIP_OK;
+    const int lanes = (h->lanes > 1 && B >= 16 * h->lanes && !getenv("SVHIP_RN_STOP")) ? h->lanes : 1;
+    if (lanes > 1) {
+        const int per = ((B + lanes - 1) / lanes + 3) & ~3;
+        SV_HIP(h, hipEventRecord(h->lane_ev[4], h->stream));
+        for (int l = 0; l < lanes && !rc; ++l) {
+            const int b0 = l * per, n = std::min(per, B - b0);
+            if (n <= 0) break;
+            SV_HIP(h, hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[4], 0));
+            h->cur = h->lane_stream[l];
+            rc = rawnet2_forward_part(h, d_wav, b0, n);
+            h->cur = h->stream;
+            if (rc) break;
+            SV_HIP(h, hipEventRecord(h->lane_ev[l], h->lane_stream[l]));
+            SV_HIP(h, hipStreamWaitEvent(h->stream, h->lane_ev[l], 0));
+        }
+    } else {
+        h->cur = h->stream;
+        rc = rawnet2_forward_part(h, d_wav, 0, B);
+    }
+    if (!rc) h->lastB = B;
+    return rc;
 }
 
 int check_ready(svhip_handle* h, int B) {
@@ -1040,12 +1078,17 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) h->num_cu = ncu;
     }
     {
-        const char* le = getenv("SVHIP_LANES");            // 1 or 2 (default 2 for ECAPA): half-batches on two streams
-        h->lanes = le ? atoi(le) : 1;                      // measured +3.7 % with 2 lanes, but per-kernel timings then overlap; default 1
-        if (h->lanes != 2 || cfg->model != SVHIP_MODEL_ECAPA) h->lanes = 1;
-        if (h->lanes == 2) {
-            for (int i = 0; i < 2; ++i) (void)hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking);
-            for (int i = 0; i < 3; ++i) (void)hipEventCreateWithFlags(&h->lane_ev[i], hipEventDisableTiming);
+        // batch slices on separate streams, SVHIP_LANES = 1 .. 4 (default 1).  Measured at B = 256: ECAPA -1.5 .. +3.7 % with two
+        // (its big GEMMs fill the chip either way); RawNet2 +3 % with two or three, -22 % with four — slices of ONE call all sit in
+        // the same phase of the network, so little complements.  What does pay for RawNet2 is whole batches in flight on
+        // separate handles / streams (+12 .. 21 %, bench.py `rawnet2_3_streams`): a serving-loop choice, not a library default.
+        const char* le = getenv("SVHIP_LANES");
+        h->lanes = le ? atoi(le) : 1;
+        if (h->lanes < 1 || h->lanes > 4 || cfg->model == SVHIP_MODEL_NONE) h->lanes = 1;
+        if (cfg->model == SVHIP_MODEL_ECAPA && h->lanes > 2) h->lanes = 2;
+        if (h->lanes > 1) {
+            for (int i = 0; i < h->lanes; ++i) (void)hipStreamCreateWithFlags(&h->lane_stream[i], hipStreamNonBlocking);
+            for (int i = 0; i < 5; ++i) (void)hipEventCreateWithFlags(&h->lane_ev[i], hipEventDisableTiming);
         }
     }
     int rc = build_fbank_tables(h);
@@ -1064,8 +1107,8 @@ int svhip_destroy(svhip_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     prof_collect(h);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) if (h->lane_stream[i]) { (void)hipStreamSynchronize(h->lane_stream[i]); (void)hipStreamDestroy(h->lane_stream[i]); }
-    for (int i = 0; i < 3; ++i) if (h->lane_ev[i]) (void)hipEventDestroy(h->lane_ev[i]);
+    for (int i = 0; i < 4; ++i) if (h->lane_stream[i]) { (void)hipStreamSynchronize(h->lane_stream[i]); (void)hipStreamDestroy(h->lane_stream[i]); }
+    for (int i = 0; i < 5; ++i) if (h->lane_ev[i]) (void)hipEventDestroy(h->lane_ev[i]);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SVHIP_OK;
