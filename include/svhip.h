@@ -110,7 +110,10 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
  * (src/processing/audio_loader.py:110-150): wrap-pad files not longer than L to L+1 samples, take num_eval
  * crops of L samples at int(linspace(0, len - L, num_eval)), scale by 1/32768 (soundfile float32).  pcm holds
  * the files back to back; file f is pcm[offsets[f] .. offsets[f] + lengths[f]).  crops_out is
- * (n_files * num_eval, L) fp32.  Ships int16 over PCIe instead of num_eval overlapping fp32 crops. */
+ * (n_files * num_eval, L) fp32.  Ships int16 over PCIe instead of num_eval overlapping fp32 crops.  Host PCM is staged in a
+ * buffer of the handle; with SVHIP_ASYNC (host or device input, device output) the call returns once the copy and the kernel
+ * are enqueued — offsets / lengths are copied before it returns, the PCM array must stay valid until the stream has passed
+ * the copy (immediately for pageable memory; a later synchronisation for pinned memory, which is what makes it overlap). */
 int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, const int64_t* offsets, const int32_t* lengths,
                      int32_t n_files, int32_t num_eval, int32_t L, float* crops_out, int32_t flags);
 

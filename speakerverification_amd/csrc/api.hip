@@ -128,6 +128,13 @@ struct svhip_handle {
     std::vector<ProfEntry> prof_entries;
     double flops_per_utt = 0;
     void* comm = nullptr;                     // RCCL communicator state, owned by comm.hip
+    // svhip_crop_pcm16 staging (host-pointer calls): one grow-only device PCM buffer (copies and kernels are ordered on the
+    // handle's stream) and a ring of pinned host / device metadata slots, each guarded by an event, so that SVHIP_ASYNC calls
+    // can return before the copy has run
+    void* crop_pcm = nullptr; size_t crop_pcm_cap = 0;
+    struct CropSlot { char* host = nullptr; char* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    CropSlot crop_slot[4];
+    int crop_next = 0;
 };
 
 namespace {
@@ -1104,6 +1111,12 @@ int svhip_destroy(svhip_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->comm) (void)svhip_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->crop_pcm) (void)hipFree(h->crop_pcm);
+    for (auto& sl : h->crop_slot) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     for (void* p : h->allocs) (void)hipFree(p);
     prof_collect(h);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
@@ -1257,32 +1270,57 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
     if (!h || !pcm || !offsets || !lengths || !crops_out || n_files <= 0 || num_eval <= 0 || L <= 0 || n_samples <= 0) return SVHIP_ERR_INVALID;
     SV_HIP(h, hipSetDevice(h->cfg.device));
     const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    if ((flags & SVHIP_ASYNC) && !dout) SV_FAIL(h, SVHIP_ERR_INVALID, "SVHIP_ASYNC needs a device output pointer");
     if (!din)      // host metadata is range-checked before it reaches the GPU
         for (int f = 0; f < n_files; ++f)
             if (lengths[f] <= 0 || offsets[f] < 0 || offsets[f] + lengths[f] > n_samples)
                 SV_FAIL(h, SVHIP_ERR_INVALID, "file %d: offset/length outside the PCM buffer", f);
-    void *d_pcm = nullptr, *d_off = nullptr, *d_len = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() {
-        if (!din) { if (d_pcm) (void)hipFree(d_pcm); if (d_off) (void)hipFree(d_off); if (d_len) (void)hipFree(d_len); }
-        if (!dout && d_out) (void)hipFree(d_out);
-    };
-    hipError_t e = hipSuccess;
+    const void *d_pcm = pcm, *d_off = offsets, *d_len = lengths;
+    void* d_out = crops_out;
     const size_t out_bytes = (size_t)n_files * num_eval * L * 4;
+    svhip_handle::CropSlot* slot = nullptr;
     if (!din) {
-        if ((e = hipMalloc(&d_pcm, (size_t)n_samples * 2)) == hipSuccess) e = hipMalloc(&d_off, (size_t)n_files * 8);
-        if (e == hipSuccess) e = hipMalloc(&d_len, (size_t)n_files * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_pcm, pcm, (size_t)n_samples * 2, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, (size_t)n_files * 8, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_len, lengths, (size_t)n_files * 4, hipMemcpyHostToDevice, h->stream);
-    } else { d_pcm = const_cast<int16_t*>(pcm); d_off = const_cast<int64_t*>(offsets); d_len = const_cast<int32_t*>(lengths); }
-    if (e == hipSuccess) { if (dout) d_out = crops_out; else e = hipMalloc(&d_out, out_bytes); }
-    if (e != hipSuccess) { cleanup(); SV_FAIL(h, SVHIP_ERR_HIP, "crop staging failed: %s", hipGetErrorString(e)); }
+        // PCM: one device buffer (the copy is ordered behind the previous call's kernel on this stream); pageable host memory makes
+        // the copy call itself block until the bytes are staged, pinned memory makes it truly asynchronous
+        const size_t pcm_bytes = (size_t)n_samples * 2;
+        if (h->crop_pcm_cap < pcm_bytes) {
+            SV_HIP(h, hipStreamSynchronize(h->stream));
+            if (h->crop_pcm) (void)hipFree(h->crop_pcm);
+            h->crop_pcm = nullptr; h->crop_pcm_cap = 0;
+            SV_HIP(h, hipMalloc(&h->crop_pcm, pcm_bytes + pcm_bytes / 4));
+            h->crop_pcm_cap = pcm_bytes + pcm_bytes / 4;
+        }
+        // metadata: copied into a pinned slot of the handle, so the caller's arrays are free on return
+        slot = &h->crop_slot[h->crop_next];
+        h->crop_next = (h->crop_next + 1) & 3;
+        if (slot->busy) { SV_HIP(h, hipEventSynchronize(slot->done)); slot->busy = false; }
+        const size_t meta = (size_t)n_files * 12;
+        if (slot->cap < meta) {
+            if (slot->host) (void)hipHostFree(slot->host);
+            if (slot->dev) (void)hipFree(slot->dev);
+            slot->host = slot->dev = nullptr; slot->cap = 0;
+            SV_HIP(h, hipHostMalloc((void**)&slot->host, meta * 2, hipHostMallocDefault));
+            SV_HIP(h, hipMalloc((void**)&slot->dev, meta * 2));
+            slot->cap = meta * 2;
+            if (!slot->done) SV_HIP(h, hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+        }
+        memcpy(slot->host, offsets, (size_t)n_files * 8);
+        memcpy(slot->host + (size_t)n_files * 8, lengths, (size_t)n_files * 4);
+        SV_HIP(h, hipMemcpyAsync(h->crop_pcm, pcm, pcm_bytes, hipMemcpyHostToDevice, h->stream));
+        SV_HIP(h, hipMemcpyAsync(slot->dev, slot->host, meta, hipMemcpyHostToDevice, h->stream));
+        d_pcm = h->crop_pcm; d_off = slot->dev; d_len = slot->dev + (size_t)n_files * 8;
+    }
+    void* tmp_out = nullptr;
+    if (!dout) { SV_HIP(h, hipMalloc(&tmp_out, out_bytes)); d_out = tmp_out; }
+    h->cur = h->stream;
     int rc = run(h, "crop_pcm16", 0, [&]() { return launch_crop_pcm16((const int16_t*)d_pcm, (const int64_t*)d_off, (const int32_t*)d_len, n_files, num_eval, L, (float*)d_out, h->stream); });
-    if (!rc && !dout) e = hipMemcpyAsync(crops_out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
-    if (!(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
-    cleanup();
+    hipError_t e = hipSuccess;
+    if (slot && !rc) { e = hipEventRecord(slot->done, h->stream); slot->busy = e == hipSuccess; }
+    if (!rc && !dout && e == hipSuccess) e = hipMemcpyAsync(crops_out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
+    if (!(flags & SVHIP_ASYNC)) { const hipError_t e2 = hipStreamSynchronize(h->stream); if (e == hipSuccess) e = e2; }
+    if (tmp_out) (void)hipFree(tmp_out);
     if (rc) return rc;
-    if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "crop copy-out failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) SV_FAIL(h, SVHIP_ERR_HIP, "crop staging / copy failed: %s", hipGetErrorString(e));
     return SVHIP_OK;
 }
 

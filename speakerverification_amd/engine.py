@@ -212,25 +212,41 @@ class Engine:
         self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out
 
-    def crop_pcm16(self, pcm_list, num_eval, L=32000, out=None):
+    def crop_pcm16(self, pcm_list, num_eval, L=32000, out=None, async_=False):
         """list of 1-D int16 arrays (decoded files) -> (len(list) * num_eval, L) fp32 eval-mode crops, cropped on
         the device (int16 travels over PCIe; reference semantics of loadWAV for 16-bit files).  With ``out`` a CUDA
         tensor the crops stay in HBM (the embed call then takes them as a device pointer: no fp32 crop crosses PCIe)."""
         lens = np.asarray([len(a) for a in pcm_list], dtype=np.int32)
         offs = np.zeros(len(pcm_list), dtype=np.int64)
         offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        if len(pcm_list) == 1 and _is_torch(pcm_list[0]):          # one packed (pinned) int16 tensor holding the files back to back
+            raise ValueError("pass packed PCM through crop_pcm16_packed")
         pcm = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int16) for a in pcm_list]))
-        n = len(pcm_list) * num_eval
+        return self.crop_pcm16_packed(pcm, offs, lens, num_eval, L, out=out, async_=async_)
+
+    def crop_pcm16_packed(self, pcm, offs, lens, num_eval, L=32000, out=None, async_=False):
+        """the files back to back in ONE int16 array (numpy, or a pinned torch tensor for truly asynchronous copies) with their
+        offsets / lengths; async_=True (device `out` only) returns once the copy and the crop kernel are enqueued."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        p = _Buf(pcm, np.int16)
+        if p.device:
+            raise ValueError("packed PCM lives on the host (device PCM: call the C ABI with SVHIP_IN_DEVICE)")
+        n_files = int(lens.shape[0])
+        n = n_files * num_eval
         if out is None:
             out = np.empty((n, L), dtype=np.float32)
         elif tuple(out.shape) != (n, L):
             raise ValueError(f"out must be ({n}, {L})")
         o = _Buf(out, np.float32, writable=True)
-        self._order_after_torch(o)
-        TRANSFER_STATS["h2d_bytes"] += pcm.nbytes + offs.nbytes + lens.nbytes
+        if async_ and not o.device:
+            raise ValueError("async_ needs a device output tensor")
+        self._order_after_torch(o, async_=async_)
+        TRANSFER_STATS["h2d_bytes"] += p.nbytes + offs.nbytes + lens.nbytes
         _count([], [o])
-        self._ck(self.lib.svhip_crop_pcm16(self.h, pcm.ctypes.data, pcm.size, offs.ctypes.data, lens.ctypes.data, len(pcm_list),
-                                           int(num_eval), int(L), o.ptr, _lib.OUT_DEVICE if o.device else 0))
+        flags = (_lib.OUT_DEVICE if o.device else 0) | (_lib.ASYNC if async_ else 0)
+        self._ck(self.lib.svhip_crop_pcm16(self.h, p.ptr, p.nbytes // 2, offs.ctypes.data, lens.ctypes.data, n_files,
+                                           int(num_eval), int(L), o.ptr, flags))
         return out
 
     def synth_waveforms(self, seed, first_utt, B, L=None, out=None, async_=False):

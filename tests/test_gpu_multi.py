@@ -134,3 +134,29 @@ def test_per_trial_scoring_api_with_the_real_engine(golden_dir):
     assert float(np.abs(scoring.score_trials(feats, ia, ib, "cosine") - g["cosine"]).max()) <= 1e-5
     assert float(np.abs(scoring.score_trials(feats, ia, ib, "norm", cohorts=g["cohort"], top=top) - g["zt_norm"]).max()) <= 1e-4
     assert float(np.abs(scoring.score_trials(feats, ia, ib, "pnorm") - g["pnorm"]).max()) <= 1e-5
+
+
+def test_handles_on_two_devices_in_one_process():
+    """launch attributes are kept per device, so one process may own handles on several GPUs.  (gpurun boxes show one
+    GPU: skipped there; the bookkeeping itself is covered on the CPU by svhip_selftest.)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=1)
+    wav = synth.synth_waveforms(4)
+    outs = []
+    for dev in (0, 1):
+        eng = Engine(model="ecapa", compute="bf16", channels=512, max_batch=4, device=dev)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs.append(eng.embed_wave(wav))
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_load_tensor_rejects_null_data():
+    """a 0-d tensor still holds one element; NULL data is refused for every rank."""
+    eng = Engine(model="ecapa", channels=64, max_batch=1)
+    shape = (C.c_int64 * 1)(0)
+    rc = eng.lib.svhip_load_tensor(eng.h, b"blocks.0.norm.norm.num_batches_tracked", None, shape, 0, _lib.I64)
+    assert rc == -1 and b"null data" in eng.lib.svhip_last_error(eng.h)
+    eng.close()
