@@ -76,3 +76,36 @@ def test_rawnet2_batch_sizes(B):
     a, b = outs["f32"], outs["bf16"]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.isfinite(b).all() and cos.min() >= 0.99, cos
+
+
+@pytest.mark.parametrize("L,B", [(8000, 5), (24000, 3), (40000, 2), (32000, 40)])
+def test_fused_blocks_other_geometries(L, B, monkeypatch):
+    """csrc/rn_block128.hip (the fused 128-channel residual blocks) on other utterance lengths / batch sizes: tile counts that do
+    not divide, several utterances per workgroup, short last tiles — against the unfused kernel sequence (same bf16 storage
+    points, so the two agree to bf16 round-off) and the fp32 engine."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=2)
+    wav = synth.synth_waveforms(B, L, seed=5)
+    outs = {}
+    for name, compute, unfused in (("f32", "f32", False), ("unfused", "bf16", True), ("fused", "bf16", False)):
+        if unfused:
+            monkeypatch.setenv("SVHIP_RN_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("SVHIP_RN_UNFUSED", raising=False)
+        eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[name] = eng.embed_wave(wav).reshape(B, -1)
+        if name == "fused":
+            again = eng.embed_wave(wav).reshape(B, -1)
+            assert np.array_equal(again, outs[name])                         # deterministic (no atomics, fixed summation order)
+        eng.close()
+    scale = float(np.abs(outs["f32"]).max())
+    assert np.isfinite(outs["fused"]).all()
+    assert float(np.abs(outs["fused"] - outs["unfused"]).max()) <= 0.03 * scale
+    # bf16 RawNet2 on arbitrary random weights can sit far from fp32 (8 un-normalised residual blocks); what this test pins is that
+    # the fused kernels are no further from the fp32 engine than the unfused bf16 sequence they replace
+    def cos_to_f32(a):
+        return (a * outs["f32"]).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(outs["f32"], axis=1))
+    cf, cu = cos_to_f32(outs["fused"]), cos_to_f32(outs["unfused"])
+    print("cos fused", cf, "unfused", cu)
+    assert cf.min() >= cu.min() - 0.02 and cf.min() >= 0.9, (cf, cu)
