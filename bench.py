@@ -18,7 +18,8 @@ Prints ONE JSON line on rank 0 (field contract: README / DESIGN.md §5): `value`
 the dominant kernel (the pointwise-conv MFMA GEMM) timed with HIP events on the launch stream inside the timed region;
 `cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only); sub-records:
 `check` (the last timed step's embeddings verified against the fp32-parity path and a bitwise re-run), `scoring`
-(BASELINE configs[3] + CPU baselines), `rawnet2` (configs[2]), `ecapa_f32` (the 1e-4-parity path), `pcie` (int16 PCM over
+(BASELINE configs[3] + CPU baselines), `rawnet2` (configs[2]), `ecapa_f32` / `ecapa_f32x3` (the 1e-4-parity paths: exact fp32
+MFMA / split-bf16 MFMA triples on fp32 operands), `pcie` (int16 PCM over
 PCIe -> device crop -> embed), `shard` (multi-GPU: all-gather + row-sharded scoring of the gathered matrix).
 """
 from __future__ import annotations
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "f32x3"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--model", default="ecapa", choices=["ecapa", "rawnet2"], help="ecapa = headline (configs[1]); rawnet2 = configs[2]")
     ap.add_argument("--config", default="batch", choices=["batch", "shard"],
@@ -251,11 +252,12 @@ def make_engine(model, compute, B, local, embed=None):
 def dominant_label(model, compute):
     if model == "rawnet2":
         return "rn_block128"              # the fused 128-channel residual blocks: 41 % of the model's FLOPs in two launches
-    return "gemm_pw2" if compute == "bf16" else "gemm_pw"
+    return "gemm_pw2" if compute == "bf16" else "gemm_pw"       # f32 / f32x3: the LDS-DMA kernel on fp32 operands
 
 
 def roofline_of(prof, label, compute):
-    peak = PEAK_BF16_TFLOPS if compute == "bf16" else PEAK_F32_TFLOPS
+    # f32x3: three bf16 MFMAs per product -> the bf16 peak / 3 is what an x3 kernel can deliver in reference-graph FLOPs
+    peak = {"bf16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS, "f32x3": PEAK_BF16_TFLOPS / 3.0}[compute]
     dom = prof.get(label, {"ms": 0.0, "launches": 0, "flops": 0.0})
     avg_ms = dom["ms"] / max(1, dom["launches"])
     achieved = (dom["flops"] / max(1, dom["launches"])) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -673,6 +675,7 @@ def run_batch(args, ranks, dev):
             for name, fn in (("rawnet2", lambda: sub_bench("rawnet2", "bf16", B, local, dev, wavs)),
                              ("rawnet2_3_streams", lambda: multi_stream_bench("rawnet2", "bf16", B, local, dev, wavs)),
                              ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
+                             ("ecapa_f32x3", lambda: sub_bench("ecapa", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:
                     line[name] = fn()

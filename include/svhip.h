@@ -43,13 +43,15 @@ typedef enum svhip_status {
 } svhip_status;
 
 enum { SVHIP_MODEL_ECAPA = 0, SVHIP_MODEL_RAWNET2 = 1, SVHIP_MODEL_NONE = 2 /* fbank + scoring only */ };
-enum { SVHIP_F32 = 0, SVHIP_BF16 = 1, SVHIP_I64 = 2 };
+enum { SVHIP_F32 = 0, SVHIP_BF16 = 1, SVHIP_I64 = 2, SVHIP_F32X3 = 3 /* compute only */ };
 enum { SVHIP_IN_DEVICE = 1, SVHIP_OUT_DEVICE = 2, SVHIP_ASYNC = 4 };
 
 typedef struct svhip_config {
     int32_t struct_size;    /* = sizeof(svhip_config), for ABI evolution */
     int32_t model;          /* SVHIP_MODEL_* */
-    int32_t compute;        /* SVHIP_F32: fp32 MFMA, 1e-4 parity path; SVHIP_BF16: bf16 MFMA, fp32 accumulate */
+    int32_t compute;        /* SVHIP_F32: fp32 MFMA, 1e-4 parity path; SVHIP_BF16: bf16 MFMA, fp32 accumulate;
+                               SVHIP_F32X3: fp32 storage and arithmetic everywhere except the k = 1 / k = 5 convolution GEMMs, whose
+                               products are three bf16 MFMAs on hi / lo-split fp32 operands (~2^-17 per product): 1e-4 parity, ~2x faster */
     int32_t device;         /* HIP device ordinal */
     int32_t channels;       /* ECAPA C (channels = [C,C,C,C,3C], ECAPA_TDNN.py:378) */
     int32_t n_mels;         /* 80 */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SVHIP_LIB_PATH") or os.path.join(HERE, "libsvhip.so")
 
 OK = 0
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
-F32, BF16, I64 = 0, 1, 2
+F32, BF16, I64, F32X3 = 0, 1, 2, 3
 IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
 COMM_ID_BYTES = 128
 

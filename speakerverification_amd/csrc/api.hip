@@ -30,6 +30,7 @@ struct HostTensor {
 struct ConvLayer {            // one conv1d as a GEMM operand set (device pointers)
     int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, dil = 1, cin = 0;
     void* W = nullptr;        // packed [Np][Kp] in the compute dtype
+    void* Wsplit = nullptr;   // SVHIP_F32X3 handles: the same matrix as (hi bf16 << 16 | lo bf16) words, for gemm_pw's split path
     float* bias = nullptr;    // [N] or null
     float* scale = nullptr;   // folded BatchNorm (eval): y = x*scale + shift, or null
     float* shift = nullptr;
@@ -56,6 +57,7 @@ struct svhip_handle {
     hipEvent_t lane_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // [lane] done events, [4] = fork point
     int lanes = 1;                            // > 1: the forward runs as that many batch slices on as many streams
     bool bf16 = false;
+    bool x3 = false;                          // SVHIP_F32X3: fp32 handle whose conv GEMMs run as split-bf16 MFMA triples
     bool finalized = false;
     std::string err;
     std::map<std::string, HostTensor> host_w;
@@ -453,6 +455,18 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
         float* d;
         if ((rc = dev_upload(h, &d, packed))) return rc;
         L.W = d;
+        if (h->x3) {
+            std::vector<uint32_t> ws(packed.size());
+            for (size_t i = 0; i < packed.size(); ++i) {
+                const uint16_t hi = f32_to_bf16_rne(packed[i]);
+                uint32_t hu = (uint32_t)hi << 16;
+                float hf; memcpy(&hf, &hu, 4);
+                ws[i] = hu | f32_to_bf16_rne(packed[i] - hf);
+            }
+            uint32_t* dsplit;
+            if ((rc = dev_upload(h, &dsplit, ws))) return rc;
+            L.Wsplit = dsplit;
+        }
     }
     if (!bname.empty()) {
         const HostTensor* b = getw(h, bname);
@@ -714,6 +728,10 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
     const bool bf = h->bf16;
+    if (h->x3) {              // gemm_pw takes the pre-split weights, the generic kernel (A2 / ragged shapes) the fp32 ones
+        p.x3 = 1;
+        if (gemm_pw_supported(p, false) && L.Wsplit) p.W = L.Wsplit;
+    }
     hipStream_t st = h->cur;
     (void)label;
     if (p.colsum) {                       // only the pw2 epilogue produces the partials; otherwise the caller falls back
@@ -1072,6 +1090,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
     svhip_handle* h = new svhip_handle();
     h->cfg = *cfg;
     h->bf16 = cfg->compute == SVHIP_BF16;
+    h->x3 = cfg->compute == SVHIP_F32X3;
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
     if (cfg->stream) { h->stream = reinterpret_cast<hipStream_t>(cfg->stream); h->own_stream = false; }

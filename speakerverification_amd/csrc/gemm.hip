@@ -89,7 +89,19 @@ __device__ __forceinline__ float epilogue_act1(float v) {
     return v;
 }
 
-template <typename T, bool CONV, bool HAS_A2, int EPI>
+// fp32 value pair -> bf16 hi / lo parts (x = hi + lo up to 2^-17 relative): eight k-values of one fragment row
+__device__ __forceinline__ void split_hi_lo(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t ha = static_cast<bf16_t>(a[e]), hb = static_cast<bf16_t>(b[e]);
+        hi[e] = ha; hi[4 + e] = hb;
+        lo[e] = static_cast<bf16_t>(a[e] - static_cast<float>(ha));
+        lo[4 + e] = static_cast<bf16_t>(b[e] - static_cast<float>(hb));
+    }
+}
+
+// X3 (T = float only, SVHIP_F32X3 handles): every product as three bf16 MFMAs on hi / lo-split fragments (see gemm_pw.hip)
+template <typename T, bool CONV, bool HAS_A2, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     typedef MmaTraits<T> TR;
     typedef typename TR::chunk_t chunk_t;
@@ -204,6 +216,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         if (kt + 1 < nk) load_tile(kt + 1);
         const char* As = smem + buf * (2 * TILE_BYTES);
         const char* Bs = As + TILE_BYTES;
+        if constexpr (X3) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {         // chunks (4pr + fh, 4pr + 2 + fh) of a row = this lane's 8 of the step's 16 k-values
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    split_hi_lo(*reinterpret_cast<const f32x4*>(As + swz(wm * 64 + i * 32 + fr, 4 * pr + fh)),
+                                *reinterpret_cast<const f32x4*>(As + swz(wm * 64 + i * 32 + fr, 4 * pr + 2 + fh)), ah[i], al[i]);
+                    split_hi_lo(*reinterpret_cast<const f32x4*>(Bs + swz(wn * 64 + i * 32 + fr, 4 * pr + fh)),
+                                *reinterpret_cast<const f32x4*>(Bs + swz(wn * 64 + i * 32 + fr, 4 * pr + 2 + fh)), bh[i], bl[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             chunk_t af[2], bfr[2];
@@ -216,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) TR::mma(af[i], bfr[j], acc[i][j]);
+        }
         }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
@@ -251,15 +285,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T, bool CONV, bool HAS_A2, int EPI>
-hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+template <typename T, bool CONV, bool HAS_A2, int EPI, bool X3>
+hipError_t launch_inst_x(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     dim3 grid(ntm * ntn), block(256);
     const size_t lds = 4 * TILE_BYTES;
     static DeviceOnce attr;         // 64 KiB of dynamic LDS per workgroup, raised once per device
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_kernel<T, CONV, HAS_A2, EPI>), (int)lds)) return e;
-    hipLaunchKernelGGL((gemm_kernel<T, CONV, HAS_A2, EPI>), grid, block, lds, stream, p);
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_kernel<T, CONV, HAS_A2, EPI, X3>), (int)lds)) return e;
+    hipLaunchKernelGGL((gemm_kernel<T, CONV, HAS_A2, EPI, X3>), grid, block, lds, stream, p);
     return hipGetLastError();
+}
+
+template <typename T, bool CONV, bool HAS_A2, int EPI>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+    if constexpr (sizeof(T) == 4) {
+        if (p.x3) return launch_inst_x<T, CONV, HAS_A2, EPI, true>(p, stream);
+    }
+    return launch_inst_x<T, CONV, HAS_A2, EPI, false>(p, stream);
 }
 
 template <typename T, int EPI>

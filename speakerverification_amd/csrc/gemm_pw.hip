@@ -96,8 +96,24 @@ template <> struct Frag<bf16_t> {
 
 // CONV: the A operand is the im2col view of a dilated 1-D convolution (per-lane DMA source = frame
 // t + (tap - taps/2)*dil of the same utterance, reflect / zero padded; padded chunks read a zero page).
-template <typename T, int EPI, bool OUT_F32, int PBN, bool CONV>
+// fp32 value pair -> bf16 hi / lo parts (x = hi + lo up to 2^-17 relative): eight k-values of one fragment row
+__device__ __forceinline__ void split_hi_lo(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t ha = static_cast<bf16_t>(a[e]), hb = static_cast<bf16_t>(b[e]);
+        hi[e] = ha; hi[4 + e] = hb;
+        lo[e] = static_cast<bf16_t>(a[e] - static_cast<float>(ha));
+        lo[4 + e] = static_cast<bf16_t>(b[e] - static_cast<float>(hb));
+    }
+}
+
+// X3 (T = float only): fp32 operands in memory and LDS, each product formed as THREE bf16 MFMAs on hi / lo-split fragments
+// (hi.hi + hi.lo + lo.hi, fp32 accumulate): ~2^-17 relative per product instead of 2^-24, at 3/16 of the fp32 MFMA's cycles.
+// The activations are split in registers after the fragment read; the packed weights hold (hi bf16 << 16) | lo bf16 per fp32
+// slot (api.hip make_conv, SVHIP_F32X3 handles), so their "split" is two byte permutes per pair.
+template <typename T, int EPI, bool OUT_F32, int PBN, bool CONV, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
+    static_assert(!X3 || sizeof(T) == 4, "the split path reads fp32 operands");
     typedef Frag<T> FR;
     typedef typename FR::chunk_t chunk_t;
     typedef TileCfg<PBN> TC;
@@ -191,6 +207,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
         const char* As = smem + stage * STAGE;
         const char* Bs = As + A_TILE;
         if (DBG && (p.debug & 2)) { stage = stage == NSTAGE - 1 ? 0 : stage + 1; continue; }
+        if constexpr (X3) {
+            // lane (fr, fh) holds chunk 2s + fh of its row for s = 0..3; chunks (2s, 2s+1) x (s, s+1) = 16 k-values = one bf16 MFMA step
+            f32x4 xc[4][MI], wc[4][2];
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xc[ss][i] = *reinterpret_cast<const f32x4*>(As + swz(wm * WROWS + i * 32 + fr, 2 * ss + fh));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wc[ss][j] = *reinterpret_cast<const f32x4*>(Bs + swz(wn * 64 + j * 32 + fr, 2 * ss + fh));
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                bf16x8 xh[MI], xl[MI], wh[2], wl[2];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) split_hi_lo(xc[2 * pr][i], xc[2 * pr + 1][i], xh[i], xl[i]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {        // the weights were split at load time: word = (hi bf16 << 16) | lo bf16 (two v_perm per two k)
+                    u32x4 wa, wb, ph, pl;
+                    __builtin_memcpy(&wa, &wc[2 * pr][j], 16);
+                    __builtin_memcpy(&wb, &wc[2 * pr + 1][j], 16);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        ph[e] = __builtin_amdgcn_perm(wa[2 * e + 1], wa[2 * e], 0x07060302u);
+                        pl[e] = __builtin_amdgcn_perm(wa[2 * e + 1], wa[2 * e], 0x05040100u);
+                        ph[2 + e] = __builtin_amdgcn_perm(wb[2 * e + 1], wb[2 * e], 0x07060302u);
+                        pl[2 + e] = __builtin_amdgcn_perm(wb[2 * e + 1], wb[2 * e], 0x05040100u);
+                    }
+                    __builtin_memcpy(&wh[j], &ph, 16);
+                    __builtin_memcpy(&wl[j], &pl, 16);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);     // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+                    }
+            }
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            continue;
+        }
         // fragment reads are software-pipelined one k-substep ahead of the MFMAs that consume them
         chunk_t xf[2][MI], wf[2][2];
 #pragma unroll
@@ -299,13 +357,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     }
 }
 
-template <typename T, int EPI, bool OUT_F32, int BN, bool CONV>
-hipError_t launch_inst2(const GemmParams& p, hipStream_t stream) {
+template <typename T, int EPI, bool OUT_F32, int BN, bool CONV, bool X3>
+hipError_t launch_inst3(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + PBM - 1) / PBM, ntn = (p.N + BN - 1) / BN;
     static DeviceOnce attr;
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>), TileCfg<BN>::LDS)) return e;
-    hipLaunchKernelGGL((gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV>), dim3(ntm * ntn), dim3(512), TileCfg<BN>::LDS, stream, p);
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV, X3>), TileCfg<BN>::LDS)) return e;
+    hipLaunchKernelGGL((gemm_pw_kernel<T, EPI, OUT_F32, BN, CONV, X3>), dim3(ntm * ntn), dim3(512), TileCfg<BN>::LDS, stream, p);
     return hipGetLastError();
+}
+
+template <typename T, int EPI, bool OUT_F32, int BN, bool CONV>
+hipError_t launch_inst2(const GemmParams& p, hipStream_t stream) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (p.x3) return launch_inst3<T, EPI, OUT_F32, BN, CONV, true>(p, stream);
+    }
+    return launch_inst3<T, EPI, OUT_F32, BN, CONV, false>(p, stream);
 }
 
 template <typename T, int EPI, bool OUT_F32, int BN>

@@ -74,6 +74,8 @@ struct GemmParams {
     int taps = 1, dil = 1, cin = 0, pad_mode = 0;
     int act1 = 0, act2 = 0;
     int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
+    int x3 = 0;               // fp32 operands only: products as three bf16 MFMAs on hi / lo-split fragments.  gemm_pw then expects W as
+                              // (hi bf16 << 16 | lo bf16) words (ConvLayer::Wsplit); the generic kernel splits true fp32 W itself
     int debug = 0;            // developer ablations (tools/gemm_bench): 1 no loads in the loop, 2 no MFMA, 4 no epilogue
     int Wrows = 0;            // allocated rows of W (loads clamp to Wrows-1); packed weights: N rounded up to 128
 };

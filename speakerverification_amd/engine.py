@@ -70,7 +70,7 @@ class Engine:
         self.lib = _lib.load()
         cfg = _lib.default_config()
         cfg.model = {"ecapa": _lib.MODEL_ECAPA, "rawnet2": _lib.MODEL_RAWNET2, "none": _lib.MODEL_NONE}[model]
-        cfg.compute = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16}[compute]
+        cfg.compute = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16, "f32x3": _lib.F32X3, "bf16x3": _lib.F32X3}[compute]
         cfg.device = int(device)
         cfg.channels = int(channels)
         cfg.n_mels = int(n_mels)
@@ -86,7 +86,7 @@ class Engine:
         cfg.stream = C.c_void_p(int(stream)) if stream else None
         self.cfg = cfg
         self.model = model
-        self.compute = "bf16" if cfg.compute == _lib.BF16 else "f32"
+        self.compute = {_lib.BF16: "bf16", _lib.F32X3: "f32x3"}.get(cfg.compute, "f32")
         self.max_batch = cfg.max_batch
         self.samples = cfg.samples
         self.frames = cfg.samples // cfg.hop_length + 1

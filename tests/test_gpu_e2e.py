@@ -110,3 +110,21 @@ def test_prepare_cohorts_and_test_from_list_match_reference(handler, golden_dir)
     embs = {f: torch.nn.functional.normalize(mh.embed_utterance(f, num_eval=2, normalize=False), p=2, dim=1).numpy() for f in files}
     want = [o_scoring.zt_norm_similarity(embs[t.split()[0]], embs[t.split()[1]], coh, 200) for t in tr]
     assert float(np.abs(np.array(sc) - np.array(want)).max()) <= 2e-3      # (s - mu) / sigma amplifies 1e-6 score noise by 1/sigma ~ 1e2
+
+
+def test_evaluate_from_list_f32x3_matches_reference(tmp_path, golden_dir):
+    """the split-bf16 compute mode (hip_compute='f32x3') end to end: the reference's golden cosine scores within the same 1e-4"""
+    import torch
+    tmp = str(tmp_path)
+    args = dict(ARGS, hip_compute="f32x3", save_folder=tmp)
+    net = WrappedModel(SpeakerEncoder(**args))
+    mh = ModelHandling(net, **args)
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E_SEED_W)
+    net.module.load_state_dict({"__S__." + k: v for k, v in sd.items()})
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    files, trial_path, lines = make_e2e_files(tmp)
+    sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path="unused",
+                                      num_eval=2, scoring_mode="cosine")
+    err = float(np.abs(np.array(sc) - g["scores_ne2"]).max())
+    print("f32x3 e2e cosine score error", err)
+    assert err <= 1e-4, err

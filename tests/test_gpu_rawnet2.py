@@ -19,16 +19,17 @@ def make(compute, seed_w):
     return m
 
 
-def test_rawnet2_fp32_matches_reference(golden_dir):
+@pytest.mark.parametrize("compute", ["f32", "f32x3"])
+def test_rawnet2_fp32_matches_reference(golden_dir, compute):
     g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
-    m = make("f32", int(g["seed_w"]))
+    m = make(compute, int(g["seed_w"]))
     x = synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"]))
     out = m(x)
     ref = g["out"]
     assert out.shape == ref.shape == (2, 320)
     scale = float(np.abs(ref).max())
     err = float(np.abs(out - ref).max())
-    print("rawnet2 fp32 err", err, "scale", scale)
+    print("rawnet2", compute, "err", err, "scale", scale)
     # outputs are un-normalised and large (|out| ~ 280 with these weights): tolerance 1e-4 of the scale
     assert err <= 1e-4 * scale
     # what scoring consumes: L2-normalised embeddings within 1e-4
