@@ -237,14 +237,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
                     __builtin_memcpy(&wh[j], &ph, 16);
                     __builtin_memcpy(&wl[j], &pl, 16);
                 }
+                // term-major: consecutive MFMAs hit different accumulators (small terms first)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);     // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
             }
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             continue;
