@@ -171,13 +171,13 @@ def scoring_cpu_baseline(E, cohort, ia, ib, top):
     return res
 
 
-def scoring_bench(dev, with_cpu=True):
+def scoring_bench(dev, with_cpu=True, compute="f32"):
     """BASELINE config 4: 1.2 M synthetic 192-d embeddings, 1.2 M-trial list, cohort 5994, top 200."""
     import numpy as np
     import torch
     from speakerverification_amd.engine import Engine
     assert torch.cuda.current_stream().cuda_stream != 0
-    eng = Engine(model="none", device=dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    eng = Engine(model="none", device=dev.index, stream=torch.cuda.current_stream().cuda_stream, compute=compute)
     N, P, K, top, D = 1_200_000, 1_200_000, 5994, 200, 192
     g = torch.Generator(device=dev).manual_seed(2)
     E = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32)
@@ -225,7 +225,7 @@ def scoring_bench(dev, with_cpu=True):
     res["min_dcf_trials_per_s"] = P / t
     t = timed(lambda: eng.roc_points(sc_host, lab_host))
     res["roc_points_trials_per_s"] = P / t
-    res["config"] = {"embeddings": N, "trials": P, "cohort": K, "top": top, "dim": D}
+    res["config"] = {"embeddings": N, "trials": P, "cohort": K, "top": top, "dim": D, "gemm": compute}
     if with_cpu:
         res["cpu_baseline"] = scoring_cpu_baseline(E[:200_000].cpu().numpy(), cohort.cpu().numpy(),
                                                    np.arange(200_000), np.random.default_rng(4).permutation(200_000), top)
@@ -669,6 +669,10 @@ def run_batch(args, ranks, dev):
         if world == 1 and not args.no_scoring and args.model == "ecapa":
             try:
                 line["scoring"] = scoring_bench(dev, with_cpu=not args.no_cpu_baseline)
+                if not args.no_extras:   # same workload with the score GEMMs as split-bf16 MFMA triples (exact fp32 stays the default)
+                    x3 = scoring_bench(dev, with_cpu=False, compute="f32x3")
+                    line["scoring_f32x3"] = {k: x3[k] for k in ("asnorm_pairs_per_s", "asnorm_stats_s", "asnorm_cohort_gemm_TFLOPs",
+                                                                 "dense_pairs_per_s", "dense_TFLOPs", "config")}
             except Exception as e:  # scoring is reported next to, not inside, the headline
                 line["scoring"] = {"error": repr(e)}
         if world == 1 and not args.no_extras and args.model == "ecapa" and args.compute == "bf16":

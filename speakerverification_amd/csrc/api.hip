@@ -1443,16 +1443,27 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     return pairs_common(h, 1, E, N, D, mu, sigma, ia, ib, P, out, flags);
 }
 
-// out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed)
-static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO, int64_t ldo) {
+// out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed).  On an
+// SVHIP_F32X3 handle the products are split-bf16 MFMA triples: `dBsplit` is B as (hi << 16 | lo) words (split_b below).
+static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO, int64_t ldo,
+                      const void* dBsplit = nullptr) {
     if (D % 32 != 0) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embedding dim %d must be a multiple of 32", D);
     if (Na > (1 << 30) / 1 || Nb > (1 << 30)) SV_FAIL(h, SVHIP_ERR_INVALID, "matrix too large");
     GemmParams p;
     p.A = dA; p.W = dB; p.Y = dO;
     p.M = (int)Na; p.N = (int)Nb; p.K = D; p.Kp = D; p.Wrows = (int)Nb;
     p.lda = D; p.ldy = (int)ldo; p.T = 1;
+    if (dBsplit && gemm_pw_supported(p, false)) { p.W = dBsplit; p.x3 = 1; }
     hipStream_t st = h->stream;
     return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
+}
+
+// F32X3 handles: B as split words in a temporary the caller frees after the stream has drained (nullptr on exact handles)
+static int split_b(svhip_handle* h, const float* dB, int64_t Nb, int D, void** out) {
+    *out = nullptr;
+    if (!h->x3) return SVHIP_OK;
+    SV_HIP(h, hipMalloc(out, (size_t)Nb * D * 4));
+    return run(h, "split_words", 0, [&]() { return launch_split_words(dB, *out, Nb * D, h->stream); });
 }
 
 int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float* B, int64_t Nb, int32_t D, float* out, int32_t flags) {
@@ -1466,10 +1477,13 @@ int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float*
     if ((rc = tA.in(A, (size_t)Na * D * 4, din, &dA))) return rc;
     if ((rc = tB.in(B, (size_t)Nb * D * 4, din, &dB))) return rc;
     if ((rc = tO.out(out, (size_t)Na * Nb * 4, dout, &dO))) return rc;
-    if ((rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb))) return rc;
-    if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream));
-    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
-    return SVHIP_OK;
+    void* bsplit = nullptr;
+    if ((rc = split_b(h, (const float*)dB, Nb, D, &bsplit))) { if (bsplit) (void)hipFree(bsplit); return rc; }
+    rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb, bsplit);
+    if (!rc && !dout) { const hipError_t e = hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream); if (e != hipSuccess) rc = SVHIP_ERR_HIP; }
+    if (bsplit || !(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
+    if (bsplit) (void)hipFree(bsplit);
+    return rc;
 }
 
 int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* cohort, int32_t K, int32_t top,
@@ -1492,15 +1506,18 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     const int64_t ldk = (K + 3) & ~3;                             // row stride of the slab (16-byte rows for the DMA GEMM)
     const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 31) / (ldk * 4)));
     float* slab = nullptr;
-    SV_HIP(h, hipMalloc((void**)&slab, (size_t)slab_rows * ldk * 4));
+    void* csplit = nullptr;
+    if ((rc = split_b(h, (const float*)dC, K, D, &csplit))) { if (csplit) (void)hipFree(csplit); return rc; }
+    if (hipMalloc((void**)&slab, (size_t)slab_rows * ldk * 4) != hipSuccess) { if (csplit) { (void)hipStreamSynchronize(h->stream); (void)hipFree(csplit); } SV_FAIL(h, SVHIP_ERR_NOMEM, "cohort score slab"); }
     for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
         const int64_t rows = std::min(slab_rows, N - r0);
-        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab, ldk);
+        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab, ldk, csplit);
         if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, (int)ldk, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
         if (rc) break;
     }
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(slab);
+    if (csplit) (void)hipFree(csplit);
     if (rc) return rc;
     if (!dout) {
         SV_HIP(h, hipMemcpy(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost));

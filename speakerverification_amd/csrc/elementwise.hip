@@ -475,6 +475,26 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
     return hipGetLastError();
 }
 
+// fp32 -> (hi bf16 << 16) | lo bf16 words: the weight-side operand format of gemm_pw's split (F32X3) path
+__global__ __launch_bounds__(256) void split_words_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = src[i];
+        const bf16_t h = static_cast<bf16_t>(v);
+        const bf16_t l = static_cast<bf16_t>(v - static_cast<float>(h));
+        uint16_t hb, lb;
+        __builtin_memcpy(&hb, &h, 2);
+        __builtin_memcpy(&lb, &l, 2);
+        dst[i] = ((uint32_t)hb << 16) | lb;
+    }
+}
+
+hipError_t launch_split_words(const float* src, void* dst, int64_t n, hipStream_t stream) {
+    if (!src || !dst || n <= 0) return hipErrorInvalidValue;
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(split_words_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, src, reinterpret_cast<uint32_t*>(dst), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_crop_pcm16(const int16_t* pcm, const int64_t* off, const int32_t* len, int n_files, int num_eval, int L,
                              float* out, hipStream_t stream) {
     if (n_files <= 0 || num_eval <= 0 || L <= 0) return hipErrorInvalidValue;

@@ -162,6 +162,8 @@ hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x
 // reduce the pw2 column-sum partials: out (B, C) = mean over T  [and out (B, 2C) = [mean | std] with sq]
 hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
                                   float* out, float eps, hipStream_t stream);
+// fp32 matrix -> (hi bf16 << 16 | lo bf16) words (the pre-split weight operand of gemm_pw's F32X3 path)
+hipError_t launch_split_words(const float* src, void* dst, int64_t n, hipStream_t stream);
 // eval-mode crops of int16 PCM files (back to back in `pcm`) -> (n_files * num_eval, L) fp32, 1/32768 scaling
 hipError_t launch_crop_pcm16(const int16_t* pcm, const int64_t* off, const int32_t* len, int n_files, int num_eval, int L,
                              float* out, hipStream_t stream);
