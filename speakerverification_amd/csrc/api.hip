@@ -89,6 +89,7 @@ struct svhip_handle {
         float* afms_fcT = nullptr;              // fc weight transposed [cin][cout] (the gate kernel reads consecutive outputs per wave)
     };
     RnBlock rn_blocks[8];
+    bool layer_labels = getenv("SVHIP_LAYER_LABELS") != nullptr;
     float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
     void* rn_filt = nullptr;
     float *rn_agg_scale = nullptr, *rn_agg_shift = nullptr;
@@ -741,6 +742,11 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
     const char* klabel = (L.taps > 1 && !gemm_pw2_supported(p, bf)) ? (A2 ? "gemm_conv_add" : "gemm_conv")
                                     : (gemm_pw2_supported(p, bf) ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2") : (gemm_pw_supported(p, bf) ? "gemm_pw" : "gemm_generic"));
+    char shaped[96];
+    if (h->layer_labels) {                // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
+        snprintf(shaped, sizeof(shaped), "%s M%d N%d K%d", klabel, M, L.N, L.K);
+        klabel = shaped;
+    }
     return run(h, klabel, (double)M * L.flops_per_row, [&]() { return launch_gemm(p, bf, st); });
 }
 

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
     // ---- DMA geometry: wave w fills 8-row groups g = w + 8j (j < 4: A rows, j >= 4: W rows) ----
     const char* src[LOADS_PER_STAGE];
     int dst[LOADS_PER_STAGE];
-    int cutt[4] = {0, 0, 0, 0}, ct[4] = {0, 0, 0, 0}, clc[4] = {0, 0, 0, 0};     // CONV: utterance base row, frame, logical chunk
+    int ct[4] = {0, 0, 0, 0}, clc[4] = {0, 0, 0, 0};     // CONV: frame within its utterance, logical chunk
 #pragma unroll
     for (int j = 0; j < LOADS_PER_STAGE; ++j) {
         const int g = wave + 8 * j;                                    // 8-row group: 0..31 A, 32.. W
@@ -155,15 +155,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
         const int lc = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk this lane fetches
         if (isA) {
             const int m = min(m0 + r, p.M - 1);
-            src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + lc * EPC) * sizeof(T);
+            // (CONV: the row start only — the chunk is part of the per-K-step offset)
+            src[j] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + (CONV ? 0 : lc * EPC)) * sizeof(T);
             dst[j] = g * 1024;
-            if (CONV) { const int b = m / p.T; cutt[j] = b * p.T; ct[j] = m - b * p.T; clc[j] = lc; }
+            if (CONV) { ct[j] = m - (m / p.T) * p.T; clc[j] = lc; }
         } else {
             const int n = min(n0 + r, p.Wrows - 1);
             src[j] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + lc * EPC) * sizeof(T);
             dst[j] = A_TILE + (g - 32) * 1024;
         }
     }
+    // CONV address: a 32-bit offset from the lane's own row, computed branch-free (a select with a 64-bit multiply or a division
+    // in one arm compiles to exec-mask branches between the MFMA groups; see gemm_pw2.hip)
+    const float rcin = CONV ? 1.0f / (float)p.cin : 0.0f;
+    const bool reflect = p.pad_mode == PAD_REFLECT;
+    const int ldab = p.lda * (int)sizeof(T), half = p.taps >> 1;
     auto issue = [&](int stage, int kt) {
         char* base = smem + stage * STAGE;
 #pragma unroll
@@ -171,13 +177,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
             const char* s = src[j] + (int64_t)kt * ROWB;
             if (CONV && j < 4) {
                 const int k = kt * BK + clc[j] * EPC;
-                const int tap = k / p.cin;
-                int tt = ct[j] + (tap - (p.taps >> 1)) * p.dil;
-                bool ok = k < p.K;
-                if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
-                else ok = ok && tt >= 0 && tt < p.T;
-                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cutt[j] + tt) * p.lda + (k - tap * p.cin)) * sizeof(T)
-                       : reinterpret_cast<const char*>(p.zero_page);
+                const int tap = (int)(((float)k + 0.5f) * rcin);            // k / cin, exact for k < 2^16, cin <= 2^10 (checked on the host)
+                const int t0 = ct[j];
+                const int tt = t0 + (tap - half) * p.dil;
+                const bool inside = (unsigned)tt < (unsigned)p.T;
+                const int tr = reflect_idx(tt, p.T);                         // == tt when inside
+                const bool ok = (k < p.K) & (inside | reflect);
+                int offs = (tr - t0) * ldab + (k - tap * p.cin) * (int)sizeof(T);
+                asm volatile("" : "+v"(offs));
+                uint64_t q = reinterpret_cast<uint64_t>(src[j]) + (int64_t)offs;
+                asm volatile("" : "+v"(q));
+                s = reinterpret_cast<const char*>(ok ? q : reinterpret_cast<uint64_t>(p.zero_page));
             }
             __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dst[j]), 16, 0, 0);
         }
@@ -406,6 +416,7 @@ bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; padded k / frames read the zero page
         if (!p.zero_page || p.cin % epc != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;
         if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return false;
+        if (p.Kp >= 65536 || p.cin > 1024) return false;       // the kernel's k / cin is a float multiply
     } else if (p.K != p.Kp) {
         return false;                                        // every K chunk of every row must be real data
     }

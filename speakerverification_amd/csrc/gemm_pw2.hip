@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     // for what phase g+1 reads; the two wave groups run one phase apart.
     const char* src[4][2];
     int dsto[2];
-    int cbase[2][2] = {{0, 0}, {0, 0}}, cfrm[2][2] = {{0, 0}, {0, 0}}, cchk[2] = {0, 0};   // CONV: utterance base row, frame, chunk of the X rows
+    int cfrm[2][2] = {{0, 0}, {0, 0}}, cchk[2] = {0, 0};   // CONV: frame (within its utterance) and chunk of the X rows
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
@@ -156,8 +156,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         for (int ty = 0; ty < 4; ++ty) {
             if (ty < 2) {
                 const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
-                src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + c * 8) * 2;
-                if (CONV) { const int b = m / p.T; cbase[ty][jj] = b * p.T; cfrm[ty][jj] = m - b * p.T; }
+                // (CONV: the row start only — the chunk is part of the per-K-tile offset)
+                src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + (CONV ? 0 : c * 8)) * 2;
+                if (CONV) cfrm[ty][jj] = m - (m / p.T) * p.T;
             } else {
                 const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
                 src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
@@ -166,7 +167,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
     // CONV: the X half-tiles are the im2col view of a dilated 1-D convolution — chunk c of K tile kt is k = kt*64 + 8c ..:
     // tap k / cin of frame t + (tap - taps/2) * dil (reflect or zero padded, chunks past K read the zero page)
+    // The address is a 32-bit offset from the lane's own row (a few frames either way), branch-free: a select between two cheap
+    // values compiles to v_cndmask, one with a 64-bit multiply in an arm compiles to exec-mask branches between the MFMA phases.
     const float rcin = CONV ? 1.0f / (float)p.cin : 0.0f;
+    const bool reflect = p.pad_mode == PAD_REFLECT;
+    const int lda2 = p.lda * 2, half = p.taps >> 1;
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
 #pragma unroll
@@ -175,12 +180,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             if (CONV && ty < 2) {
                 const int k = kt * 64 + cchk[jj] * 8;
                 const int tap = (int)(((float)k + 0.5f) * rcin);          // k / cin (exact: k < 2^16, cin <= 2^10), 3 VALU ops instead of a division
-                int tt = cfrm[ty][jj] + (tap - (p.taps >> 1)) * p.dil;
-                bool ok = k < p.K;
-                if (p.pad_mode == PAD_REFLECT) tt = reflect_idx(tt, p.T);
-                else ok = ok && tt >= 0 && tt < p.T;
-                s = ok ? reinterpret_cast<const char*>(p.A) + ((int64_t)(cbase[ty][jj] + tt) * p.lda + (k - tap * p.cin)) * 2
-                       : reinterpret_cast<const char*>(p.zero_page);
+                const int t0 = cfrm[ty][jj];
+                const int tt = t0 + (tap - half) * p.dil;
+                const bool inside = (unsigned)tt < (unsigned)p.T;
+                const int tr = reflect_idx(tt, p.T);                       // == tt when inside
+                const bool ok = (k < p.K) & (inside | reflect);
+                int offs = (tr - t0) * lda2 + (k - tap * p.cin) * 2;
+                asm volatile("" : "+v"(offs));                              // keep the arithmetic out of an `ok` branch
+                uint64_t q = reinterpret_cast<uint64_t>(src[ty][jj]) + (int64_t)offs;
+                asm volatile("" : "+v"(q));
+                s = reinterpret_cast<const char*>(ok ? q : reinterpret_cast<uint64_t>(p.zero_page));
             }
             __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
         }
@@ -411,6 +420,7 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
     if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; needs the zero page for padded k / frames
         if (!p.zero_page || p.cin % 8 != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;
         if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return false;
+        if (p.Kp >= 65536 || p.cin > 1024) return false;       // the kernel's k / cin is a float multiply
         return true;
     }
     return p.K == p.Kp;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #include "kernels.h"
@@ -32,7 +33,7 @@ __global__ void checksum_bf16(const uint16_t* y, size_t n, double* out) {
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; };
+struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; int T = 0; int pad = PAD_REFLECT; };
 
 int main(int argc, char** argv) {
     const bool bf16 = !(argc > 1 && atoi(argv[1]) == 0);
@@ -52,6 +53,19 @@ int main(int argc, char** argv) {
         {"res2  N128  K384 conv3d2 relu +A2", M, 128, 384, 3, 2, 128, ACT_RELU, ACT_NONE, true, false},
         {"tdnn  N1024 K1024 none", M, C, C, 1, 1, 0, ACT_NONE, ACT_NONE, false, false},
     };
+    if (argc > 6 && !strcmp(argv[6], "rn")) {          // RawNet2 blocks 2 - 7 at B utterances of 32 000 samples (k = 3 convs, zero padding)
+        const int T2 = 1175, T3 = 391, T5 = 130, T6 = 43;
+        shapes = {
+            {"rn b2 conv1 N256 K384 c3 bn-lrelu", B * T2, 256, 384, 3, 1, 128, ACT_NONE, ACT_LRELU03, false, false, T2, PAD_ZERO},
+            {"rn b2 conv2 N256 K768 c3", B * T2, 256, 768, 3, 1, 256, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO},
+            {"rn b2 plain N256 K768", B * T2, 256, 768, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO},
+            {"rn b3 conv  N256 K768 c3 bn-lrelu", B * T3, 256, 768, 3, 1, 256, ACT_NONE, ACT_LRELU03, false, false, T3, PAD_ZERO},
+            {"rn b3 plain N256 K768", B * T3, 256, 768, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T3, PAD_ZERO},
+            {"rn b5 conv2 N512 K1536 c3", B * T5, 512, 1536, 3, 1, 512, ACT_NONE, ACT_NONE, false, false, T5, PAD_ZERO},
+            {"rn b6 conv  N512 K1536 c3 bn-lrelu", B * T6, 512, 1536, 3, 1, 512, ACT_NONE, ACT_LRELU03, false, false, T6, PAD_ZERO},
+            {"rn b6 plain N512 K1536", B * T6, 512, 1536, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T6, PAD_ZERO},
+        };
+    }
     size_t maxA = (size_t)M * 3 * C, maxW = (size_t)3 * C * 3 * C + 128 * 3 * C, maxY = (size_t)M * 3 * C;
     void *A, *A2, *W, *Y; float *bias, *scale, *shift;
     CK(hipMalloc(&A, maxA * esz)); CK(hipMalloc(&A2, maxA * esz)); CK(hipMalloc(&W, maxW * esz)); CK(hipMalloc(&Y, maxY * 4));
@@ -68,8 +82,8 @@ int main(int argc, char** argv) {
         GemmParams p;
         p.A = A; p.A2 = s.a2 ? A2 : nullptr; p.W = W; p.Y = Y; p.bias = bias; p.scale = scale; p.shift = shift;
         p.M = s.M; p.N = s.N; p.K = s.K; p.Kp = round_up(s.K, gemm_bk(bf16)); p.Wrows = round_up(s.N, 128);
-        p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = T;
-        p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = PAD_REFLECT; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = 0; p.zero_page = zp;
+        p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = s.T ? s.T : T;
+        p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = s.pad; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = 0; p.zero_page = zp;
         for (int rd = 0; rd < rounds; ++rd)
         for (int debug : debugs) {
             p.debug = debug;
