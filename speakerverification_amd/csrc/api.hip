@@ -740,8 +740,10 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
         else p.colsum = nullptr;
     }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
-    const char* klabel = (L.taps > 1 && !gemm_pw2_supported(p, bf)) ? (A2 ? "gemm_conv_add" : "gemm_conv")
-                                    : (gemm_pw2_supported(p, bf) ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2") : (gemm_pw_supported(p, bf) ? "gemm_pw" : "gemm_generic"));
+    p.num_cu = h->num_cu;
+    const GemmRoute route = gemm_route(p, bf);
+    const char* klabel = route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
+                         : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
     if (h->layer_labels) {                // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
         snprintf(shaped, sizeof(shaped), "%s M%d N%d K%d", klabel, M, L.N, L.K);

@@ -326,6 +326,22 @@ hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+GemmRoute gemm_route(const GemmParams& p, bool bf16) {
+#ifdef SVHIP_GEMM_DEBUG
+    const bool skip_pw2 = (p.debug & 8) != 0;               // tools/gemm_bench: A/B the 256 x 256 kernel against gemm_pw
+    const bool no_narrow = (p.debug & 64) != 0;
+#else
+    const bool skip_pw2 = false, no_narrow = false;
+#endif
+    const bool pw = gemm_pw_supported(p, bf16);
+    if (!skip_pw2 && gemm_pw2_supported(p, bf16)) {
+        const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu) return ROUTE_PW_NARROW;
+        return ROUTE_PW2;
+    }
+    return pw ? ROUTE_PW : ROUTE_GENERIC;
+}
+
 hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
     // host-side shape contract (checked before any launch: a bad shape must not reach the GPU)
     const int epc = bf16 ? 8 : 4;
@@ -339,8 +355,12 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         return hipErrorInvalidValue;
     }
     if (p.bias_utt && (p.T <= 0)) return hipErrorInvalidValue;
-    if (p.taps > 1 && gemm_pw2_supported(p, bf16)) return launch_gemm_pw2(p, stream);       // conv-gather on the LDS-DMA kernels
-    if (gemm_pw_supported(p, bf16)) return launch_gemm_pw(p, bf16, stream);
+    switch (gemm_route(p, bf16)) {
+        case ROUTE_PW2: return launch_gemm_pw2(p, stream);
+        case ROUTE_PW: return launch_gemm_pw(p, bf16, stream);
+        case ROUTE_PW_NARROW: return launch_gemm_pw(p, bf16, stream, true);
+        default: break;
+    }
     return bf16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }
 

@@ -437,13 +437,12 @@ bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     return true;
 }
 
-hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream) {
+hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow) {
     if (!gemm_pw_supported(p, bf16) || p.M <= 0 || p.N <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     if (bf16) {
-        if (gemm_pw2_supported(p, bf16) && !(DBG && (p.debug & 8))) return launch_gemm_pw2(p, stream);
         if (p.out_f32) return launch_epi<bf16_t, true, 128>(p, stream);
         // 256-wide N tiles halve the LDS-DMA bytes per FLOP; the output tile (256 x 256 bf16) still fits the LDS
-        if (p.N >= 256 && !(DBG && (p.debug & 32))) return launch_epi<bf16_t, false, 256>(p, stream);
+        if (p.N >= 256 && !narrow && !(DBG && (p.debug & 32))) return launch_epi<bf16_t, false, 256>(p, stream);
         return launch_epi<bf16_t, false, 128>(p, stream);
     }
     return launch_epi<float, true, 128>(p, stream);

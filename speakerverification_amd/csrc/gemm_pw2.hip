@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
     const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};  // tools/gemm_bench (debug bit 16384): s_memtime at the stage boundaries
-#define PW2_STAMP(i) if (DBG2 && (p.debug & 16384) && p.R) ts[i] = __builtin_readcyclecounter();
+#define PW2_STAMP(i) if (DBG2 && (p.debug & 16384) && p.ts) ts[i] = __builtin_readcyclecounter();
     PW2_STAMP(0)
 
     // accumulators acc16[i][j][e] = channel n0 + wn*64 + j*16 + 4*q4 + e of frame m0 + wm*128 + i*16 + r16; they start at the bias
@@ -373,21 +373,56 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
     PW2_STAMP(4)
     char* Yb = reinterpret_cast<char*>(p.Y);
+    if (p.R) {
+        // residual (RawNet2 conv2 + shortcut): added on the way out, where a lane holds 16 contiguous bytes of a row — the
+        // accumulator layout (4 channels of one frame per lane) would read it in scattered 8-byte pieces.  The sum is formed
+        // in fp32 from the bf16-rounded tile and rounded once more (<= 1 bf16 ulp against a single rounding).
+        const char* Rb = reinterpret_cast<const char*>(p.R);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {               // 256 rows x 32 16-byte chunks / 512 threads
-        const int idx = it * 512 + tid;
-        const int row = idx >> 5, q = idx & 31;
-        const int rr = row & 15;
-        const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
-        const u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
-        const int m = m0 + row, n = n0 + q * 8;
-        if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
+        for (int half = 0; half < 2; ++half) {      // two batches of 8 residual loads in flight per lane
+            u32x4 rv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = (half * 8 + it) * 512 + tid;
+                const int m = min(m0 + (idx >> 5), p.M - 1), n = min(n0 + (idx & 31) * 8, p.N - 8);
+                rv[it] = *reinterpret_cast<const u32x4*>(Rb + ((int64_t)m * p.ldr + n) * 2);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = (half * 8 + it) * 512 + tid;
+                const int row = idx >> 5, q = idx & 31;
+                const int rr = row & 15;
+                const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
+                u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(d[e] << 16) + __uint_as_float(rv[it][e] << 16);
+                    const float hi = __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rv[it][e] & 0xffff0000u);
+                    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+                    const bf16x2 pk = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
+                    d[e] = __builtin_bit_cast(uint32_t, pk);
+                }
+                const int m = m0 + row, n = n0 + q * 8;
+                if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {           // 256 rows x 32 16-byte chunks / 512 threads
+            const int idx = it * 512 + tid;
+            const int row = idx >> 5, q = idx & 31;
+            const int rr = row & 15;
+            const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
+            const u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
+            const int m = m0 + row, n = n0 + q * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
+        }
     }
-    if (DBG2 && (p.debug & 16384) && p.R) {
+    if (DBG2 && (p.debug & 16384) && p.ts) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[5] = __builtin_readcyclecounter();
         if (tid == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.R)) + (int64_t)blockIdx.x * 8;
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ts) + (int64_t)blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) o[i] = ts[i];
             unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -409,7 +444,8 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
-    if (!bf16 || p.out_f32 || p.bias_utt || p.A2 || (p.R && !(DBG2 && (p.debug & 16384)))) return false;
+    if (!bf16 || p.out_f32 || p.bias_utt || p.A2) return false;
+    if (p.R && (p.colsum || p.ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(p.R) & 15))) return false;      // (the column sums are taken before the residual)
     if (p.act2 != ACT_NONE && !(p.act2 == ACT_LRELU03 && p.act1 == ACT_NONE)) return false;
     if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;      // at most one utterance boundary per 256-row tile
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;

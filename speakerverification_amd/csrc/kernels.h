@@ -66,8 +66,10 @@ struct GemmParams {
     int colsum_sq = 0;
     int64_t colsum_stride = 0;
     const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
-    const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last (generic kernel only)
+    const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last
     int ldr = 0;
+    int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
+    void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
     int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
     int T = 1;
@@ -89,8 +91,15 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
 // pointwise fast path (gemm_pw.hip): 256 x 128 tiles, LDS-DMA ring; launch_gemm routes to it when supported
+// Which kernel launch_gemm runs for a shape (the profile labels of api.hip name the same choice):
+//   PW2        256 x 256 role-staggered bf16 kernel (gemm_pw2.hip)
+//   PW_NARROW  gemm_pw's 256 x 128 tile: a pw2 grid of at most half the CUs finishes in one round either way, and the half-size
+//              tile takes about half as long (RawNet2 blocks 6 / 7, 86 tiles: 370 -> 470 - 510 TFLOP/s)
+//   PW         gemm_pw with its default tile;  GENERIC  the register-staged kernel of gemm.hip
+enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3 };
+GemmRoute gemm_route(const GemmParams& p, bool bf16);
 bool gemm_pw_supported(const GemmParams& p, bool bf16);
-hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream);
+hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow = false);
 // bf16 256 x 256 role-staggered variant for the big layers (gemm_pw2.hip); launch_gemm_pw routes to it
 bool gemm_pw2_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);

@@ -33,7 +33,7 @@ __global__ void checksum_bf16(const uint16_t* y, size_t n, double* out) {
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; int T = 0; int pad = PAD_REFLECT; };
+struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; int T = 0; int pad = PAD_REFLECT; bool resid = false; };
 
 int main(int argc, char** argv) {
     const bool bf16 = !(argc > 1 && atoi(argv[1]) == 0);
@@ -59,10 +59,15 @@ int main(int argc, char** argv) {
             {"rn b2 conv1 N256 K384 c3 bn-lrelu", B * T2, 256, 384, 3, 1, 128, ACT_NONE, ACT_LRELU03, false, false, T2, PAD_ZERO},
             {"rn b2 conv2 N256 K768 c3", B * T2, 256, 768, 3, 1, 256, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO},
             {"rn b2 plain N256 K768", B * T2, 256, 768, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO},
+            {"rn b2 conv2 +R N256 K768 c3", B * T2, 256, 768, 3, 1, 256, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO, true},
+            {"rn b2 plain +R N256 K768", B * T2, 256, 768, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T2, PAD_ZERO, true},
             {"rn b3 conv  N256 K768 c3 bn-lrelu", B * T3, 256, 768, 3, 1, 256, ACT_NONE, ACT_LRELU03, false, false, T3, PAD_ZERO},
             {"rn b3 plain N256 K768", B * T3, 256, 768, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T3, PAD_ZERO},
             {"rn b5 conv2 N512 K1536 c3", B * T5, 512, 1536, 3, 1, 512, ACT_NONE, ACT_NONE, false, false, T5, PAD_ZERO},
             {"rn b6 conv  N512 K1536 c3 bn-lrelu", B * T6, 512, 1536, 3, 1, 512, ACT_NONE, ACT_LRELU03, false, false, T6, PAD_ZERO},
+            {"rn b5 conv2 +R N512 K1536 c3", B * T5, 512, 1536, 3, 1, 512, ACT_NONE, ACT_NONE, false, false, T5, PAD_ZERO, true},
+            {"rn b6 conv2 +R N512 K1536 c3", B * T6, 512, 1536, 3, 1, 512, ACT_NONE, ACT_NONE, false, false, T6, PAD_ZERO, true},
+            {"rn b6 plain +R N512 K1536", B * T6, 512, 1536, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T6, PAD_ZERO, true},
             {"rn b6 plain N512 K1536", B * T6, 512, 1536, 1, 1, 0, ACT_NONE, ACT_NONE, false, false, T6, PAD_ZERO},
         };
     }
@@ -84,6 +89,7 @@ int main(int argc, char** argv) {
         p.M = s.M; p.N = s.N; p.K = s.K; p.Kp = round_up(s.K, gemm_bk(bf16)); p.Wrows = round_up(s.N, 128);
         p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = s.T ? s.T : T;
         p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = s.pad; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = 0; p.zero_page = zp;
+        if (s.resid) { p.R = A2; p.ldr = s.N; }
         for (int rd = 0; rd < rounds; ++rd)
         for (int debug : debugs) {
             p.debug = debug;
@@ -108,11 +114,11 @@ int main(int argc, char** argv) {
             if (debug & 16384) {          // stage timestamps of one launch (non-persistent pw2 kernel)
                 const int nwg = ((s.M + 255) / 256) * ((s.N + 255) / 256);
                 unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 64)); CK(hipMemset(dts, 0, (size_t)nwg * 64));
-                p.R = dts;
+                p.ts = dts;
                 CK(launch_gemm(p, bf16, st)); CK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hts((size_t)nwg * 8);
                 CK(hipMemcpy(hts.data(), dts, (size_t)nwg * 64, hipMemcpyDeviceToHost));
-                p.R = nullptr; CK(hipFree(dts));
+                p.ts = nullptr; CK(hipFree(dts));
                 unsigned long long t0 = ~0ull, t1 = 0;      // s_memtime is per XCD: calibrate on the XCD of workgroup 0
                 const unsigned xcc0 = (unsigned)hts[7] & 15;
                 double sum[5] = {0, 0, 0, 0, 0};
