@@ -921,6 +921,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     // block i is applied by block i + 1 on the way in (or by the rn_afms_apply pass in front of the first GEMM block)
     int first = 0;
     const bool fuse_ok = bf && stop_after < 0 && !getenv("SVHIP_RN_UNFUSED");
+    const bool no_tail = getenv("SVHIP_RN_UNFUSED") != nullptr;        // (tests: the separate passes against the fused tail)
     const float *g_alpha = nullptr, *g_gate = nullptr;          // pending gate of the previous fused block
     const void* xin = x;
     for (; fuse_ok && first < 8; ++first) {
@@ -970,22 +971,33 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
         if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
         if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, K.cout))) return rc;
-        void* y = o;
-        if (K.downsample) {                                                          // :228-229
-            if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, bf, B, T, K.cout, st); }))) return rc;
-            T /= 3;
-            y = hb;
-        }
-        // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
-        if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, rn_mean, st, rn_scratch, 16); }))) return rc;
-        if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
-                 return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
-             }))) return rc;
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
         void* npre = stop_after >= 0 ? nullptr : pre;           // (the developer hook keeps the unfused sequence)
-        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+        const int Tn = K.downsample ? T / 3 : T;
+        if (!no_tail && rn_tail_supported(bf, Tn, K.cout)) {
+            // max-pool + AFMS + next pre-activation in one launch, the pooled activation held in registers      :228-229, :62-68
+            char tl[48] = "rn_tail";
+            if (h->layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
+            if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
+                     return launch_rn_tail(o, xn, npre, bf, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
+                 }))) return rc;
+            T = Tn;
+        } else {
+            void* y = o;
+            if (K.downsample) {                                                          // :228-229
+                if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, bf, B, T, K.cout, st); }))) return rc;
+                T /= 3;
+                y = hb;
+            }
+            // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
+            if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, rn_mean, st, rn_scratch, 16); }))) return rc;
+            if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
+                     return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
+                 }))) return rc;
+            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+        }
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
     }

@@ -216,6 +216,11 @@ hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin,
 hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
                                 hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
                                 void* pre = nullptr, float slope = 0.3f);
+// fused block tail (rawnet2.hip): [max_pool1d(3)] + AFMS + the next consumer's lrelu(bn(.)), one workgroup per utterance with the
+// pooled activation held in registers; rn_tail_supported says whether (Tn, C) fits (else the four separate passes run)
+bool rn_tail_supported(bool bf16, int Tn, int C);
+hipError_t launch_rn_tail(const void* x, void* y, void* pre, bool bf16, bool pool, const float* alpha, const float* WT, const float* bias,
+                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream);
 // Fused 128 -> 128 pooled RawNetBasicBlock (rn_block128.hip, bf16): previous block's AFMS gate on the way in, BN + LeakyReLU,
 // conv1 + BN + LeakyReLU, conv2 + identity shortcut, max_pool1d(3), per-tile column sums of the pooled output.
 struct RnBlock128Params {

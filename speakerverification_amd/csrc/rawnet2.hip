@@ -293,6 +293,109 @@ __global__ __launch_bounds__(256) void rn_attn_pool_kernel(const float* __restri
     out[(int64_t)b * 2 * C + C + c] = sqrtf(fmaxf(q - m * m, 1e-5f));
 }
 
+
+// ---- fused block tail: [max_pool1d(3)] -> AFMS (column mean, fc, sigmoid, (y + alpha) * gate) -> next block's lrelu(bn(.)) ----
+// RawNet_baseline.py:62-68,228-229.  One workgroup per utterance: the pooled activation stays in registers (at most TAIL_NCH
+// 16-byte chunks per thread) between the column-mean pass and the gated write, so the block output is read from HBM once
+// and the four separate passes (rn_maxpool3, rn_afms_mean, rn_afms_gate, rn_afms_apply) become one launch.
+// Measured and not kept: two utterances per workgroup sharing one read of the fc weight (C = 512: 1 MiB per workgroup, the
+// matrix-vector product is ~25 of the ~45 us of the late blocks) — 54 us instead of 47, half as many workgroups each twice as
+// long; a per-workgroup rotation of the row order (-10 us: the 256 workgroups read the same lines at the same time) would make
+// an utterance's gate depend on its position in the batch.
+constexpr int TAIL_THREADS = 1024, TAIL_NCH = 16;
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ pre,
+                                                               const float* __restrict__ alpha, const float* __restrict__ WT,
+                                                               const float* __restrict__ bias, const float* __restrict__ nscale,
+                                                               const float* __restrict__ nshift, int Tin, int Tn, int C, float slope) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float part[8192];                     // 32 KiB: column-sum partials, then the gate's partial dot products
+    __shared__ float mean[512], gate[512];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int cpr = C / VEC, rstep = TAIL_THREADS / cpr;
+    const int cc = tid % cpr, r0 = tid / cpr, c = cc * VEC;
+    const T* xb = x + b * Tin * (int64_t)C + c;
+    Vec16<T> held[TAIL_NCH];
+    float sum[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TAIL_NCH; ++i) {
+        const int t = r0 + i * rstep;
+        if (t < Tn) {
+            if (POOL) {
+                const T* q = xb + (int64_t)(3 * t) * C;
+                const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(q), bb = *reinterpret_cast<const Vec16<T>*>(q + C),
+                               d = *reinterpret_cast<const Vec16<T>*>(q + 2 * C);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), d.get(j)));
+            } else {
+                held[i] = *reinterpret_cast<const Vec16<T>*>(xb + (int64_t)t * C);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sum[j] += held[i].get(j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[r0 * C + c + j] = sum[j];
+    __syncthreads();
+    if (tid < C) {
+        float m = 0.0f;
+        for (int r = 0; r < rstep; ++r) m += part[r * C + tid];
+        mean[tid] = m / (float)Tn;
+    }
+    __syncthreads();
+    // gate[n] = sigmoid(bias[n] + sum_c WT[c][n] * mean[c]): thread = (4 channels n, one slice of c); WT is the fc weight transposed
+    {
+        const int n4 = C / 4, slices = TAIL_THREADS / n4, per = C / slices;
+        const int nq = tid % n4, sl = tid / n4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* w = WT + (int64_t)(sl * per) * C + nq * 4;
+#pragma unroll 8
+        for (int k = 0; k < per; ++k) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)k * C);
+            const float mv = mean[sl * per + k];
+            acc[0] = fmaf(wv[0], mv, acc[0]); acc[1] = fmaf(wv[1], mv, acc[1]); acc[2] = fmaf(wv[2], mv, acc[2]); acc[3] = fmaf(wv[3], mv, acc[3]);
+        }
+        *reinterpret_cast<f32x4*>(&part[sl * C + nq * 4]) = acc;
+        __syncthreads();
+        if (tid < C) {
+            float a = bias[tid];
+            for (int q = 0; q < slices; ++q) a += part[q * C + tid];
+            gate[tid] = 1.0f / (1.0f + expf(-a));
+        }
+        __syncthreads();
+    }
+    float al[VEC], g[VEC], ns[VEC], nh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        al[j] = alpha[c + j]; g[j] = gate[c + j];
+        ns[j] = pre ? nscale[c + j] : 0.0f; nh[j] = pre ? nshift[c + j] : 0.0f;
+    }
+    T* yb = y + b * Tn * (int64_t)C + c;
+    T* pb = pre ? pre + b * Tn * (int64_t)C + c : nullptr;
+#pragma unroll
+    for (int i = 0; i < TAIL_NCH; ++i) {
+        const int t = r0 + i * rstep;
+        if (t < Tn) {
+            Vec16<T> o, q;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.set(j, (held[i].get(j) + al[j]) * g[j]);
+            *reinterpret_cast<Vec16<T>*>(yb + (int64_t)t * C) = o;
+            if (pb) {                                  // from the value as stored (rounded to T), like rn_afms_apply
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float v = fmaf(o.get(j), ns[j], nh[j]);
+                    q.set(j, v > 0.0f ? v : slope * v);
+                }
+                *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+            }
+        }
+    }
+}
+
 inline int grid_for(int64_t items) {
     int64_t g = (items + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -348,6 +451,28 @@ hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* 
     const int64_t chunks = (int64_t)B * T * (C / vec);
     if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (bf16_t*)pre, slope);
     else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks, next_scale, next_shift, (float*)pre, slope);
+    return hipGetLastError();
+}
+
+bool rn_tail_supported(bool bf16, int Tn, int C) {
+    const int vec = bf16 ? 8 : 4;
+    if (C % vec || C % 4 || C > 512 || Tn <= 0) return false;
+    const int cpr = C / vec, n4 = C / 4;
+    if (TAIL_THREADS % cpr || TAIL_THREADS % n4 || n4 > TAIL_THREADS || C % (TAIL_THREADS / n4)) return false;
+    if ((TAIL_THREADS / cpr) * C > 8192 || (TAIL_THREADS / n4) * C > 8192) return false;      // LDS partials
+    return (int64_t)Tn * cpr <= (int64_t)TAIL_NCH * TAIL_THREADS;                                // the utterance fits the registers
+}
+
+hipError_t launch_rn_tail(const void* x, void* y, void* pre, bool bf16, bool pool, const float* alpha, const float* WT, const float* bias,
+                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream) {
+    const int Tn = pool ? Tin / 3 : Tin;
+    if (!x || !y || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(bf16, Tn, C) || (pre && (!next_scale || !next_shift)))
+        return hipErrorInvalidValue;
+#define SV_TAIL(TT, P) hipLaunchKernelGGL((rn_tail_kernel<TT, P>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
+                                          alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope)
+    if (bf16) { if (pool) SV_TAIL(bf16_t, true); else SV_TAIL(bf16_t, false); }
+    else { if (pool) SV_TAIL(float, true); else SV_TAIL(float, false); }
+#undef SV_TAIL
     return hipGetLastError();
 }
 
