@@ -12,7 +12,13 @@
 //     the weights as the A operand, so a lane owns 4 consecutive output channels of one frame and
 //     the epilogue (bias, ReLU, BatchNorm affine) writes packed bf16x4 straight back into U;
 //   * a cooperative pass then streams y_j to HBM as whole rows and adds the next chunk c_{j+1}
-//     in place (fp32 add, one bf16 rounding — same as the unfused path).
+//     in place (fp32 add, one bf16 rounding — same as the unfused path); the c_{j+1} rows are requested
+//     before the last tap's MFMAs.
+// Where the time goes (tools/res2_bench ablations, C = 1024, 150 us per launch): global traffic of the row passes 35 - 45 us,
+// MFMAs 30 (28 at peak), epilogue 20, weight staging 12, barriers / loop skeleton 24.  All 256 workgroups reach their row
+// passes together, so HBM sees 7 bursts of 60 MB per launch; measured and of no effect on the total: software-pipelined
+// fragment reads, the c_{j+1} prefetch above, y_j stores delayed behind the next stage's weight loads (C = 512: 64 us either
+// way).  What would help is two workgroups per CU out of phase, which the 136 KiB of LDS (C = 1024) rule out.
 #include "common.h"
 #include "kernels.h"
 
@@ -61,17 +67,21 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
     u32x4 wregs[WCH];
     auto wload = [&](int layer, int tap) {
         const char* wsrc = reinterpret_cast<const char*>(p.W[layer]);
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));               // (addresses recomputed per call: hoisted, they spill)
 #pragma unroll
         for (int e = 0; e < WCH; ++e) {
-            const int c = tid + 512 * e;
+            const int c = tid_w + 512 * e;
             const int n = c / NCH, ch = c % NCH;
             wregs[e] = *reinterpret_cast<const u32x4*>(wsrc + ((int64_t)n * p.Kp + tap * CW) * 2 + ch * 16);
         }
     };
     auto wstore = [&]() {
+        int tid_w = tid;
+        asm volatile("" : "+v"(tid_w));
 #pragma unroll
         for (int e = 0; e < WCH; ++e) {
-            const int c = tid + 512 * e;
+            const int c = tid_w + 512 * e;
             const int n = c / NCH, ch = c % NCH;
             *reinterpret_cast<u32x4*>(Wt + n * ROWB + ((ch ^ CF::swz(n)) << 4)) = wregs[e];
         }
@@ -110,35 +120,66 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
     for (int s = 1; s < 8; ++s) {
         const int layer = s - 1;
         f32x16 acc[MI];
+        float zero = 0.0f;
+        asm volatile("" : "+v"(zero));                  // the accumulators start HERE (not hoisted over the previous stage's row pass)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][r] = zero;
 
+        constexpr int RSTEP = 512 / NCH;                            // rows per trip of the whole workgroup (32 / 64)
+        constexpr int RB = 7;                                       // row chunks per thread per group
+        constexpr int NPRE = (R2_TMAX / RSTEP + RB - 1) / RB * RB;  // row chunks per thread: 14 / 7
+        const bool noglob = R2DBG && (p.debug & 1);
+
+        // every row chunk of c_{s+1} is requested before the last tap's MFMAs and consumed in the row pass below
+        u32x4 cpre[NPRE];
         for (int tap = 0; tap < 3; ++tap) {
+            if (tap == 2 && s < 7 && !noglob) {
+                int tid_p = tid;
+                asm volatile("" : "+v"(tid_p));
+                const int row0 = tid_p / NCH, ch0 = tid_p % NCH;
+                const char* h1s = reinterpret_cast<const char*>(H1) + (s + 1) * CW * 2;
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k) {
+                    const int rowc = min(row0 + k * RSTEP, T - 1);
+                    cpre[k] = *reinterpret_cast<const u32x4*>(h1s + ((uint32_t)rowc * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u);
+                }
+            }
             const bool more = !(s == 7 && tap == 2);
             if (more && !(R2DBG && (p.debug & 4))) { if (tap < 2) wload(layer, tap + 1); else wload(layer + 1, 0); }
             const int delta = (tap - 1) * p.dil;
+            // (per-tap copies the optimiser cannot see through: hoisted out of the stage loop, the swizzled offsets of every
+            //  (K step, tile) pair cost more registers than the double-buffered fragments and spill)
+            int fh_t = fh, fr_t = fr;
+            asm volatile("" : "+v"(fh_t), "+v"(fr_t));
             int rbase[MI], rsw[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int t = (wq + CF::MW * i) * 32 + fr + delta;
+                const int t = (wq + CF::MW * i) * 32 + fr_t + delta;
                 const int row = min(reflect_idx(t, T), T - 1);
                 rbase[i] = row * ROWB;
                 rsw[i] = CF::swz(row);
             }
-            const int wrow = (wn * 32 + fr);
+            const int wrow = (wn * 32 + fr_t);
             const int wbase = wrow * ROWB, wsw = CF::swz(wrow);
+            // ONE straight-line body: all MI m-tiles (the compiler keeps the next K step's fragment reads in flight under the MFMAs).
+            // Tiles that start at or past T multiply clamped rows and are dropped by the epilogue (with T = 401 that is one tile
+            // of the wq = 1 waves, which wait at the barrier for the wq = 0 waves anyway; short utterances waste MFMAs on a kernel
+            // that is latency-bound for them).  Measured alternatives: a per-tile `if (tile < T)` around each MFMA puts every MFMA
+            // in its own basic block — fragment read, full lgkmcnt wait, one MFMA, 56 times per tap (440 TFLOP/s); a second body
+            // for short utterances beside this one makes the register allocator spill in the row pass below.
+            if (!(R2DBG && (p.debug & 2))) {
+                constexpr int NK = CW / 16;
 #pragma unroll
-            for (int kk = 0; kk < CW / 16; ++kk) {
-                const int ch = 2 * kk + fh;
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wt + wbase + ((ch ^ wsw) << 4));
+                for (int kk = 0; kk < NK; ++kk) {
+                    const int ch = 2 * kk + fh_t;
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wt + wbase + ((ch ^ wsw) << 4));
+                    bf16x8 xf[MI];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    if ((wq + CF::MW * i) * 32 < T && !(R2DBG && (p.debug & 2))) {          // wave-uniform: skip m-tiles beyond T
-                        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(U + rbase[i] + ((ch ^ rsw[i]) << 4));
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
-                    }
+                    for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(U + rbase[i] + ((ch ^ rsw[i]) << 4));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[i], acc[i], 0, 0, 0);
                 }
             }
             __syncthreads();                                    // Wt (and, after tap 2, U) are free
@@ -146,16 +187,18 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
         }
 
         // ---- epilogue: acc[i][4g+e] = (t = (wq + MW*i)*32 + fr, n = wn*32 + 8g + 4fh + e) -> U ------
+        int fh_e = fh, fr_e = fr;
+        asm volatile("" : "+v"(fh_e), "+v"(fr_e));
         if (!(R2DBG && (p.debug & 8)))
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n = wn * 32 + 8 * g + 4 * fh;
+            const int n = wn * 32 + 8 * g + 4 * fh_e;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias[layer] + n);
             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale[layer] + n);
             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(p.shift[layer] + n);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int t = (wq + CF::MW * i) * 32 + fr;
+                const int t = (wq + CF::MW * i) * 32 + fr_e;
                 if (t < T) {
                     typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                     bf16x4 o;
@@ -187,34 +230,30 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
                 }
             }
         } else {
-            constexpr int RSTEP = 512 / NCH;                        // rows per trip of the whole workgroup (32 / 64)
-            constexpr int RB = 7;                                   // row chunks per thread in flight
-            const int row0 = tid / NCH, ch0 = tid % NCH;
+            int tid_r = tid;
+            asm volatile("" : "+v"(tid_r));
+            const int row0 = tid_r / NCH, ch0 = tid_r % NCH;
             const uint32_t goff0 = ((uint32_t)row0 * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u;
             const uint32_t gstep = (uint32_t)RSTEP * (uint32_t)p.ld * 2u;
-            const char* h1s = reinterpret_cast<const char*>(H1) + (s + 1) * CW * 2;
             char* h2s = reinterpret_cast<char*>(H2) + s * CW * 2;
-            const bool noglob = R2DBG && (p.debug & 1);
-            for (int it0 = 0; it0 * RSTEP < T; it0 += RB) {
-                u32x4 cn[RB];
 #pragma unroll
-                for (int k = 0; k < RB; ++k) {
-                    const int row = row0 + (it0 + k) * RSTEP;
-                    if (s < 7 && row < T && !noglob) cn[k] = *reinterpret_cast<const u32x4*>(h1s + goff0 + (uint32_t)(it0 + k) * gstep);
-                }
+            for (int g = 0; g < NPRE / RB; ++g) {                   // every row chunk of c_{s+1} was requested before the last tap
+                const int it0 = g * RB;
+                if (it0 * RSTEP < T) {
 #pragma unroll
-                for (int k = 0; k < RB; ++k) {
-                    const int row = row0 + (it0 + k) * RSTEP;
-                    if (row < T) {
-                        char* up = U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4);
-                        const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
-                        if (!noglob) *reinterpret_cast<bf16x8*>(h2s + goff0 + (uint32_t)(it0 + k) * gstep) = y;
-                        if (s < 7 && !noglob) {
-                            const bf16x8 cv = __builtin_bit_cast(bf16x8, cn[k]);
-                            bf16x8 u;
+                    for (int k = 0; k < RB; ++k) {
+                        const int row = row0 + (it0 + k) * RSTEP;
+                        if (row < T) {
+                            char* up = U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4);
+                            const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
+                            if (!noglob) *reinterpret_cast<bf16x8*>(h2s + goff0 + (uint32_t)(it0 + k) * gstep) = y;
+                            if (s < 7 && !noglob) {
+                                const bf16x8 cv = __builtin_bit_cast(bf16x8, cpre[it0 + k]);
+                                bf16x8 u;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cv[e]));
-                            *reinterpret_cast<bf16x8*>(up) = u;
+                                for (int e = 0; e < 8; ++e) u[e] = static_cast<bf16_t>(static_cast<float>(y[e]) + static_cast<float>(cv[e]));
+                                *reinterpret_cast<bf16x8*>(up) = u;
+                            }
                         }
                     }
                 }
