@@ -110,3 +110,29 @@ def test_fused_blocks_other_geometries(L, B, monkeypatch):
     cf, cu = cos_to_f32(outs["fused"]), cos_to_f32(outs["unfused"])
     print("cos fused", cf, "unfused", cu)
     assert cf.min() >= cu.min() - 0.02 and cf.min() >= 0.9, (cf, cu)
+
+
+@pytest.mark.parametrize("L,B", [(32000, 3), (12000, 2)])
+def test_fused_tail_fp32_matches_separate_passes(L, B, monkeypatch):
+    """rn_tail_kernel (max-pool + AFMS + next pre-activation in one launch, csrc/rawnet2.hip) on the fp32 path against the four
+    separate passes it replaces (SVHIP_RN_UNFUSED keeps them): same arithmetic, only the summation order of the column mean and
+    of the gate's dot products differs."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=3)
+    wav = synth.synth_waveforms(B, L, seed=8)
+    outs = []
+    for unfused in (True, False):
+        if unfused:
+            monkeypatch.setenv("SVHIP_RN_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("SVHIP_RN_UNFUSED", raising=False)
+        eng = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        outs.append(eng.embed_wave(wav).reshape(B, -1))
+        labels = set(eng.profile_results())
+        eng.profile(False)
+        eng.close()
+        assert ("rn_tail" in labels) == (not unfused), labels
+    scale = float(np.abs(outs[0]).max())
+    assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5 * scale
