@@ -229,12 +229,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                           \
         __builtin_amdgcn_s_barrier();                                                               \
     } else {                                                                                        \
-        const int g_ = 4 * kt + (gidx);                                                             \
-        if (7 + g_ < total) {                                                                       \
-            const int need = g_ + 6, kk = need >> 2, pp = need & 3;                                 \
-            if (pp == 0) issue(0, kk); else if (pp == 1) issue(3, kk); else if (pp == 2) issue(1, kk); else issue(2, kk + 1); \
+        /* the last two K tiles: `left_` phases remain (this one included), so which half-tile is still to be issued and how */ \
+        /* many may stay in flight are compile-time constants (as a run-time ladder each phase was a chain of scalar branches) */ \
+        constexpr int left_ = 4 * rem - (gidx);                                                     \
+        if (left_ > 7) {                                                                            \
+            constexpr int pp_ = ((gidx) + 6) & 3;                                                   \
+            const int kk_ = kt + (((gidx) + 6) >> 2);                                               \
+            if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
         }                                                                                           \
-        wait_left(min(8 + g_, total) - (g_ + 3));                                                   \
+        wait_left((left_ < 8 ? left_ : 8) - 3);                                                     \
         __builtin_amdgcn_s_barrier();                                                               \
     }
 #define PW2_MFMA(I0, WARR, J0)                                                                      \
@@ -245,9 +248,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                 acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_s_barrier();
-#define PW2_KTILE(steady_, KT_, WCUR, WNXT)                                                         \
+#define PW2_KTILE(steady_, REM_, KT_, WCUR, WNXT)                                                   \
     {                                                                                               \
         constexpr bool steady = (steady_);                                                          \
+        constexpr int rem = (REM_);                /* K tiles left, this one included (tail tiles only) */ \
         const int kt = (KT_);                                                                       \
         const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
         /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         PW2_PHASE_END(2)                                                                            \
         PW2_MFMA(4, whi, 2)                                                                         \
         /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
-        if (steady || kt + 1 < nkt) {                                                               \
+        if (steady || rem > 1) {                                                                    \
             const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
@@ -280,19 +284,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
     int kt0 = 0;
     for (; kt0 + 2 < nkt; ++kt0) {                  // steady state: every issue exists, five half-tiles stay in flight
-        PW2_KTILE(true, kt0, wlo, wnx)              // (two K tiles per trip with the W-lo sets swapping roles spills: slower)
+        PW2_KTILE(true, 0, kt0, wlo, wnx)           // (two K tiles per trip with the W-lo sets swapping roles spills: slower)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
     }
-    for (; kt0 < nkt; ++kt0) {                      // last two K tiles: issues run out, counted drain
-        PW2_KTILE(false, kt0, wlo, wnx)
+    if (nkt >= 2) {                                 // last two K tiles: issues run out, counted drain
+        PW2_KTILE(false, 2, kt0, wlo, wnx)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+        ++kt0;
     }
+    PW2_KTILE(false, 1, kt0, wlo, wnx)
 #undef PW2_KTILE
 #undef PW2_PHASE_END
 #undef PW2_MFMA
