@@ -79,7 +79,7 @@ def test_rawnet2_batch_sizes(B):
     assert np.isfinite(b).all() and cos.min() >= 0.99, cos
 
 
-@pytest.mark.parametrize("L,B", [(8000, 5), (24000, 3), (40000, 2), (32000, 40)])
+@pytest.mark.parametrize("L,B", [(8000, 5), (24000, 3), (40000, 2), (32000, 40), (50000, 2)])
 def test_fused_blocks_other_geometries(L, B, monkeypatch):
     """csrc/rn_block128.hip (the fused 128-channel residual blocks) on other utterance lengths / batch sizes: tile counts that do
     not divide, several utterances per workgroup, short last tiles — against the unfused kernel sequence (same bf16 storage
