@@ -84,6 +84,7 @@ struct svhip_handle {
         bool downsample = false, has_shortcut = false;
         float *bn1_scale = nullptr, *bn1_shift = nullptr;
         ConvLayer conv1, conv2, shortcut;       // conv1 carries bn2 as its epilogue
+        void* conv2sc_W = nullptr;              // bf16 handles: [Np][conv2.K + cin] = conv2 | 1 x 1 shortcut, one GEMM for both (gemm_pw2 A3)
         float* alpha = nullptr;
         LinearLayer afms_fc;
         float* afms_fcT = nullptr;              // fc weight transposed [cin][cout] (the gate kernel reads consecutive outputs per wave)
@@ -632,6 +633,21 @@ int finalize_rawnet2(svhip_handle* h) {
             if ((rc = make_conv(h, B.conv1, p + ".conv1.weight", "", p + ".bn2", 1))) return rc;
             if ((rc = make_conv(h, B.conv2, p + ".conv2.weight", "", "", 1))) return rc;
             if (B.has_shortcut && (rc = make_conv(h, B.shortcut, p + ".shortcut.0.weight", "", "", 1))) return rc;
+            if (B.has_shortcut && h->bf16 && B.conv2.K % 64 == 0 && inpl % 64 == 0) {
+                // conv2 and the shortcut share their output: [conv2 columns (tap-major) | shortcut columns] as one K axis
+                const HostTensor* w2 = getw(h, p + ".conv2.weight");           // (planes, planes, 3)
+                const HostTensor* ws = getw(h, p + ".shortcut.0.weight");      // (planes, inpl, 1)
+                const int K2 = B.conv2.K, Kt = K2 + inpl, Np = B.conv2.Np;
+                std::vector<uint16_t> pk((size_t)Np * Kt, 0);
+                for (int n = 0; n < planes; ++n) {
+                    for (int t = 0; t < 3; ++t)
+                        for (int c = 0; c < planes; ++c) pk[(size_t)n * Kt + t * planes + c] = f32_to_bf16_rne(w2->data[((size_t)n * planes + c) * 3 + t]);
+                    for (int c = 0; c < inpl; ++c) pk[(size_t)n * Kt + K2 + c] = f32_to_bf16_rne(ws->data[(size_t)n * inpl + c]);
+                }
+                uint16_t* d;
+                if ((rc = dev_upload(h, &d, pk))) return rc;
+                B.conv2sc_W = d;
+            }
             if ((rc = upload_f32(h, p + ".afms.alpha", &B.alpha))) return rc;
             if ((rc = make_linear(h, B.afms_fc, p + ".afms.fc.weight", p + ".afms.fc.bias"))) return rc;
             {
@@ -888,6 +904,21 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     return rc;
 }
 
+// conv2 + 1 x 1 shortcut of a RawNet2 block as ONE conv-gather GEMM: K = 3 * cout conv columns of hb, then cin columns of `pre`
+static GemmParams conv2sc_params(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
+    GemmParams p;
+    p.A = hb; p.W = K.conv2sc_W; p.Y = o; p.zero_page = h->d_zero;
+    p.M = M; p.N = K.cout; p.K = K.conv2.K; p.Kp = K.conv2.K + K.cin; p.Wrows = K.conv2.Np;
+    p.lda = K.cout; p.ldy = K.cout; p.T = T; p.taps = 3; p.dil = 1; p.cin = K.cout; p.pad_mode = PAD_ZERO;
+    p.A3 = pre; p.lda3 = K.cin; p.K3 = K.cin;
+    p.num_cu = h->num_cu;
+    return p;
+}
+static bool conv2sc_fits(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
+    const GemmParams p = conv2sc_params(h, K, pre, hb, o, M, T);
+    return gemm_pw2_supported(p, true) && gemm_route(p, true) == ROUTE_PW2;
+}
+
 // RawNet2.forward (models/RawNet2_custom.py:161-227) on device-resident waveforms (B, L), utterances [b0, b0 + B) of the call,
 // enqueued on h->cur.  Every workspace buffer is per-utterance contiguous, so a batch slice is an offset into each.
 int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B) {
@@ -963,14 +994,19 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         if ((bi == 0 && first == 0) || stop_after >= 0) {
             if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
         }
+        // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
+        // A 1 x 1 shortcut rides in conv2's GEMM as extra K columns when the 256 x 256 kernel takes it (no shortcut tensor in HBM)
+        const bool fold_sc = K.has_shortcut && K.conv2sc_W && !no_tail && conv2sc_fits(h, K, pre, hb, o, M, T);
         const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
-        if (K.has_shortcut) {
+        if (K.has_shortcut && !fold_sc) {
             if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
             resid = sc;
         }
-        // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
         if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
-        if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, K.cout))) return rc;
+        if (fold_sc) {
+            GemmParams p = conv2sc_params(h, K, pre, hb, o, M, T);
+            if ((rc = run(h, "gemm_pw2_conv", (double)M * (K.conv2.flops_per_row + K.shortcut.flops_per_row), [&]() { return launch_gemm(p, true, st); }))) return rc;
+        } else if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, K.cout))) return rc;
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;

@@ -355,6 +355,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         return hipErrorInvalidValue;
     }
     if (p.bias_utt && (p.T <= 0)) return hipErrorInvalidValue;
+    if (p.A3 && gemm_route(p, bf16) != ROUTE_PW2) return hipErrorInvalidValue;       // (only the 256 x 256 kernel reads a second K segment)
     switch (gemm_route(p, bf16)) {
         case ROUTE_PW2: return launch_gemm_pw2(p, stream);
         case ROUTE_PW: return launch_gemm_pw(p, bf16, stream);

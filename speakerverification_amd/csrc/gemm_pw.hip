@@ -411,7 +411,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 bool gemm_pw_supported(const GemmParams& p, bool bf16) {
     const int epc = bf16 ? 8 : 4;
     const int bk = bf16 ? 64 : 32;
-    if (p.A2) return false;
+    if (p.A2 || p.A3) return false;
     if (p.Kp % bk != 0) return false;
     if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; padded k / frames read the zero page
         if (!p.zero_page || p.cin % epc != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;

@@ -91,7 +91,7 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
     }
 }
 
-template <int EPI, bool CONV>
+template <int EPI, int CONV>        // CONV: 0 plain, 1 conv-gather, 2 conv-gather + appended pointwise K segment (A3)
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     const float rcin = CONV ? 1.0f / (float)p.cin : 0.0f;
     const bool reflect = p.pad_mode == PAD_REFLECT;
     const int lda2 = p.lda * 2, half = p.taps >> 1;
+    const int a3_shift = (CONV == 2 && p.lda3 > 0) ? __builtin_ctz((unsigned)(p.lda / p.lda3)) : 0;
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
 #pragma unroll
@@ -190,6 +191,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                 uint64_t q = reinterpret_cast<uint64_t>(src[ty][jj]) + (int64_t)offs;
                 asm volatile("" : "+v"(q));
                 s = reinterpret_cast<const char*>(ok ? q : reinterpret_cast<uint64_t>(p.zero_page));
+                if (CONV == 2) {
+                    // K tiles past the conv columns (uniform per K tile: K % 64 == 0) read row m of A3: same row index as this
+                    // lane's X row, so its byte offset is the X row offset scaled by lda3 / lda (a power of two, checked on the host)
+                    uint64_t q3 = reinterpret_cast<uint64_t>(p.A3) + ((reinterpret_cast<uint64_t>(src[ty][jj]) - reinterpret_cast<uint64_t>(p.A)) >> a3_shift)
+                                  + (uint32_t)((k - p.K) * 2);
+                    asm volatile("" : "+v"(q3));
+                    s = kt * 64 >= p.K ? reinterpret_cast<const char*>(q3) : s;
+                }
             }
             __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
         }
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #undef PW2_STAMP
 }
 
-template <int EPI, bool CONV>
+template <int EPI, int CONV>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static DeviceOnce attr;
@@ -459,6 +468,11 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y)) & 15) return false;
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
     if (p.scale && ((reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15)) return false;
+    if (p.A3) {              // appended pointwise segment: conv-gather, no activation, tile-aligned segments, lda = lda3 << s
+        if (p.taps <= 1 || p.act1 != ACT_NONE || p.act2 != ACT_NONE || p.K % 64 != 0 || p.K3 <= 0 || p.K3 % 64 != 0 || p.Kp != p.K + p.K3) return false;
+        if (p.lda3 <= 0 || p.lda % p.lda3 != 0 || ((p.lda / p.lda3) & (p.lda / p.lda3 - 1)) != 0 || p.lda3 % 8 != 0 || p.K3 > p.lda3) return false;
+        if (reinterpret_cast<uintptr_t>(p.A3) & 15) return false;
+    }
     if (p.taps > 1) {        // conv-gather: 16-byte chunks must not straddle taps; needs the zero page for padded k / frames
         if (!p.zero_page || p.cin % 8 != 0 || p.taps * p.cin != p.K || p.T <= 0 || p.M % p.T != 0) return false;
         if (p.pad_mode == PAD_REFLECT && (p.taps / 2) * p.dil >= p.T) return false;
@@ -471,12 +485,13 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw2_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     const bool conv = p.taps > 1;
-    if (p.act2 == ACT_LRELU03) return conv ? launch_inst<EPI_BN_LRELU03, true>(p, stream) : launch_inst<EPI_BN_LRELU03, false>(p, stream);
+    if (p.A3) return launch_inst<EPI_NONE, 2>(p, stream);
+    if (p.act2 == ACT_LRELU03) return conv ? launch_inst<EPI_BN_LRELU03, 1>(p, stream) : launch_inst<EPI_BN_LRELU03, 0>(p, stream);
     switch (p.act1) {
-        case ACT_NONE: return conv ? launch_inst<EPI_NONE, true>(p, stream) : launch_inst<EPI_NONE, false>(p, stream);
-        case ACT_RELU: return conv ? launch_inst<EPI_RELU, true>(p, stream) : launch_inst<EPI_RELU, false>(p, stream);
-        case ACT_GELU: return conv ? launch_inst<EPI_GELU, true>(p, stream) : launch_inst<EPI_GELU, false>(p, stream);
-        case ACT_LRELU03: return conv ? launch_inst<EPI_LRELU03, true>(p, stream) : launch_inst<EPI_LRELU03, false>(p, stream);
+        case ACT_NONE: return conv ? launch_inst<EPI_NONE, 1>(p, stream) : launch_inst<EPI_NONE, 0>(p, stream);
+        case ACT_RELU: return conv ? launch_inst<EPI_RELU, 1>(p, stream) : launch_inst<EPI_RELU, 0>(p, stream);
+        case ACT_GELU: return conv ? launch_inst<EPI_GELU, 1>(p, stream) : launch_inst<EPI_GELU, 0>(p, stream);
+        case ACT_LRELU03: return conv ? launch_inst<EPI_LRELU03, 1>(p, stream) : launch_inst<EPI_LRELU03, 0>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -68,6 +68,10 @@ struct GemmParams {
     const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
     const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last
     int ldr = 0;
+    // conv-gather GEMMs on the 256 x 256 bf16 kernel only: K3 extra K columns appended after the taps * cin conv columns, read
+    // from row m of a second matrix (the 1 x 1 shortcut of a RawNet2 block as part of conv2's GEMM: W is [N][K + K3], Kp = K + K3)
+    const void* A3 = nullptr;
+    int lda3 = 0, K3 = 0;
     int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
