@@ -63,9 +63,13 @@ constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 2
 template <typename T> struct SincCfg;
 template <> struct SincCfg<bf16_t> {
     static constexpr int COPY_BYTES = SINC_SAMPLES * 2 + 32;   // +32: successive copies start 2 bank-slots apart
-    static constexpr int LDS = 8 * COPY_BYTES;
+    static constexpr int XLDS = 8 * COPY_BYTES;
+    static constexpr int OUT_OFF = (XLDS + 255) & ~255;        // output tile: SINC_PT pooled frames x 128 filters, bf16
+    static constexpr int LDS = OUT_OFF + SINC_PT * 256;
 };
 template <> struct SincCfg<float> {
+    static constexpr int XLDS = SINC_SAMPLES * 4;
+    static constexpr int OUT_OFF = 0;
     static constexpr int LDS = SINC_SAMPLES * 4;
 };
 
@@ -107,26 +111,63 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         for (int kk = 0; kk < 126; ++kk) wff[kk] = w[2 * kk];
     }
 
+    // bf16: the tile's output goes through an LDS image and leaves as whole 256-byte rows one iteration later (under the next
+    // tile's staging).  Straight from the accumulator layout a store instruction writes 16 bytes to each of 32 rows: those
+    // stores were 260 of the kernel's 720 us (ablation: no stores 460 us, no MFMAs 408 us).
+    char* const otile = smem + CF::OUT_OFF;
+    auto flush = [&](int tpf) {                                      // 64 rows x 16 chunks of 16 bytes, 4 per thread
+        int tid_f = tid;
+        asm volatile("" : "+v"(tid_f));                              // (per-call address arithmetic: hoisted out of the tile loop it spills)
+#pragma unroll
+        for (int e = 0; e < SINC_PT * 16 / 256; ++e) {
+            const int idx = e * 256 + tid_f;
+            const int row = idx >> 4, c16 = idx & 15;
+            const u32x4 t = *reinterpret_cast<const u32x4*>(otile + row * 256 + ((c16 ^ ((row >> 1) & 15)) << 4));
+            const u32x4 d = (row & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
+            if (tpf + row < T1) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (((int64_t)b * T1 + tpf + row) * 128 + c16 * 8) * 2) = d;
+        }
+    };
+    constexpr int NSMP = (SINC_SAMPLES + 255) / 256;
+    float xr[NSMP];                                                 // raw samples of the NEXT tile (gamma / beta are L2-resident)
+    auto fetch = [&](int tpn, bool live) {
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+#pragma unroll
+        for (int e = 0; e < NSMP; ++e) {
+            const int j = 3 * tpn + tid_l + 256 * e;
+            const bool ok = live && tpn < T1 && tid_l + 256 * e < SINC_SAMPLES && j < L;
+            xr[e] = x[ok ? j : 0];
+        }
+    };
+    fetch(blockIdx.x * tiles_per_wg * SINC_PT, true);
+    int tp_prev = -1;
     for (int it = 0; it < tiles_per_wg; ++it) {
         const int tp0 = (blockIdx.x * tiles_per_wg + it) * SINC_PT;
         if (tp0 >= T1) break;                                        // workgroup-uniform
         const int s0 = 3 * tp0;                                      // first sample of this tile
-        __syncthreads();                                             // previous tile's reads are done
-        for (int i = tid; i < SINC_SAMPLES; i += 256) {
-            const int j = s0 + i;
-            float v = 0.0f;
-            if (j < L) v = gamma[j] * (x[j] - mean) * inv + beta[j];          // RawNet_baseline.py:24
-            if (BF) {
-                const bf16_t bv = static_cast<bf16_t>(v);
+        __syncthreads();                                             // previous tile's reads are done, its output image is complete
+        // this tile's samples were requested one iteration ago (before the previous tile's MFMAs): no global round trip here
+        int tid_s = tid;
+        asm volatile("" : "+v"(tid_s));
 #pragma unroll
-                for (int p = 0; p < 8; ++p)                                   // copy p holds the tile shifted by p samples
-                    if (i - p >= 0) *reinterpret_cast<bf16_t*>(smem + p * CF::LDS / 8 + (i - p) * 2) = bv;
-            } else {
-                reinterpret_cast<float*>(smem)[i] = v;
+        for (int e = 0; e < NSMP; ++e) {
+            const int i = tid_s + 256 * e;
+            if (i < SINC_SAMPLES) {
+                const int j = s0 + i;
+                const float v = j < L ? gamma[j] * (xr[e] - mean) * inv + beta[j] : 0.0f;      // RawNet_baseline.py:24
+                if (BF) {
+                    const bf16_t bv = static_cast<bf16_t>(v);
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)                               // copy p holds the tile shifted by p samples
+                        if (i - p >= 0) *reinterpret_cast<bf16_t*>(smem + p * (CF::XLDS / 8) + (i - p) * 2) = bv;
+                } else {
+                    reinterpret_cast<float*>(smem)[i] = v;
+                }
             }
         }
+        fetch(tp0 + SINC_PT, it + 1 < tiles_per_wg);                 // next tile's samples: in flight under this tile's MFMAs
+        if (BF && tp_prev >= 0) flush(tp_prev);                      // (stores behind the loads: vmcnt retires in order)
         __syncthreads();
-
         // acc[a][j]: fp32: a = position group g (filters of this wave); bf16: a = filter block of this wave's half (position group gw)
         f32x16 acc[2][3];
 #pragma unroll
@@ -139,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
-                const char* base = smem + (s & 7) * (CF::LDS / 8) + ((s >> 3) + fh) * 16;
+                const char* base = smem + (s & 7) * (CF::XLDS / 8) + ((s >> 3) + fh) * 16;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
@@ -159,12 +200,14 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                 }
         }
         // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 filters per group
+        int fr_e = fr, fh_e = fh;
+        asm volatile("" : "+v"(fr_e), "+v"(fh_e));
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int tp = tp0 + 32 * (BF ? gw : g) + fr;
+            const int tp = tp0 + 32 * (BF ? gw : g) + fr_e;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f = (BF ? nf * 64 + g * 32 : wave * 32) + 8 * q + 4 * fh;
+                const int f = (BF ? nf * 64 + g * 32 : wave * 32) + 8 * q + 4 * fh_e;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_scale + f);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(bn_shift + f);
                 float v[4];
@@ -183,7 +226,10 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                     if (BF) {
                         typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
                         bf16x4 pk = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
-                        *reinterpret_cast<bf16x4*>(out + oi) = pk;
+                        {   // 8-byte chunk c8 of row `row` lives at chunk c8 ^ (row & 31): the 32 rows of one store land on 32 banks
+                            const int row = 32 * gw + fr_e, c8 = f >> 2;
+                            *reinterpret_cast<bf16x4*>(otile + row * 256 + ((c8 ^ (row & 31)) << 3)) = pk;
+                        }
                         if (pre) {
                             bf16x4 pp;
 #pragma unroll
@@ -202,6 +248,11 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                 }
             }
         }
+        tp_prev = tp0;
+    }
+    if (BF && tp_prev >= 0) {
+        __syncthreads();
+        flush(tp_prev);
     }
 }
 
