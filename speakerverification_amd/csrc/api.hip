@@ -98,6 +98,8 @@ struct svhip_handle {
     LinearLayer rn_fc;
     void* rn_buf[6] = {};                 // activation ping-pong buffers
     float* rn_scratch = nullptr;
+    void* rn_xn = nullptr;
+    int rn_Lp = 0;
     float *rn_stats = nullptr, *rn_mean = nullptr, *rn_s = nullptr, *rn_logits = nullptr, *rn_pooled = nullptr;
     float* rn_part = nullptr;             // fused 128-channel blocks: per-tile column sums (B, ntiles, 128)
     int num_cu = 256;
@@ -690,6 +692,12 @@ int alloc_workspace(svhip_handle* h) {
             h->rn_buf[i] = q;
         }
         if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
+        if (h->bf16) {                                           // LayerNorm output as bf16, zero-tailed rows (operand of the bf16 sinc kernel)
+            h->rn_Lp = (int)round_up(c.samples + RN_XN_TAIL, 64);
+            uint16_t* q;
+            if ((rc = dev_alloc(h, &q, 2 * B * (size_t)h->rn_Lp))) return rc;
+            h->rn_xn = q;
+        }
         if ((rc = dev_alloc(h, &h->rn_part, B * (size_t)(rn_block128_ntiles(h->rn_T1) + 1) * 4 * 128))) return rc;
         if ((rc = dev_alloc(h, &h->rn_mean, B * 512))) return rc;
         if ((rc = dev_alloc(h, &h->rn_scratch, B * 16 * 512))) return rc;
@@ -936,7 +944,8 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     float* rn_pooled = h->rn_pooled + (size_t)b0 * 1024;
     float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     int rc;
-    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st); }))) return rc;
+    void* rn_xn = bf ? static_cast<char*>(h->rn_xn) + (size_t)b0 * 2 * h->rn_Lp * 2 : nullptr;
+    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st, rn_xn, h->rn_Lp, h->rn_gamma, h->rn_beta); }))) return rc;
     int T = h->rn_T1;
     void *x = off(h->rn_buf[0], b0 * per_utt, e), *pre = off(h->rn_buf[1], b0 * per_utt, e), *hb = off(h->rn_buf[2], b0 * per_utt, e),
          *o = off(h->rn_buf[3], b0 * per_utt, e), *sc = off(h->rn_buf[4], b0 * per_utt, e), *xn = off(h->rn_buf[5], b0 * per_utt, e);
@@ -945,7 +954,8 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
-             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st);
+             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st,
+                                   nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu);
          }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
     // bf16: the 128 -> 128 pooled blocks (layer1, layer2) each run as ONE fused kernel + the AFMS gate kernel; the gate of

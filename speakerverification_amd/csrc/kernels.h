@@ -209,11 +209,17 @@ hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------
 // RawNet2 (rawnet2.hip)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream);
+// (xn: optional bf16 copies of the LayerNorm output, per utterance two zero-tailed rows of Lp >= L + RN_XN_TAIL samples (Lp % 64
+//  == 0): sample j at index j, then sample j + 1 at index j — the operand of the bf16 sinc kernel, which reads up to 470 samples
+//  past its last tile's first sample)
+constexpr int RN_XN_TAIL = 512;
+hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn = nullptr, int Lp = 0,
+                              const float* gamma = nullptr, const float* beta = nullptr);
 // LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
-                          hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr);
+                          hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr,
+                          const void* xn = nullptr, int Lp = 0, int num_cu = 256);
 hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
                             float slope, hipStream_t stream);
 hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream);

@@ -22,7 +22,11 @@ namespace svhip {
 
 namespace {
 
-__global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restrict__ x, int L, float* __restrict__ stats) {
+// With `xn` the kernel also writes the LayerNorm output gamma * (x - mean) * inv + beta (RawNet_baseline.py:24) as bf16 into a
+// zero-tailed row of Lp samples: the bf16 sinc kernel stages its operand from it with LDS-DMA (no arithmetic in its tile loop).
+__global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restrict__ x, int L, float* __restrict__ stats,
+                                                          bf16_t* __restrict__ xn, int Lp, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const float* __restrict__ p = x + (int64_t)b * L;
@@ -50,10 +54,43 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
     q = wave_sum(q);
     if (lane == 0) red[wave] = q;
     __syncthreads();
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)(L - 1);          // torch.std: unbiased
+    const float inv = 1.0f / (sqrtf(var) + 1e-6f);
     if (threadIdx.x == 0) {
-        const float var = (red[0] + red[1] + red[2] + red[3]) / (float)(L - 1);      // torch.std: unbiased
         stats[2 * b] = mean;
-        stats[2 * b + 1] = 1.0f / (sqrtf(var) + 1e-6f);
+        stats[2 * b + 1] = inv;
+    }
+    if (xn) {
+        // copy 0: sample j at index j; copy 1: sample j + 1 at index j — so that every 2-sample LDS-DMA of the sinc kernel, for an
+        // even or an odd shift, starts on a 4-byte boundary
+        bf16_t* __restrict__ o0 = xn + (int64_t)b * 2 * Lp;
+        bf16_t* __restrict__ o1 = o0 + Lp;
+        const bool vec = (L % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+        for (int j0 = threadIdx.x * 8; j0 < Lp; j0 += 256 * 8) {
+            float v[9];
+            if (vec && j0 + 8 <= L) {                                // 16-byte loads (scalar loads ran this pass at 50 us per launch)
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(p + j0), x1 = *reinterpret_cast<const f32x4*>(p + j0 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + j0), g1 = *reinterpret_cast<const f32x4*>(gamma + j0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + j0), b1 = *reinterpret_cast<const f32x4*>(beta + j0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = g0[e] * (x0[e] - mean) * inv + b0[e];
+                    v[4 + e] = g1[e] * (x1[e] - mean) * inv + b1[e];
+                }
+                v[8] = j0 + 8 < L ? gamma[j0 + 8] * (p[j0 + 8] - mean) * inv + beta[j0 + 8] : 0.0f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int j = j0 + e;
+                    v[e] = j < L ? gamma[j] * (p[j] - mean) * inv + beta[j] : 0.0f;
+                }
+            }
+            bf16x8 a, c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = static_cast<bf16_t>(v[e]); c[e] = static_cast<bf16_t>(v[e + 1]); }
+            *reinterpret_cast<bf16x8*>(o0 + j0) = a;
+            *reinterpret_cast<bf16x8*>(o1 + j0) = c;
+        }
     }
 }
 
@@ -63,13 +100,15 @@ constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 2
 template <typename T> struct SincCfg;
 template <> struct SincCfg<bf16_t> {
     static constexpr int COPY_BYTES = SINC_SAMPLES * 2 + 32;   // +32: successive copies start 2 bank-slots apart
-    static constexpr int XLDS = 8 * COPY_BYTES;
-    static constexpr int OUT_OFF = (XLDS + 255) & ~255;        // output tile: SINC_PT pooled frames x 128 filters, bf16
-    static constexpr int LDS = OUT_OFF + SINC_PT * 256;
+    static constexpr int XLDS = 8 * COPY_BYTES;                // one operand buffer: 8 sample-shifted copies of the tile
+    static constexpr int OUT_OFF = (2 * XLDS + 255) & ~255;    // two operand buffers, then two output images
+    static constexpr int OUT_BYTES = SINC_PT * 256;            // output tile: SINC_PT pooled frames x 128 filters, bf16
+    static constexpr int LDS = OUT_OFF + 2 * OUT_BYTES;
 };
 template <> struct SincCfg<float> {
     static constexpr int XLDS = SINC_SAMPLES * 4;
     static constexpr int OUT_OFF = 0;
+    static constexpr int OUT_BYTES = 0;
     static constexpr int LDS = SINC_SAMPLES * 4;
 };
 
@@ -80,11 +119,18 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                                                          const void* __restrict__ filt, const float* __restrict__ bn_scale,
                                                          const float* __restrict__ bn_shift, T* __restrict__ out, T* __restrict__ pre, const float* __restrict__ nscale,
                                                          const float* __restrict__ nshift, int L, int T1,
-                                                         int tiles_per_wg) {
+                                                         int B, const bf16_t* __restrict__ xn, int Lp) {
     typedef SincCfg<T> CF;
     constexpr bool BF = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.y;
+    // Persistent: the grid is two workgroups per CU, each owns a contiguous range of (utterance, tile) items and loads its filter
+    // fragments ONCE (32 KiB per wave, every wave of every workgroup from the same 64 KiB table: with 4 tiles per workgroup and
+    // 10 752 workgroups that start-up was ~5 us each, a fifth of the kernel — 723 / 613 / 553 / 497 us at 2 / 4 / 8 / 42 tiles).
+    const int tiles_u = (T1 + SINC_PT - 1) / SINC_PT;
+    const int items = B * tiles_u;                               // (< 2^31: checked by the launcher)
+    const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item0 = (int)blockIdx.x * per, item1 = item0 + per < items ? item0 + per : items;
+    if (item0 >= items) return;                                  // workgroup-uniform
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // fp32: wave = n-tile (filters wave*32 .. +31), both position groups.  bf16: wave = (filter half nf, position group gw):
@@ -92,8 +138,6 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
     // wave the kernel sat on the LDS read port (1 KiB per MFMA from 8 waves = 256 B/clk per CU): 0.91 ms -> see DESIGN.md
     const int nf = wave & 1, gw = wave >> 1;
     const int fr = lane & 31, fh = lane >> 5;
-    const float mean = stats[2 * b], inv = stats[2 * b + 1];
-    const float* __restrict__ x = wav + (int64_t)b * L;
 
     // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand)
     bf16x8 wfb[BF ? 2 : 1][BF ? 16 : 1];
@@ -111,63 +155,87 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         for (int kk = 0; kk < 126; ++kk) wff[kk] = w[2 * kk];
     }
 
-    // bf16: the tile's output goes through an LDS image and leaves as whole 256-byte rows one iteration later (under the next
-    // tile's staging).  Straight from the accumulator layout a store instruction writes 16 bytes to each of 32 rows: those
-    // stores were 260 of the kernel's 720 us (ablation: no stores 460 us, no MFMAs 408 us).
-    char* const otile = smem + CF::OUT_OFF;
-    auto flush = [&](int tpf) {                                      // 64 rows x 16 chunks of 16 bytes, 4 per thread
+    // bf16: no arithmetic and no VGPR traffic on the way in — the LayerNorm output exists as bf16 (rn_ln_stats), and the 8
+    // sample-shifted copies of the NEXT tile are written by 2-byte LDS-DMA while this tile's MFMAs run (two operand buffers).
+    // The tile's output goes through an LDS image (two of them) and leaves as whole 256-byte rows one iteration later.
+    // History: register-staged operand + 16-byte scattered stores 720 us (ablations: no stores 460, no MFMAs 408) -> samples
+    // requested one tile ahead + LDS output image 637 us -> LDS-DMA operand, one barrier per tile: see DESIGN.md.
+    auto flush = [&](int b, int tpf, const char* img) {              // 64 rows x 16 chunks of 16 bytes, 4 per thread
         int tid_f = tid;
         asm volatile("" : "+v"(tid_f));                              // (per-call address arithmetic: hoisted out of the tile loop it spills)
 #pragma unroll
         for (int e = 0; e < SINC_PT * 16 / 256; ++e) {
             const int idx = e * 256 + tid_f;
             const int row = idx >> 4, c16 = idx & 15;
-            const u32x4 t = *reinterpret_cast<const u32x4*>(otile + row * 256 + ((c16 ^ ((row >> 1) & 15)) << 4));
+            const u32x4 t = *reinterpret_cast<const u32x4*>(img + row * 256 + ((c16 ^ ((row >> 1) & 15)) << 4));
             const u32x4 d = (row & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
             if (tpf + row < T1) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (((int64_t)b * T1 + tpf + row) * 128 + c16 * 8) * 2) = d;
         }
     };
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_t;
+    auto dma = [&](int item, int buf) {                          // copy pc, index i <- sample 3 * tpn + i + pc of utterance b
+        const int b = item / tiles_u, tpn = (item - b * tiles_u) * SINC_PT;
+        // 4-byte DMAs (two samples per lane, LDS destination = wave-uniform base + 4 * lane): the source of an odd shift comes
+        // from the second, one-sample-shifted copy of the waveform, so every source address is 4-byte aligned
+        const bf16_t* src0 = xn + (int64_t)b * 2 * Lp + 3 * tpn + 2 * lane;
+        char* dst = smem + buf * CF::XLDS;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                                // 8 copies x 4 segments of 128 samples = 32 wave-instructions, 8 per wave
+            const int idx = wave + 4 * e, pc = idx >> 2, q = idx & 3;
+            const bf16_t* src = src0 + (pc & 1) * Lp + (pc & ~1) + q * 128;
+            if (q * 128 + 2 * lane < SINC_SAMPLES)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + pc * (CF::XLDS / 8) + q * 256), 4, 0, 0);
+        }
+    };
     constexpr int NSMP = (SINC_SAMPLES + 255) / 256;
-    float xr[NSMP];                                                 // raw samples of the NEXT tile (gamma / beta are L2-resident)
-    auto fetch = [&](int tpn, bool live) {
+    float xr[NSMP];                                                 // fp32 path: raw samples of the NEXT tile (gamma / beta are L2-resident)
+    auto fetch = [&](int item) {
+        if (item >= item1) return;
+        const int b = item / tiles_u, tpn = (item - b * tiles_u) * SINC_PT;
+        const float* __restrict__ x = wav + (int64_t)b * L;
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));
 #pragma unroll
         for (int e = 0; e < NSMP; ++e) {
             const int j = 3 * tpn + tid_l + 256 * e;
-            const bool ok = live && tpn < T1 && tid_l + 256 * e < SINC_SAMPLES && j < L;
+            const bool ok = tid_l + 256 * e < SINC_SAMPLES && j < L;
             xr[e] = x[ok ? j : 0];
         }
     };
-    fetch(blockIdx.x * tiles_per_wg * SINC_PT, true);
-    int tp_prev = -1;
-    for (int it = 0; it < tiles_per_wg; ++it) {
-        const int tp0 = (blockIdx.x * tiles_per_wg + it) * SINC_PT;
-        if (tp0 >= T1) break;                                        // workgroup-uniform
+    if (BF) dma(item0, 0);
+    else fetch(item0);
+    int tp_prev = -1, b_prev = 0;
+    for (int item = item0; item < item1; ++item) {
+        const int it = item - item0;
+        const int b = item / tiles_u;
+        const int tp0 = (item - b * tiles_u) * SINC_PT;
         const int s0 = 3 * tp0;                                      // first sample of this tile
-        __syncthreads();                                             // previous tile's reads are done, its output image is complete
-        // this tile's samples were requested one iteration ago (before the previous tile's MFMAs): no global round trip here
-        int tid_s = tid;
-        asm volatile("" : "+v"(tid_s));
+        // bf16: this tile's operand (DMA issued one iteration ago; the barrier's vmcnt(0) retires it) is in buffer it & 1, every
+        // wave is past the MFMAs of the previous tile and past its epilogue (output image (it - 1) & 1 complete)
+        if (BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* const xbuf = smem + (BF ? (it & 1) * CF::XLDS : 0);
+        char* const otile = smem + CF::OUT_OFF + (it & 1) * CF::OUT_BYTES;
+        if (BF) {
+            if (item + 1 < item1) dma(item + 1, (it + 1) & 1);
+            if (tp_prev >= 0) flush(b_prev, tp_prev, smem + CF::OUT_OFF + ((it - 1) & 1) * CF::OUT_BYTES);
+        } else {
+            // this tile's samples were requested one iteration ago (before the previous tile's MFMAs): no global round trip here
+            const float mean = stats[2 * b], inv = stats[2 * b + 1];
+            int tid_s = tid;
+            asm volatile("" : "+v"(tid_s));
 #pragma unroll
-        for (int e = 0; e < NSMP; ++e) {
-            const int i = tid_s + 256 * e;
-            if (i < SINC_SAMPLES) {
-                const int j = s0 + i;
-                const float v = j < L ? gamma[j] * (xr[e] - mean) * inv + beta[j] : 0.0f;      // RawNet_baseline.py:24
-                if (BF) {
-                    const bf16_t bv = static_cast<bf16_t>(v);
-#pragma unroll
-                    for (int p = 0; p < 8; ++p)                               // copy p holds the tile shifted by p samples
-                        if (i - p >= 0) *reinterpret_cast<bf16_t*>(smem + p * (CF::XLDS / 8) + (i - p) * 2) = bv;
-                } else {
-                    reinterpret_cast<float*>(smem)[i] = v;
+            for (int e = 0; e < NSMP; ++e) {
+                const int i = tid_s + 256 * e;
+                if (i < SINC_SAMPLES) {
+                    const int j = s0 + i;
+                    reinterpret_cast<float*>(smem)[i] = j < L ? gamma[j] * (xr[e] - mean) * inv + beta[j] : 0.0f;      // RawNet_baseline.py:24
                 }
             }
+            fetch(item + 1);                                         // next tile's samples: in flight under this tile's MFMAs
+            __syncthreads();
         }
-        fetch(tp0 + SINC_PT, it + 1 < tiles_per_wg);                 // next tile's samples: in flight under this tile's MFMAs
-        if (BF && tp_prev >= 0) flush(tp_prev);                      // (stores behind the loads: vmcnt retires in order)
-        __syncthreads();
         // acc[a][j]: fp32: a = position group g (filters of this wave); bf16: a = filter block of this wave's half (position group gw)
         f32x16 acc[2][3];
 #pragma unroll
@@ -180,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
-                const char* base = smem + (s & 7) * (CF::XLDS / 8) + ((s >> 3) + fh) * 16;
+                const char* base = xbuf + (s & 7) * (CF::XLDS / 8) + ((s >> 3) + fh) * 16;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
@@ -248,11 +316,11 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                 }
             }
         }
-        tp_prev = tp0;
+        tp_prev = tp0; b_prev = b;
     }
     if (BF && tp_prev >= 0) {
         __syncthreads();
-        flush(tp_prev);
+        flush(b_prev, tp_prev, smem + CF::OUT_OFF + ((item1 - 1 - item0) & 1) * CF::OUT_BYTES);
     }
 }
 
@@ -454,24 +522,31 @@ inline int grid_for(int64_t items) {
 
 }  // namespace
 
-hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream) {
-    hipLaunchKernelGGL(rn_ln_stats_kernel, dim3(B), dim3(256), 0, stream, wav, L, stats);
+hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn, int Lp, const float* gamma,
+                              const float* beta) {
+    if (xn && (Lp < L + RN_XN_TAIL || Lp % 64 != 0 || !gamma || !beta)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rn_ln_stats_kernel, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<bf16_t*>(xn), Lp, gamma, beta);
     return hipGetLastError();
 }
 
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
-                          hipStream_t stream, void* pre, const float* next_scale, const float* next_shift) {
+                          hipStream_t stream, void* pre, const float* next_scale, const float* next_shift, const void* xn, int Lp, int num_cu) {
+    if (B <= 0) return hipErrorInvalidValue;
     if (T1 != (L - 250) / 3 || L < 251 + 3 || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
-    const int tiles = (T1 + SINC_PT - 1) / SINC_PT;
-    const int tpw = 4;                                        // pooled tiles per workgroup (amortises the filter fragments)
-    dim3 grid((tiles + tpw - 1) / tpw, B), block(256);
+    if (bf16 && (!xn || Lp < L + RN_XN_TAIL || Lp % 64 != 0)) return hipErrorInvalidValue;          // the bf16 kernel stages from the normalised copy
+    const int64_t items = (int64_t)B * ((T1 + SINC_PT - 1) / SINC_PT);
+    if (items >= (1ll << 31)) return hipErrorInvalidValue;
+    const int slots = 2 * (num_cu > 0 ? num_cu : 256);               // two workgroups per CU (256 VGPRs per lane, 47 KiB of LDS each)
+    dim3 grid((unsigned)(items < slots ? items : slots)), block(256);
     if (bf16)
         hipLaunchKernelGGL(rn_sinc_kernel<bf16_t>, grid, block, SincCfg<bf16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
-                           bn_shift, reinterpret_cast<bf16_t*>(out), reinterpret_cast<bf16_t*>(pre), next_scale, next_shift, L, T1, tpw);
+                           bn_shift, reinterpret_cast<bf16_t*>(out), reinterpret_cast<bf16_t*>(pre), next_scale, next_shift, L, T1, B,
+                           reinterpret_cast<const bf16_t*>(xn), Lp);
     else
         hipLaunchKernelGGL(rn_sinc_kernel<float>, grid, block, SincCfg<float>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
-                           bn_shift, reinterpret_cast<float*>(out), reinterpret_cast<float*>(pre), next_scale, next_shift, L, T1, tpw);
+                           bn_shift, reinterpret_cast<float*>(out), reinterpret_cast<float*>(pre), next_scale, next_shift, L, T1, B,
+                           static_cast<const bf16_t*>(nullptr), 0);
     return hipGetLastError();
 }
 
