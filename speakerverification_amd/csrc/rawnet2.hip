@@ -103,13 +103,15 @@ template <> struct SincCfg<bf16_t> {
     static constexpr int XLDS = 8 * COPY_BYTES;                // one operand buffer: 8 sample-shifted copies of the tile
     static constexpr int OUT_OFF = (2 * XLDS + 255) & ~255;    // two operand buffers, then two output images
     static constexpr int OUT_BYTES = SINC_PT * 256;            // output tile: SINC_PT pooled frames x 128 filters, bf16
-    static constexpr int LDS = OUT_OFF + 2 * OUT_BYTES;
+    static constexpr int BN_OFF = OUT_OFF + 2 * OUT_BYTES;     // first_bn scale[128], shift[128] (fp32)
+    static constexpr int LDS = BN_OFF + 1024;
 };
 template <> struct SincCfg<float> {
     static constexpr int XLDS = SINC_SAMPLES * 4;
     static constexpr int OUT_OFF = 0;
     static constexpr int OUT_BYTES = 0;
-    static constexpr int LDS = SINC_SAMPLES * 4;
+    static constexpr int BN_OFF = SINC_SAMPLES * 4;
+    static constexpr int LDS = BN_OFF + 1024;
 };
 
 // filters: bf16: [128][256] bf16 (k contiguous); fp32: [128][252] fp32.
@@ -203,6 +205,10 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
             xr[e] = x[ok ? j : 0];
         }
     };
+    // the BatchNorm constants of the epilogue live in LDS: an ordinary global load inside the tile loop makes the compiler drain
+    // vmcnt — the next tile's DMAs and the previous tile's row stores — before the epilogue can start
+    float* const bnl = reinterpret_cast<float*>(smem + CF::BN_OFF);
+    bnl[tid] = tid < 128 ? bn_scale[tid] : bn_shift[tid - 128];
     if (BF) dma(item0, 0);
     else fetch(item0);
     int tp_prev = -1, b_prev = 0;
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int f = (BF ? nf * 64 + g * 32 : wave * 32) + 8 * q + 4 * fh_e;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(bn_scale + f);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(bn_shift + f);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnl + f);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(bnl + 128 + f);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
