@@ -44,6 +44,14 @@ constexpr bool DBG2 = true;      // tools/gemm_bench (GemmParams::debug): 1024 /
 #else
 constexpr bool DBG2 = false;
 #endif
+// compile-time ablations (tools/abl_pw2.sh builds one gemm_bench per value; 0 in every shipped build):
+//   1 no MFMAs, 2 no operand DMAs, 4 no activation in the epilogue, 8 no output stores, 16 no fragment reads,
+//   32 every workgroup DMAs tile (0, 0)'s operands (all L2 hits: separates the memory side of the DMAs from their LDS side)
+#ifdef PW2_ABL
+constexpr int ABL = PW2_ABL;
+#else
+constexpr int ABL = 0;
+#endif
 
 // GELU for the bf16 path: x * sigmoid(x * (c0 + c1 s + c2 s^2)), s = min(x^2, 52) (the polynomial peaks at s = 52.6, so the
 // clamp keeps it monotone); coefficients are a minimax fit to 0.5 x (1 + erf(x / sqrt 2)) over [-8, 8]: |err| <= 2.6e-5 absolute,
@@ -155,12 +163,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty) {
             if (ty < 2) {
-                const int m = min(m0 + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);
+                const int m = min(((ABL & 32) ? 0 : m0) + (rho >> 6) * 128 + (ty & 1) * 64 + (rho & 63), p.M - 1);      // (ABL 32: every tile reads tile 0's operands)
                 // (CONV: the row start only — the chunk is part of the per-K-tile offset)
                 src[ty][jj] = reinterpret_cast<const char*>(p.A) + ((int64_t)m * p.lda + (CONV ? 0 : c * 8)) * 2;
                 if (CONV) cfrm[ty][jj] = m - (m / p.T) * p.T;
             } else {
-                const int n = min(n0 + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
+                const int n = min(((ABL & 32) ? 0 : n0) + (rho >> 5) * 64 + (ty & 1) * 32 + (rho & 31), p.Wrows - 1);
                 src[ty][jj] = reinterpret_cast<const char*>(p.W) + ((int64_t)n * p.Kp + c * 8) * 2;
             }
         }
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                     s = kt * 64 >= p.K ? reinterpret_cast<const char*>(q3) : s;
                 }
             }
-            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
+            if (!(ABL & 2)) __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
         }
     };
     auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     }
 #define PW2_MFMA(I0, WARR, J0)                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                  \
+    if (!(ABL & 1))                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
@@ -266,19 +275,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+                if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
         PW2_PHASE_END(0)                                                                            \
         PW2_MFMA(0, WCUR, 0)                                                                        \
         /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+                if (!(ABL & 16)) whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
         PW2_PHASE_END(1)                                                                            \
         PW2_MFMA(0, whi, 2)                                                                         \
         /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
-                xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+                if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
         PW2_PHASE_END(2)                                                                            \
         PW2_MFMA(4, whi, 2)                                                                         \
         /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
                 _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
-                    WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+                    if (!(ABL & 16)) WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
         }                                                                                           \
         PW2_PHASE_END(3)                                                                            \
         PW2_MFMA(4, WCUR, 0)                                                                        \
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         for (int i = 0; i < 8; ++i) {
             const int ml = wm * 128 + i * 16 + r16;
             float v[4];
-            act4<EPI>(v, acc16[i][cg], sc4a[cg], sh4a[cg]);
+            if (ABL & 4) { v[0] = acc16[i][cg][0]; v[1] = acc16[i][cg][1]; v[2] = acc16[i][cg][2]; v[3] = acc16[i][cg][3]; }
+            else act4<EPI>(v, acc16[i][cg], sc4a[cg], sh4a[cg]);
             typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
             const u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
             const int m = m0 + row, n = n0 + q * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
+            if (m < p.M && n < p.N && !(ABL & 8)) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
         }
     }
     if (DBG2 && (p.debug & 16384) && p.ts) {
