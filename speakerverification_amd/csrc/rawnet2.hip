@@ -99,7 +99,12 @@ constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 2
 
 template <typename T> struct SincCfg;
 template <> struct SincCfg<bf16_t> {
-    static constexpr int COPY_BYTES = SINC_SAMPLES * 2 + 32;   // +32: successive copies start 2 bank-slots apart
+    // Copy c starts at c * COPY_BYTES + 16 * ((COPY_SKEW >> 4c) & 15): start offsets (mod 256 bytes) found by search so that the
+    // ds_read_b128 lane groups of the fragment pattern (positions 3 * frame + j: stride-3 rows across the 8 copies) spread over
+    // the banks.  A uniform stride of 960 bytes cost one extra LDS cycle per lane group on average (PMC: bank-conflict cycles
+    // = 28 % of the kernel's CU cycles); this assignment a third of that — no assignment of 8 offsets is conflict-free.
+    static constexpr int COPY_BYTES = 1280;                    // 928 bytes of samples + up to 240 of skew, 256-byte multiple
+    static constexpr unsigned COPY_SKEW = 0xEC924960u;         // offsets 0, 6, 9, 4, 2, 9, 12, 14 (x 16 bytes) for copies 0..7
     static constexpr int XLDS = 8 * COPY_BYTES;                // one operand buffer: 8 sample-shifted copies of the tile
     static constexpr int OUT_OFF = (2 * XLDS + 255) & ~255;    // two operand buffers, then two output images
     static constexpr int OUT_BYTES = SINC_PT * 256;            // output tile: SINC_PT pooled frames x 128 filters, bf16
@@ -107,6 +112,8 @@ template <> struct SincCfg<bf16_t> {
     static constexpr int LDS = BN_OFF + 1024;
 };
 template <> struct SincCfg<float> {
+    static constexpr int COPY_BYTES = 0;
+    static constexpr unsigned COPY_SKEW = 0;
     static constexpr int XLDS = SINC_SAMPLES * 4;
     static constexpr int OUT_OFF = 0;
     static constexpr int OUT_BYTES = 0;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
             const int idx = wave + 4 * e, pc = idx >> 2, q = idx & 3;
             const bf16_t* src = src0 + (pc & 1) * Lp + (pc & ~1) + q * 128;
             if (q * 128 + 2 * lane < SINC_SAMPLES)
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + pc * (CF::XLDS / 8) + q * 256), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + pc * CF::COPY_BYTES + ((CF::COPY_SKEW >> (4 * pc)) & 15) * 16 + q * 256), 4, 0, 0);
         }
     };
     constexpr int NSMP = (SINC_SAMPLES + 255) / 256;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
-                const char* base = xbuf + (s & 7) * (CF::XLDS / 8) + ((s >> 3) + fh) * 16;
+                const char* base = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + fh) * 16;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
