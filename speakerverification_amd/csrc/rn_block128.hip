@@ -115,14 +115,18 @@ __device__ __forceinline__ void conv_k3(const char* src, const bf16x8 (&w)[2][12
     if (!no_rd) { fetch(0, xb[0]); fetch(1, xb[1]); }
     __builtin_amdgcn_s_setprio(1);              // the SIMD's other wave is in its vector / LDS phase: the matrix stream wins issue arbitration
     if (INIT) {
+        // A lane's 4 channels of one row are 8 bytes; rows 16 apart share a swizzle key, so 8-byte accesses of 16 rows are 2-way
+        // bank conflicts.  Lanes l and l + 16 (q4 even / odd) own the two halves of one 16-byte chunk: the even one fetches the
+        // whole chunk of channel block 0, the odd one that of block 1, and v_permlane16_swap hands each its own halves.
 #pragma unroll
-        for (int fb = 0; fb < RB_FB; ++fb)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int q = fb * 16 + r16, n = w4 * 32 + cb * 16 + 4 * q4;
-                const u32x2 y2 = *reinterpret_cast<const u32x2*>(init + q * 256 + (((n >> 3) ^ RB_SWZ(q)) << 4) + ((n >> 2) & 1) * 8);
-                acc[fb][cb] = f32x4{bf_lo(y2[0]), bf_hi(y2[0]), bf_lo(y2[1]), bf_hi(y2[1])};
-            }
+        for (int fb = 0; fb < RB_FB; ++fb) {
+            const int q = fb * 16 + r16, c16 = w4 * 4 + (q4 & 1) * 2 + (q4 >> 1);
+            const u32x4 y4 = *reinterpret_cast<const u32x4*>(init + q * 256 + ((c16 ^ RB_SWZ(q)) << 4));
+            const auto s0 = __builtin_amdgcn_permlane16_swap(y4[0], y4[2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(y4[1], y4[3], false, false);
+            acc[fb][0] = f32x4{bf_lo(s0[0]), bf_hi(s0[0]), bf_lo(s1[0]), bf_hi(s1[0])};
+            acc[fb][1] = f32x4{bf_lo(s0[1]), bf_hi(s0[1]), bf_lo(s1[1]), bf_hi(s1[1])};
+        }
     } else {
 #pragma unroll
         for (int fb = 0; fb < RB_FB; ++fb)
@@ -268,14 +272,18 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
                     const int q = fb * 16 + r16;
                     const int f = t0 - 1 + q;
                     const uint32_t vmask = (!edge || (f >= 0 && f < p.T)) ? 0xffffffffu : 0u;
+                    u32x2 o[2];
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
-                        const int n = w4 * 32 + cb * 16 + 4 * q4;
-                        u32x2 o;
-                        o[0] = bf_pack(lrelu03(fmaf(acc[fb][cb][0], sc2[cb][0], sh2[cb][0])), lrelu03(fmaf(acc[fb][cb][1], sc2[cb][1], sh2[cb][1]))) & vmask;
-                        o[1] = bf_pack(lrelu03(fmaf(acc[fb][cb][2], sc2[cb][2], sh2[cb][2])), lrelu03(fmaf(acc[fb][cb][3], sc2[cb][3], sh2[cb][3]))) & vmask;
-                        *reinterpret_cast<u32x2*>(hbuf + q * 256 + (((n >> 3) ^ RB_SWZ(q)) << 4) + ((n >> 2) & 1) * 8) = o;
+                        o[cb][0] = bf_pack(lrelu03(fmaf(acc[fb][cb][0], sc2[cb][0], sh2[cb][0])), lrelu03(fmaf(acc[fb][cb][1], sc2[cb][1], sh2[cb][1]))) & vmask;
+                        o[cb][1] = bf_pack(lrelu03(fmaf(acc[fb][cb][2], sc2[cb][2], sh2[cb][2])), lrelu03(fmaf(acc[fb][cb][3], sc2[cb][3], sh2[cb][3]))) & vmask;
                     }
+                    // whole 16-byte chunks: the even lane of a pair writes channel block 0 (its half, then its partner's), the odd
+                    // one block 1 (see conv_k3's accumulator load) — ds_write_b128 of 8 consecutive rows is conflict-free
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                    const int c16 = w4 * 4 + (q4 & 1) * 2 + (q4 >> 1);
+                    *reinterpret_cast<u32x4*>(hbuf + q * 256 + ((c16 ^ RB_SWZ(q)) << 4)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows requested in the previous vector phase have landed (converted next)
@@ -289,15 +297,10 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
 #pragma unroll
             for (int fb = 0; fb < RB_FB; ++fb) {
                 const int q = fb * 16 + r16;
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const int n = w4 * 32 + cb * 16 + 4 * q4;
-                    const int off = q * 256 + (((n >> 3) ^ RB_SWZ(q)) << 4) + ((n >> 2) & 1) * 8;
-                    u32x2 o;
-                    o[0] = bf_pack(acc[fb][cb][0], acc[fb][cb][1]);
-                    o[1] = bf_pack(acc[fb][cb][2], acc[fb][cb][3]);
-                    *reinterpret_cast<u32x2*>(smem + RB_O + off) = o;
-                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(bf_pack(acc[fb][0][0], acc[fb][0][1]), bf_pack(acc[fb][1][0], acc[fb][1][1]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(bf_pack(acc[fb][0][2], acc[fb][0][3]), bf_pack(acc[fb][1][2], acc[fb][1][3]), false, false);
+                const int c16 = w4 * 4 + (q4 & 1) * 2 + (q4 >> 1);
+                *reinterpret_cast<u32x4*>(smem + RB_O + q * 256 + ((c16 ^ RB_SWZ(q)) << 4)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
         RB_STAMP(0)
