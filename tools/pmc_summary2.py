@@ -16,7 +16,7 @@ import json
 import re
 import sys
 
-PAT = re.compile(r"(gemm_pw2_kernel<\d, (?:true|false)>|gemm_pw_kernel|gemm_kernel|rn_block128_kernel<\w+>|rn_sinc_kernel|res2net_chain_kernel|"
+PAT = re.compile(r"(gemm_pw2_kernel<\d, \d>|gemm_pw_kernel|rn_tail_kernel|gemm_kernel|rn_block128_kernel<\w+>|rn_sinc_kernel|res2net_chain_kernel|"
                  r"se_apply_kernel|asp_fused_kernel|fbank_kernel|rn_afms_apply_kernel|rn_maxpool3_kernel|se_mlp_kernel|rowvec_linear_kernel|"
                  r"colsum\w*_kernel|colstats_kernel|rn_afms_gate_kernel|rn_block_kernel|prologue\w*_kernel|pair_kernel<\d>|topk_stats\w*|l2norm_kernel)")
 
@@ -29,7 +29,7 @@ def key(row):
     if not m:
         return None
     k = m.group(1)
-    if k.startswith("gemm_pw2_kernel<2, false>"):
+    if k.startswith("gemm_pw2_kernel<2, 0>"):
         k += " grid=" + row["Grid_Size"]          # the K = 1024 layers and mfa are the same instance
     return k
 
