@@ -136,3 +136,22 @@ def test_fused_tail_fp32_matches_separate_passes(L, B, monkeypatch):
         assert ("rn_tail" in labels) == (not unfused), labels
     scale = float(np.abs(outs[0]).max())
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("L", [16001, 20003])
+def test_bf16_sample_counts_that_are_not_a_multiple_of_8(L):
+    """The bf16 sinc kernel stages its operand by LDS-DMA from the pre-normalised bf16 waveform (two zero-tailed copies one sample
+    apart); utterance lengths that are not a multiple of 8 take the scalar branch of the pass that writes them."""
+    B = 3
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=9)
+    wav = synth.synth_waveforms(B, L, seed=10)
+    outs = {}
+    for compute in ("f32", "bf16"):
+        eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[compute] = eng.embed_wave(wav).reshape(B, -1)
+        eng.close()
+    a, b = outs["f32"], outs["bf16"]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.isfinite(b).all() and cos.min() >= 0.99, cos
