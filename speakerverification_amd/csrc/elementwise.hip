@@ -215,8 +215,9 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 // coalesced along C in 16-byte loads (the kernel is bound by how many of those each lane keeps in flight:
 // 1 MB of fp32 weights per workgroup out of L2).  With `part` the squeeze (mean over frames) is taken straight
 // from the column-sum partials of the pw2 GEMM epilogue (layout: colsum_finalize_kernel above).
+constexpr int SE_MLP_THREADS = 1024;      // 16 waves: the two matrix-vector products are chains of L2 round trips (256 threads: 33 us)
 template <typename WT>
-__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ part, int T,
+__global__ __launch_bounds__(SE_MLP_THREADS) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ part, int T,
                                                      const WT* __restrict__ W1, const float* __restrict__ b1,
                                                      const WT* __restrict__ W2T, const float* __restrict__ b2,
                                                      float* __restrict__ s, int B, int C, int H) {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
         const int r0 = b * T, r1 = r0 + T - 1;
         const float inv = 1.0f / (float)T;
-        for (int ch = threadIdx.x; ch < nch4; ch += 256) {
+        for (int ch = threadIdx.x; ch < nch4; ch += SE_MLP_THREADS) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int tm0 = r0 / 256; tm0 <= r1 / 256; tm0 += 3) {       // three tiles' 24 loads in flight (see colsum_finalize_kernel)
                 f32x4 ps[3][8];
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         }
     } else {
         const f32x4* m4 = reinterpret_cast<const f32x4*>(mean + (int64_t)b * C);
-        for (int ch = threadIdx.x; ch < nch4; ch += 256) xm4[ch] = m4[ch];
+        for (int ch = threadIdx.x; ch < nch4; ch += SE_MLP_THREADS) xm4[ch] = m4[ch];
     }
     __syncthreads();
     const Vec16<WT>* W1v = reinterpret_cast<const Vec16<WT>*>(W1);
-    for (int n0 = wave * 4; n0 < H; n0 += 16) {                 // 4 hidden units per wave per pass
+    for (int n0 = wave * 4; n0 < H; n0 += SE_MLP_THREADS / 16) {      // 4 hidden units per wave per pass
         float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int ch = lane; ch < nch; ch += 64) {
@@ -279,20 +280,33 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ m
         }
     }
     __syncthreads();
+    // second product: thread = (16-byte chunk of output channels, slice of the hidden units); partial dot products meet in LDS
+    // (one thread per chunk walking all H hidden units left 7 of 8 waves idle behind a chain of H / 2 dependent L2 round trips)
     const Vec16<WT>* W2v = reinterpret_cast<const Vec16<WT>*>(W2T);
-    for (int ch = threadIdx.x; ch < nch; ch += 256) {           // VEC output channels per thread: dot over H
-        float a0[VEC], a1[VEC];
+    float* psum = hid + H;                                      // [slices][C]
+    const int slices = SE_MLP_THREADS / nch > 0 ? min(SE_MLP_THREADS / nch, H) : 1;
+    const int per = (H + slices - 1) / slices;
+    for (int w = threadIdx.x; w < nch * slices; w += SE_MLP_THREADS) {
+        const int ch = w % nch, sl = w / nch;
+        float a0[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { a0[e] = b2[ch * VEC + e]; a1[e] = 0.f; }
+        for (int e = 0; e < VEC; ++e) a0[e] = 0.f;
+        const int n1 = min(H, (sl + 1) * per);
 #pragma unroll 8
-        for (int n = 0; n < H; n += 2) {
-            const Vec16<WT> w0 = W2v[(int64_t)n * nch + ch], w1 = W2v[(int64_t)(n + 1) * nch + ch];
-            const float h0 = hid[n], h1 = hid[n + 1];
+        for (int n = sl * per; n < n1; ++n) {
+            const Vec16<WT> w0 = W2v[(int64_t)n * nch + ch];
+            const float h0 = hid[n];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { a0[e] = fmaf(w0.get(e), h0, a0[e]); a1[e] = fmaf(w1.get(e), h1, a1[e]); }
+            for (int e = 0; e < VEC; ++e) a0[e] = fmaf(w0.get(e), h0, a0[e]);
         }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s[(int64_t)b * C + ch * VEC + e] = 1.0f / (1.0f + expf(-(a0[e] + a1[e])));
+        for (int e = 0; e < VEC; ++e) psum[sl * C + ch * VEC + e] = a0[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += SE_MLP_THREADS) {
+        float a = b2[c];
+        for (int sl = 0; sl < slices; ++sl) a += psum[sl * C + c];
+        s[(int64_t)b * C + c] = 1.0f / (1.0f + expf(-a));
     }
 }
 
@@ -510,10 +524,12 @@ hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool wit
 
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
                          const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream) {
-    const size_t lds = (size_t)(C + H) * sizeof(float);
+    const int vec = w_bf16 ? 8 : 4;
+    const int slices = std::max(1, std::min(SE_MLP_THREADS / std::max(1, C / vec), H));
+    const size_t lds = (size_t)(C + H + (size_t)slices * C) * sizeof(float);
     if (lds > 64 * 1024 || B <= 0 || H % 16 != 0 || C % 8 != 0 || (!mean && !part)) return hipErrorInvalidValue;
-    if (w_bf16) hipLaunchKernelGGL(se_mlp_kernel<bf16_t>, dim3(B), dim3(256), lds, stream, mean, part, T, (const bf16_t*)W1, b1, (const bf16_t*)W2T, b2, s, B, C, H);
-    else hipLaunchKernelGGL(se_mlp_kernel<float>, dim3(B), dim3(256), lds, stream, mean, part, T, (const float*)W1, b1, (const float*)W2T, b2, s, B, C, H);
+    if (w_bf16) hipLaunchKernelGGL(se_mlp_kernel<bf16_t>, dim3(B), dim3(SE_MLP_THREADS), lds, stream, mean, part, T, (const bf16_t*)W1, b1, (const bf16_t*)W2T, b2, s, B, C, H);
+    else hipLaunchKernelGGL(se_mlp_kernel<float>, dim3(B), dim3(SE_MLP_THREADS), lds, stream, mean, part, T, (const float*)W1, b1, (const float*)W2T, b2, s, B, C, H);
     return hipGetLastError();
 }
 
