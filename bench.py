@@ -354,6 +354,53 @@ def multi_stream_bench(model, compute, B, local, dev, wavs, n_streams=3, steps=3
     return {"value": steps * B / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3, "streams": n_streams, "steps": steps, "finite": ok}
 
 
+def fusion_bench(B, local, dev, wavs, steps=20):
+    """the reference's production model Raw_ECAPA_sinc_asp — ECAPA-TDNN C = 512 (192-d, mel power without log,
+    `features: raw`) and RawNet2 (320-d) on the SAME device-resident waveform batch, concatenated to 512-d.  `serial`: both
+    engines on one stream; `two_streams`: one stream per branch (RawNet2's small late kernels run beside ECAPA's GEMMs)."""
+    import torch
+    from speakerverification_amd import synth
+    from speakerverification_amd.engine import Engine
+    res = {}
+    for name, nst in (("serial", 1), ("two_streams", 2)):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nst)]
+        with torch.cuda.stream(streams[0]):
+            ee = Engine(model="ecapa", compute="bf16", channels=512, embed_dim=192, max_batch=B, samples=SAMPLES, log_input=False,
+                        device=local, stream=streams[0].cuda_stream)
+            ee.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=1))
+            ee.finalize()
+        with torch.cuda.stream(streams[-1]):
+            er = Engine(model="rawnet2", compute="bf16", embed_dim=320, max_batch=B, samples=SAMPLES, device=local, stream=streams[-1].cuda_stream)
+            er.load_state_dict(synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1))
+            er.finalize()
+        out = torch.empty((B, 512), device=dev, dtype=torch.float32)
+        oe, orn = torch.empty((B, 192), device=dev, dtype=torch.float32), torch.empty((B, 320), device=dev, dtype=torch.float32)
+        dt = None
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                w = wavs[k % len(wavs)]
+                with torch.cuda.stream(streams[0]):
+                    ee.embed_wave(w, out=oe, async_=True)
+                with torch.cuda.stream(streams[-1]):
+                    er.embed_wave(w, out=orn, async_=True)
+                if nst == 2:
+                    streams[0].wait_stream(streams[1])
+                with torch.cuda.stream(streams[0]):
+                    out[:, :192].copy_(oe, non_blocking=True)          # torch.cat([out1, out2], dim=-1)  (Raw_ECAPA_sinc_asp.py:50)
+                    out[:, 192:].copy_(orn, non_blocking=True)
+                if nst == 2:
+                    streams[1].wait_stream(streams[0])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        res[name] = {"value": steps * B / dt, "unit": "embeddings/s", "ms_per_step": dt / steps * 1e3, "finite": bool(torch.isfinite(out).all().item())}
+        ee.close()
+        er.close()
+    res["config"] = {"model": "Raw_ECAPA_sinc_asp (ECAPA-TDNN C=512 -> 192-d on mel power, RawNet2 sinc/asp -> 320-d)", "batch": B, "dtype": "bf16"}
+    return res
+
+
 def pcie_bench(eng, dev, B):
     """PCIe-inclusive rate: decoded 16-bit PCM on the host -> int16 over PCIe -> device crop (svhip_crop_pcm16) -> embed.
     (Never `value`: BASELINE's metric is quoted on HBM-resident waveforms.)  Two forms: `serial` = one synchronous crop call per
@@ -680,6 +727,7 @@ def run_batch(args, ranks, dev):
                              ("rawnet2_3_streams", lambda: multi_stream_bench("rawnet2", "bf16", B, local, dev, wavs)),
                              ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
                              ("ecapa_f32x3", lambda: sub_bench("ecapa", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
+                             ("fusion", lambda: fusion_bench(B, local, dev, wavs)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:
                     line[name] = fn()

@@ -101,12 +101,12 @@ class Engine:
         self.h = h
         self._stream = int(stream) if stream else None
 
-    def _order_after_torch(self, *bufs, async_=False):
+    def _order_after_torch(self, *bufs, async_=False, ordered=False):
         """Device tensors handed in by torch may still be in flight on torch's current stream.  When the
         handle runs on that same stream the order is already right; otherwise wait for torch's stream
         on the host before the library touches the data (and refuse async calls, which would race)."""
-        if torch is None or not any(b.device for b in bufs):
-            return
+        if ordered or torch is None or not any(b.device for b in bufs):
+            return                                  # (ordered: the caller has already waited for torch's stream)
         cur = torch.cuda.current_stream(self.device)
         if self._stream is not None and cur.cuda_stream == self._stream:
             return
@@ -202,12 +202,14 @@ class Engine:
         self._ck(self.lib.svhip_embed_features(self.h, i.ptr, B, T, o.ptr, self._flags(i, o, async_)))
         return out
 
-    def embed_wave(self, wav, out=None, async_=False):
+    def embed_wave(self, wav, out=None, async_=False, ordered=False):
+        """``ordered=True``: the caller guarantees that the device buffers are complete and stay alive (it has synchronised
+        torch's stream and will call synchronize() on this handle): lets an async call run on the handle's OWN stream."""
         B, L = wav.shape
         if out is None:
             out = self._out(wav, (B, self.embed_dim))
         i, o = _Buf(wav, np.float32), _Buf(out, np.float32, writable=True)
-        self._order_after_torch(i, o, async_=async_)
+        self._order_after_torch(i, o, async_=async_, ordered=ordered)
         _count([i], [o])
         self._ck(self.lib.svhip_embed_wave(self.h, i.ptr, B, L, o.ptr, self._flags(i, o, async_)))
         return out

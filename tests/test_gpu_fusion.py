@@ -59,3 +59,20 @@ def test_fusion_blob_and_whole_file_engine_cache(tmp_path):
         assert len(m._engines) <= m.ENGINE_CACHE
     e1 = m.embed_wave(synth.synth_waveforms(8, 32000, seed=1))
     assert m._engine is primary and np.array_equal(e0, e1)              # the fixed-length handle survived and was not rebuilt
+
+
+def test_fusion_device_batch_runs_both_branches_concurrently():
+    """A CUDA-tensor batch takes the two-stream path of Raw_ECAPA.forward (each branch on its handle's own stream): same
+    numbers as the host path, bit for bit (same kernels, same order inside each branch)."""
+    import torch
+    m = Raw_ECAPA_sinc_asp.MainModel(nOut=512, embed_batch=8, **KW)
+    sd = {"ECAPA_TDNN." + k: v for k, v in synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=1).items()}
+    sd.update({"rawnet2v2." + k: v for k, v in synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1).items()})
+    m.load_state_dict(sd)
+    x = synth.synth_waveforms(5, 32000, seed=3)
+    host = m(x)
+    dev = m(torch.from_numpy(x).cuda())
+    assert dev.is_cuda and tuple(dev.shape) == (5, 512)
+    assert np.array_equal(dev.cpu().numpy(), host)
+    big = m(torch.from_numpy(synth.synth_waveforms(11, 32000, seed=4)).cuda())        # more rows than embed_batch: chunked path
+    assert tuple(big.shape) == (11, 512) and bool(torch.isfinite(big).all())
