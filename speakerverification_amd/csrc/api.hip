@@ -993,7 +993,9 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         svhip_handle::RnBlock& Kp = h->rn_blocks[first - 1];
         const float* nsc = first < 8 ? h->rn_blocks[first].bn1_scale : h->rn_agg_scale;
         const float* nsh = first < 8 ? h->rn_blocks[first].bn1_shift : h->rn_agg_shift;
-        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, x, bf, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
+        // x itself is read only as an identity shortcut (or as a debug stage): not written when the next block projects its input
+        void* xdst = (first < 8 && h->rn_blocks[first].has_shortcut && stop_after < 0) ? nullptr : x;
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, xdst, bf, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = Kp.cout;
     }
     for (int bi = first; bi < 8; ++bi) {
@@ -1021,13 +1023,15 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
         void* npre = stop_after >= 0 ? nullptr : pre;           // (the developer hook keeps the unfused sequence)
+        // the block output itself is read only by an identity shortcut of the next block (or as a debug stage)
+        const bool x_dead = stop_after < 0 && npre && (bi == 7 || h->rn_blocks[bi + 1].has_shortcut);
         const int Tn = K.downsample ? T / 3 : T;
         if (!no_tail && rn_tail_supported(bf, Tn, K.cout)) {
             // max-pool + AFMS + next pre-activation in one launch, the pooled activation held in registers      :228-229, :62-68
             char tl[48] = "rn_tail";
             if (h->layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
             if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
-                     return launch_rn_tail(o, xn, npre, bf, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
+                     return launch_rn_tail(o, x_dead ? nullptr : xn, npre, bf, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
                  }))) return rc;
             T = Tn;
         } else {
@@ -1042,7 +1046,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
             if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
                      return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
                  }))) return rc;
-            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, x_dead ? nullptr : xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
         }
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;

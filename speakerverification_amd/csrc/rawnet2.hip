@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict_
         Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + id * VEC), o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.set(j, (v.get(j) + alpha[c + j]) * s[b * C + c + j]);
-        *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;
+        if (y) *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;          // (null: the next block has a projection shortcut and never reads x)
         if (pre) {
             Vec16<T> q;
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
         al[j] = alpha[c + j]; g[j] = gate[c + j];
         ns[j] = pre ? nscale[c + j] : 0.0f; nh[j] = pre ? nshift[c + j] : 0.0f;
     }
-    T* yb = y + b * Tn * (int64_t)C + c;
+    T* yb = y ? y + b * Tn * (int64_t)C + c : nullptr;     // (null: nothing reads the block output itself, only its pre-activation)
     T* pb = pre ? pre + b * Tn * (int64_t)C + c : nullptr;
 #pragma unroll
     for (int i = 0; i < TAIL_NCH; ++i) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
             Vec16<T> o, q;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.set(j, (held[i].get(j) + al[j]) * g[j]);
-            *reinterpret_cast<Vec16<T>*>(yb + (int64_t)t * C) = o;
+            if (yb) *reinterpret_cast<Vec16<T>*>(yb + (int64_t)t * C) = o;
             if (pb) {                                  // from the value as stored (rounded to T), like rn_afms_apply
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
@@ -606,7 +606,7 @@ bool rn_tail_supported(bool bf16, int Tn, int C) {
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, bool bf16, bool pool, const float* alpha, const float* WT, const float* bias,
                           const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream) {
     const int Tn = pool ? Tin / 3 : Tin;
-    if (!x || !y || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(bf16, Tn, C) || (pre && (!next_scale || !next_shift)))
+    if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(bf16, Tn, C) || (pre && (!next_scale || !next_shift)))
         return hipErrorInvalidValue;
 #define SV_TAIL(TT, P) hipLaunchKernelGGL((rn_tail_kernel<TT, P>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
                                           alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope)
