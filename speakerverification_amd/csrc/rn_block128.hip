@@ -67,6 +67,7 @@ __device__ __forceinline__ float lrelu03(float t) { return fmaxf(t, 0.3f * t); }
 // consecutive rows x two adjacent k chunks) for EVERY tap shift of the rows; r & 15 is not (2-way on the odd tap).  The 8-byte
 // accumulator-layout accesses and the row-per-16-lanes elementwise passes are 2-way under any such map; they are 1/6 of the traffic.
 #define RB_SWZ(r) (((r) & 7) << 1)
+template <int N> struct RbInt { static constexpr int value = N; };
 
 // two bf16 in one dword: unpack to fp32 (exact), pack with round-to-nearest-even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
@@ -307,59 +308,65 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
         lds_barrier();                                            // H[r & 1], O and the landed rows are visible; P[r & 1] is no longer read
         RB_STAMP(1)
         // ============================================== vector phase ==============================================
-        if (grp == 0) {
-            if (r + 1 < n_mine && !(p.debug & 4)) {
-                const int k = r + 1, item = first + k;
-                const int b = item / p.ntiles, t0 = (item - b * p.ntiles) * RB_TT;
-                const int c16 = opaque(c16_), rg = opaque(rg_);
-                f32x4 sc1[2], sh1[2], al[2], gt[2];
+        // y = (xin + alpha) * gate (rounded to bf16, as a stored tensor would be), pre = lrelu(bn1(y)), in place: the thread owns
+        // data chunk c16 of rows row0 + rg + 16 i, i < NI.  Branch-free: a per-element `valid ? f(x) : 0` compiles to eight
+        // exec-mask branches with an LDS wait each.  Group A converts rows 0..63, group B (whose pooling is half as long) the
+        // rest: with all 82 rows on group A its waves were the vector phase's critical path (3.2 k of 9.9 k cycles per round
+        // while group B waited 1.7 k at the barrier).
+        auto convert = [&](auto ni_tag, int row0) {
+            constexpr int NI = decltype(ni_tag)::value;
+            const int k = r + 1, item = first + k;
+            const int b = item / p.ntiles, t0 = (item - b * p.ntiles) * RB_TT;
+            (void)b;
+            const int c16 = opaque(c16_), rg = opaque(rg_);
+            f32x4 sc1[2], sh1[2], al[2], gt[2];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    sc1[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (0 * 128 + 8 * c16 + 4 * hf) * 4);
-                    sh1[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (1 * 128 + 8 * c16 + 4 * hf) * 4);
+            for (int hf = 0; hf < 2; ++hf) {
+                sc1[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (0 * 128 + 8 * c16 + 4 * hf) * 4);
+                sh1[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (1 * 128 + 8 * c16 + 4 * hf) * 4);
+                if (GATE) {
+                    al[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (2 * 128 + 8 * c16 + 4 * hf) * 4);
+                    gt[hf] = *reinterpret_cast<const f32x4*>(smem + RB_GATE + (k & 1) * 1024 + (8 * c16 + 4 * hf) * 4);
+                }
+            }
+            char* pbuf = smem + RB_P + (k & 1) * RB_RAWK * 1024;
+            char* ybuf = smem + RB_Y + (k & 1) * RB_YR * 256;
+            u32x4 xin[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = min(row0 + rg + 16 * i, RB_PR - 1);
+                xin[i] = *reinterpret_cast<const u32x4*>(pbuf + row * 256 + ((c16 ^ RB_SWZ(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row0 + rg + 16 * i;
+                const int f = t0 - 2 + row;
+                const uint32_t vmask = (f >= 0 && f < p.T) ? 0xffffffffu : 0u;        // conv1's zero padding applies to `pre`
+                u32x4 y4, pre4;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float a = bf_lo(xin[i][w]), c = bf_hi(xin[i][w]);
+                    uint32_t yw = xin[i][w];
                     if (GATE) {
-                        al[hf] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (2 * 128 + 8 * c16 + 4 * hf) * 4);
-                        gt[hf] = *reinterpret_cast<const f32x4*>(smem + RB_GATE + (k & 1) * 1024 + (8 * c16 + 4 * hf) * 4);
+                        yw = bf_pack((a + al[w >> 1][(2 * w) & 3]) * gt[w >> 1][(2 * w) & 3], (c + al[w >> 1][(2 * w + 1) & 3]) * gt[w >> 1][(2 * w + 1) & 3]);
+                        a = bf_lo(yw); c = bf_hi(yw);
                     }
+                    y4[w] = yw;
+                    pre4[w] = bf_pack(lrelu03(fmaf(a, sc1[w >> 1][(2 * w) & 3], sh1[w >> 1][(2 * w) & 3])),
+                                      lrelu03(fmaf(c, sc1[w >> 1][(2 * w + 1) & 3], sh1[w >> 1][(2 * w + 1) & 3]))) & vmask;
                 }
-                char* pbuf = smem + RB_P + (k & 1) * RB_RAWK * 1024;
-                char* ybuf = smem + RB_Y + (k & 1) * RB_YR * 256;
-                // y = (xin + alpha) * gate (rounded to bf16, as a stored tensor would be), pre = lrelu(bn1(y)), in place: the thread
-                // owns data chunk c16 of its rows.  Branch-free: a per-element `valid ? f(x) : 0` compiles to eight exec-mask
-                // branches with an LDS wait each
-                u32x4 xin[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int row = min(rg + 16 * i, RB_PR - 1);
-                    xin[i] = *reinterpret_cast<const u32x4*>(pbuf + row * 256 + ((c16 ^ RB_SWZ(row)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int row = rg + 16 * i;
-                    const int f = t0 - 2 + row;
-                    const uint32_t vmask = (f >= 0 && f < p.T) ? 0xffffffffu : 0u;        // conv1's zero padding applies to `pre`
-                    u32x4 y4, pre4;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        float a = bf_lo(xin[i][w]), c = bf_hi(xin[i][w]);
-                        uint32_t yw = xin[i][w];
-                        if (GATE) {
-                            yw = bf_pack((a + al[w >> 1][(2 * w) & 3]) * gt[w >> 1][(2 * w) & 3], (c + al[w >> 1][(2 * w + 1) & 3]) * gt[w >> 1][(2 * w + 1) & 3]);
-                            a = bf_lo(yw); c = bf_hi(yw);
-                        }
-                        y4[w] = yw;
-                        pre4[w] = bf_pack(lrelu03(fmaf(a, sc1[w >> 1][(2 * w) & 3], sh1[w >> 1][(2 * w) & 3])),
-                                          lrelu03(fmaf(c, sc1[w >> 1][(2 * w + 1) & 3], sh1[w >> 1][(2 * w + 1) & 3]))) & vmask;
-                    }
-                    if (row < RB_PR) {
-                        *reinterpret_cast<u32x4*>(pbuf + row * 256 + ((c16 ^ RB_SWZ(row)) << 4)) = pre4;
-                        if (row >= 2) {
-                            const int yr = row - 2;
-                            *reinterpret_cast<u32x4*>(ybuf + yr * 256 + ((c16 ^ RB_SWZ(yr)) << 4)) = y4;
-                        }
+                if (row < RB_PR) {
+                    *reinterpret_cast<u32x4*>(pbuf + row * 256 + ((c16 ^ RB_SWZ(row)) << 4)) = pre4;
+                    if (row >= 2) {
+                        const int yr = row - 2;
+                        *reinterpret_cast<u32x4*>(ybuf + yr * 256 + ((c16 ^ RB_SWZ(yr)) << 4)) = y4;
                     }
                 }
             }
+        };
+        const bool conv_next = r + 1 < n_mine && !(p.debug & 4);
+        if (grp == 0) {
+            if (conv_next) convert(RbInt<4>{}, 0);
             if (r + 2 < n_mine) issue_dma(r + 2);                 // into P[r & 1], which conv1(r) has finished with; converted next round
         } else if (r >= 1 && !(p.debug & 8)) {
             // max_pool1d(3) of O -> global, and this wave's column sums of the pooled rows
@@ -396,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
                 if (ok) *reinterpret_cast<u32x4*>(p.opool + ((int64_t)b * p.Tout + tp) * 128 + 8 * c16) = m;
             }
         }
+        if (grp == 1 && conv_next) convert(RbInt<2>{}, 64);       // rows 64 .. RB_PR - 1 of the next item
         RB_STAMP(2)
         lds_barrier();                                            // P[(r + 1) & 1] (converted) and Y are complete; O is no longer read
         RB_STAMP(3)
