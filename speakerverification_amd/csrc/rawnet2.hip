@@ -258,13 +258,19 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
         if (BF) {
+            const char* base[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
-                const char* base = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + fh) * 16;
+                base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + fh) * 16;
+            }
+            // K step outermost: six independent accumulators in flight (with the pool partner j outermost, consecutive MFMAs on the
+            // same accumulator were two issues apart — a dependent 32x32x16 needs the previous result)
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + kk * 32);
+            for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base[j] + kk * 32);
                     acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[0][kk], xf, acc[0][j], 0, 0, 0);
                     acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[1][kk], xf, acc[1][j], 0, 0, 0);
                 }
