@@ -249,10 +249,15 @@ def make_engine(model, compute, B, local, embed=None):
     return eng
 
 
-def dominant_label(model, compute):
+def dominant_label(model, compute, B=256):
     if model == "rawnet2":
         return "rn_block128"              # the fused 128-channel residual blocks: 41 % of the model's FLOPs in two launches
-    return "gemm_pw2" if compute == "bf16" else "gemm_pw"       # f32 / f32x3: the LDS-DMA kernel on fp32 operands
+    if compute != "bf16":
+        return "gemm_pw"                  # f32 / f32x3: the LDS-DMA kernel on fp32 operands
+    # tdnn1 / tdnn2 / mfa: the persistent 256 x 256 kernel once a layer has more tiles than the chip has CUs (gemm_route), else
+    # the per-tile one
+    tiles = -(-B * 401 // 256) * (CHANNELS // 256)
+    return "gemm_pw3" if tiles > 256 and CHANNELS % 256 == 0 else "gemm_pw2"
 
 
 def roofline_of(prof, label, compute):
@@ -309,7 +314,7 @@ def sub_bench(model, compute, B, local, dev, wavs, steps=10, warmup=2):
     """a smaller record of the same shape for the other configurations (rawnet2 = configs[2]; ecapa f32 = the 1e-4-parity path)"""
     import torch
     eng = make_engine(model, compute, B, local)
-    label = dominant_label(model, compute)
+    label = dominant_label(model, compute, B)
     shard = torch.empty((steps * B, eng.embed_dim), device=dev, dtype=torch.float32)
     t0 = embed_loop(eng, wavs, steps, warmup, B, shard, label)
     torch.cuda.synchronize()
@@ -662,7 +667,7 @@ def run_batch(args, ranks, dev):
     from speakerverification_amd import distributed as sv_dist
     B, K, W = args.batch, args.steps, args.warmup
     rank, world, local = ranks.rank, ranks.world, ranks.local
-    label = dominant_label(args.model, args.compute)
+    label = dominant_label(args.model, args.compute, args.batch)
     eng = make_engine(args.model, args.compute, B, local)
     embed = eng.embed_dim
     comm, carrier = make_comm(eng, ranks)
@@ -746,7 +751,7 @@ def run_shard(args, ranks, dev):
     B = args.batch
     rank, world, local = ranks.rank, ranks.world, ranks.local
     n_local = args.utts_per_gpu
-    label = dominant_label(args.model, args.compute)
+    label = dominant_label(args.model, args.compute, args.batch)
     eng = make_engine(args.model, args.compute, B, local)
     comm, carrier = make_comm(eng, ranks)
     shard = torch.empty((n_local, eng.embed_dim), device=dev, dtype=torch.float32)

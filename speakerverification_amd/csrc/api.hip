@@ -110,10 +110,11 @@ struct svhip_handle {
     float* d_wav = nullptr;       // (Bmax, L)
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
-    float* d_zero = nullptr;
+    float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
     float* d_colsum = nullptr;    // pw2 column-sum partials, per lane: [sum | sumsq] x (tiles*4) x 3C floats
     int64_t colsum_region = 0;    // floats per (lane, kind) region
-    bool last_colsum_done = false;      // 256 zero bytes (DMA source for padded conv chunks)
+    bool last_colsum_done = false;
+    int last_colsum_groups = 8;   // row groups per tile in the partials the last GEMM wrote (8: pw2, 2: pw3)
     void* X_in = nullptr;         // (M, n_mels)
     void* X0 = nullptr;           // (M, C)
     void *H1 = nullptr, *H2 = nullptr, *H3 = nullptr;   // (M, C)
@@ -759,14 +760,14 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     }
     hipStream_t st = h->cur;
     (void)label;
-    if (p.colsum) {                       // only the pw2 epilogue produces the partials; otherwise the caller falls back
-        if (gemm_pw2_supported(p, bf) && p.taps == 1) h->last_colsum_done = true;
+    p.num_cu = h->num_cu;
+    if (p.colsum) {                       // only the pw2 / pw3 epilogues produce the partials; otherwise the caller falls back
+        if (gemm_pw2_supported(p, bf) && p.taps == 1) { h->last_colsum_done = true; h->last_colsum_groups = gemm_colsum_groups(p, bf); }
         else p.colsum = nullptr;
     }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
-    p.num_cu = h->num_cu;
     const GemmRoute route = gemm_route(p, bf);
-    const char* klabel = route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
+    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
                          : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
     if (h->layer_labels) {                // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
@@ -848,7 +849,8 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         if ((rc = run(h, "se_mlp", 4.0 * B * 128 * C, [&]() {
                  return launch_se_mlp(from_part ? nullptr : d_mean, from_part ? cs_base : nullptr, T,
                                       bf ? (const void*)h->se1_bf[i] : (const void*)h->se1[i].W, h->se1[i].bias,
-                                      bf ? (const void*)h->se2T_bf[i] : (const void*)h->se2T[i], h->se2[i].bias, d_s2, bf, B, C, 128, st);
+                                      bf ? (const void*)h->se2T_bf[i] : (const void*)h->se2T[i], h->se2[i].bias, d_s2, bf, B, C, 128, st,
+                                      h->last_colsum_groups);
              }))) return rc;
         void* xout = off(CAT, (size_t)i * C, e);
         if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))
@@ -859,7 +861,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
                         PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region))) return rc;
     if (h->last_colsum_done) {
-        if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, true, B, T, C3, M, d_gstats, 1e-12f, st); }))) return rc;
+        if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, true, B, T, C3, M, d_gstats, 1e-12f, st, h->last_colsum_groups); }))) return rc;
     } else {
         if ((rc = run(h, "asp_gstats", 0, [&]() { return launch_colstats(MFA, bf, C3, B, T, C3, d_gstats, 1e-12f, st); }))) return rc;
     }

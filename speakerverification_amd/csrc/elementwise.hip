@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const float* __restr
 }
 
 // ---- finalize the column-sum partials written by the pw2 GEMM epilogue --------------------------------------
-// part[((tm*8 + rg)*2 + seg)*C + c]: utterance b owns segment seg = b - (tm*256)/T of tile tm.
+// part[((tm*RG + rg)*2 + seg)*C + c]: utterance b owns segment seg = b - (tm*256)/T of tile tm; RG row groups per tile
+// (8 x 32 rows from gemm_pw2's LDS image, 2 x 128 rows from gemm_pw3's accumulators).
+template <int RG>
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int64_t sq_stride, int with_std,
                                                               int T, int C, int M, float* __restrict__ out, float eps) {
     const int b = blockIdx.y;
@@ -181,15 +183,15 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     // an utterance of T >= 256 frames touches at most T / 256 + 2 tiles; three at a time so that their 24 (48) loads are all
     // in flight (a runtime-bounded loop exposed one round trip per tile and made this tiny kernel 40 us)
     for (int tm0 = r0 / 256; tm0 <= r1 / 256; tm0 += 3) {
-        float ps[3][8], pq[3][8];
+        float ps[3][RG], pq[3][RG];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int tm = tm0 + u;
             const int seg = b - (tm * 256) / T;
             const bool ok = tm <= r1 / 256 && seg >= 0 && seg <= 1;
 #pragma unroll
-            for (int rg = 0; rg < 8; ++rg) {
-                const int64_t o = ((int64_t)(tm * 8 + rg) * 2 + (ok ? seg : 0)) * C + c;
+            for (int rg = 0; rg < RG; ++rg) {
+                const int64_t o = ((int64_t)(tm * RG + rg) * 2 + (ok ? seg : 0)) * C + c;
                 ps[u][rg] = ok ? part[o] : 0.f;
                 pq[u][rg] = (ok && with_std) ? part[sq_stride + o] : 0.f;
             }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int rg = 0; rg < 8; ++rg) { s += ps[u][rg]; q += pq[u][rg]; }
+            for (int rg = 0; rg < RG; ++rg) { s += ps[u][rg]; q += pq[u][rg]; }
     }
     const float mean = s / (float)T;
     if (with_std) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 // 1 MB of fp32 weights per workgroup out of L2).  With `part` the squeeze (mean over frames) is taken straight
 // from the column-sum partials of the pw2 GEMM epilogue (layout: colsum_finalize_kernel above).
 constexpr int SE_MLP_THREADS = 1024;      // 16 waves: the two matrix-vector products are chains of L2 round trips (256 threads: 33 us)
-template <typename WT>
+template <typename WT, int RG>
 __global__ __launch_bounds__(SE_MLP_THREADS) void se_mlp_kernel(const float* __restrict__ mean, const float* __restrict__ part, int T,
                                                      const WT* __restrict__ W1, const float* __restrict__ b1,
                                                      const WT* __restrict__ W2T, const float* __restrict__ b2,
@@ -236,20 +238,20 @@ __global__ __launch_bounds__(SE_MLP_THREADS) void se_mlp_kernel(const float* __r
         for (int ch = threadIdx.x; ch < nch4; ch += SE_MLP_THREADS) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int tm0 = r0 / 256; tm0 <= r1 / 256; tm0 += 3) {       // three tiles' 24 loads in flight (see colsum_finalize_kernel)
-                f32x4 ps[3][8];
+                f32x4 ps[3][RG];
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const int tm = tm0 + u;
                     const int seg = b - (tm * 256) / T;
                     const bool ok = tm <= r1 / 256 && seg >= 0 && seg <= 1;
 #pragma unroll
-                    for (int rg = 0; rg < 8; ++rg)
-                        ps[u][rg] = ok ? p4[((int64_t)(tm * 8 + rg) * 2 + seg) * nch4 + ch] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int rg = 0; rg < RG; ++rg)
+                        ps[u][rg] = ok ? p4[((int64_t)(tm * RG + rg) * 2 + seg) * nch4 + ch] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
 #pragma unroll
-                    for (int rg = 0; rg < 8; ++rg) acc += ps[u][rg];
+                    for (int rg = 0; rg < RG; ++rg) acc += ps[u][rg];
             }
             xm4[ch] = acc * inv;
         }
@@ -517,19 +519,25 @@ hipError_t launch_crop_pcm16(const int16_t* pcm, const int64_t* off, const int32
 }
 
 hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
-                                  float* out, float eps, hipStream_t stream) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, part, sq_stride, with_std ? 1 : 0, T, C, M, out, eps);
+                                  float* out, float eps, hipStream_t stream, int row_groups) {
+    if (row_groups != 8 && row_groups != 2) return hipErrorInvalidValue;
+    const dim3 grid((C + 255) / 256, B);
+    if (row_groups == 8) hipLaunchKernelGGL(colsum_finalize_kernel<8>, grid, dim3(256), 0, stream, part, sq_stride, with_std ? 1 : 0, T, C, M, out, eps);
+    else hipLaunchKernelGGL(colsum_finalize_kernel<2>, grid, dim3(256), 0, stream, part, sq_stride, with_std ? 1 : 0, T, C, M, out, eps);
     return hipGetLastError();
 }
 
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
-                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream) {
+                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream, int row_groups) {
     const int vec = w_bf16 ? 8 : 4;
+    if (row_groups != 8 && row_groups != 2) return hipErrorInvalidValue;
     const int slices = std::max(1, std::min(SE_MLP_THREADS / std::max(1, C / vec), H));
     const size_t lds = (size_t)(C + H + (size_t)slices * C) * sizeof(float);
     if (lds > 64 * 1024 || B <= 0 || H % 16 != 0 || C % 8 != 0 || (!mean && !part)) return hipErrorInvalidValue;
-    if (w_bf16) hipLaunchKernelGGL(se_mlp_kernel<bf16_t>, dim3(B), dim3(SE_MLP_THREADS), lds, stream, mean, part, T, (const bf16_t*)W1, b1, (const bf16_t*)W2T, b2, s, B, C, H);
-    else hipLaunchKernelGGL(se_mlp_kernel<float>, dim3(B), dim3(SE_MLP_THREADS), lds, stream, mean, part, T, (const float*)W1, b1, (const float*)W2T, b2, s, B, C, H);
+#define SVHIP_SE_MLP(WT, RG) hipLaunchKernelGGL((se_mlp_kernel<WT, RG>), dim3(B), dim3(SE_MLP_THREADS), lds, stream, mean, part, T, (const WT*)W1, b1, (const WT*)W2T, b2, s, B, C, H)
+    if (w_bf16) { if (row_groups == 8) SVHIP_SE_MLP(bf16_t, 8); else SVHIP_SE_MLP(bf16_t, 2); }
+    else { if (row_groups == 8) SVHIP_SE_MLP(float, 8); else SVHIP_SE_MLP(float, 2); }
+#undef SVHIP_SE_MLP
     return hipGetLastError();
 }
 

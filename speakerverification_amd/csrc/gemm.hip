@@ -330,17 +330,23 @@ GemmRoute gemm_route(const GemmParams& p, bool bf16) {
 #ifdef SVHIP_GEMM_DEBUG
     const bool skip_pw2 = (p.debug & 8) != 0;               // tools/gemm_bench: A/B the 256 x 256 kernel against gemm_pw
     const bool no_narrow = (p.debug & 64) != 0;
+    const bool no_pw3 = (p.debug & 4096) != 0;              // A/B the persistent kernel against the per-tile one
 #else
-    const bool skip_pw2 = false, no_narrow = false;
+    const bool skip_pw2 = false, no_narrow = false, no_pw3 = false;
 #endif
     const bool pw = gemm_pw_supported(p, bf16);
     if (!skip_pw2 && gemm_pw2_supported(p, bf16)) {
         const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu) return ROUTE_PW_NARROW;
+        const bool pw3 = !no_pw3 && gemm_pw3_supported(p, bf16);
+        // (a capped persistent grid — the test switch SVHIP_PW3_CUS — also takes the small grids that would go to the narrow tile)
+        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu && !(pw3 && pw3_grid_cap(p.num_cu) < p.num_cu)) return ROUTE_PW_NARROW;
+        if (pw3) return ROUTE_PW3;
         return ROUTE_PW2;
     }
     return pw ? ROUTE_PW : ROUTE_GENERIC;
 }
+
+int gemm_colsum_groups(const GemmParams& p, bool bf16) { return gemm_route(p, bf16) == ROUTE_PW3 ? 2 : 8; }
 
 hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
     // host-side shape contract (checked before any launch: a bad shape must not reach the GPU)
@@ -358,6 +364,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
     if (p.A3 && gemm_route(p, bf16) != ROUTE_PW2) return hipErrorInvalidValue;       // (only the 256 x 256 kernel reads a second K segment)
     switch (gemm_route(p, bf16)) {
         case ROUTE_PW2: return launch_gemm_pw2(p, stream);
+        case ROUTE_PW3: return launch_gemm_pw3(p, stream);
         case ROUTE_PW: return launch_gemm_pw(p, bf16, stream);
         case ROUTE_PW_NARROW: return launch_gemm_pw(p, bf16, stream, true);
         default: break;

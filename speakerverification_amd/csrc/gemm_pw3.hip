@@ -1,0 +1,512 @@
+// gemm_pw3.hip — PERSISTENT bf16 pointwise GEMM, 256 x 256 tile, epilogue straight from the accumulators (gfx950).
+//
+// Same contract and the same four-phase K loop as gemm_pw2.hip (Y = epi(A . W^T), bf16 in / fp32 accumulate / bf16 out; read that
+// file's header for the ring, the swizzle and the one-phase stagger of the two wave groups).  What differs is everything
+// around the K loop, which on the K = 1024 layers of ECAPA-TDNN was a third of a tile's time (DMA prologue 6 %, GELU epilogue +
+// LDS staging 20 %, stores 7 %, gap to the next workgroup 3 %):
+//
+//   * one workgroup per CU walks a list of tiles (round r: tile r * G + band position, so that the 32 CUs of an XCD work on
+//     8 M-tiles x 4 N-tiles at a time and share their X and W lines in that XCD's L2);
+//   * the epilogue never touches the LDS ring: activation / BN affine on the accumulators, bf16 pairs, one v_permlane16_swap per
+//     dword so that a lane owns 16 contiguous bytes, and 16-byte global stores (16 frames x 64 bytes per wave instruction);
+//     the per-utterance column sums (SE squeeze, ASP statistics) are DPP row reductions of the same registers (fp32, unrounded);
+//   * so the DMA stream never stops: in a tile's last two K tiles the phases whose issue slot would be empty fetch the NEXT
+//     tile's first seven half-tiles (K tile count even: the buffer parities simply continue), with the stream's ordinary
+//     vmcnt(10) waits; its 3 KiB of bias / scale / shift go to a double-buffered LDS strip by DMA as well, so no ordinary
+//     global load sits beside the DMAs.  The epilogue runs with five half-tiles in flight and the tile's stores drain under
+//     the next tile's K loop;
+//   * vmcnt bookkeeping: a wave's queue at the next tile's start is [14 operand DMAs][NST stores], in that order (pinned with
+//     sched_barrier), so the first five phases of a tile wait with vmcnt(10 + NST) instead of vmcnt(10) — the counter retires
+//     in order, and a strict count would wait for the store acknowledgements; after a tile with masked rows (a wave may have
+//     issued fewer stores) and on a workgroup's first tile the strict count is used.
+//
+// What it bought (round 3, tools/gemm_bench + stamps, profiles/r03_pw3_*): the prologue, the stores and the inter-workgroup
+// gap are gone from the tile (start wait 1.2 k of 53.5 k cycles), the K loop is unchanged (40.5 k cycles for 32.8 k of MFMA
+// issue), and what remains between two K loops is the GELU itself: 12 - 13 k cycles in which the two waves of a SIMD share one
+// vector pipe (v_pk_* and v_exp / v_rcp cost 8 issue cycles per wave instruction, the rest 4: ~47 cycles per 64 outputs per
+// wave, and the two waves' streams add, they do not overlap).  K = 1024 layers 0.245 - 0.26 ms (per-tile kernel 0.255 - 0.27;
+// with the column sums 0.25 against 0.30), K = 3072 1.50 against 1.57 ms.
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "gemm_epi.h"
+
+namespace svhip {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+constexpr int HT = 16384;                       // one half-tile: 128 rows x 64 k bf16
+constexpr int RING = 8 * HT;                    // 128 KiB operand ring
+constexpr int CST = 3072;                       // per-tile constants: bias | scale | shift, 256 floats each
+constexpr int PW3_LDS = RING + 2 * CST;
+constexpr int PGROUP_M = 8;                     // M-tiles per tile group: 8 x 4 N-tiles = the 32 CUs of an XCD
+
+#ifdef SVHIP_GEMM_DEBUG
+constexpr bool DBG3 = true;      // tools/gemm_bench (debug bit 16384): per-workgroup stage cycle totals
+#else
+constexpr bool DBG3 = false;
+#endif
+// compile-time ablations (tools/abl_pw3.sh; 0 in every shipped build): 1 no MFMAs, 2 no operand DMAs, 4 no activation,
+// 8 no output stores (without column sums the whole K loop is then dead code), 16 no fragment reads, 64 no column sums,
+// 128 strict vmcnt everywhere (the stores' acknowledgements are waited for in the next tile's first phases)
+#ifdef PW3_ABL
+constexpr int ABL = PW3_ABL;
+#else
+constexpr int ABL = 0;
+#endif
+
+template <int EPI, int CS>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
+__global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NST = 16 + 8 * CS;                // vector-memory stores a wave issues in one tile's epilogue
+
+    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+    const int ntiles = ntm * ntn;
+    const int G = gridDim.x;
+    int perm = blockIdx.x;                          // position in a round: contiguous band per XCD (bijective for any G)
+    {
+        const int q = G >> 3, r = G & 7, xcd = perm & 7;
+        perm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (perm >> 3);
+    }
+    auto tile_of = [&](int w, int& tm, int& tn) {
+        const int per = PGROUP_M * ntn;
+        const int grp = w / per;
+        const int within = w - grp * per;
+        const int gm = min(PGROUP_M, ntm - grp * PGROUP_M);
+        const int tnn = within / gm;
+        tm = grp * PGROUP_M + (within - tnn * gm);
+        tn = tnn;
+    };
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;        // wave group == wm: rows wm*128 .. +127, cols wn*64 .. +63
+    // Only `tid` stays live across the stages of a tile: every stage derives its lane coordinates from an OPAQUE copy, so that
+    // the compiler cannot hoist a stage's address arithmetic out of the tile loop and carry it through the K loop (which runs
+    // at 256 VGPRs: every hoisted value is a spill, and every spill reload is a vector-memory load that drains the DMA queue)
+    auto lane_now = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t & 63; };
+
+    // ---- operand DMA addressing (see gemm_pw2.hip) ----------------------------------------------------------------
+    // a lane's source = wave-uniform tile base (SGPR pair: A + m0 rows, W + n0 rows, advanced by 128 bytes per K tile) + a 32-bit
+    // per-lane byte offset (row within the tile, clamped to the matrix, and the swizzled 16-byte chunk): 8 VGPRs, no 64-bit
+    // vector adds in the loop
+    uint32_t xo[2][2], wo[2][2];
+    const char* abase = nullptr;
+    const char* wbase = nullptr;
+    int dsto[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) dsto[jj] = (wave * 2 + jj) * 1024;
+    auto set_src = [&](int m0, int n0) {
+        const int lane = lane_now();
+        abase = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * 2;
+        wbase = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.Kp * 2;
+        const int mmax = p.M - 1 - m0, nmax = p.Wrows - 1 - n0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int rho = (wave * 2 + jj) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((rho >> 1) & 7);
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int m = min((rho >> 6) * 128 + ty * 64 + (rho & 63), mmax);
+                xo[ty][jj] = (uint32_t)(m * p.lda * 2 + c * 16);
+                const int n = min((rho >> 5) * 64 + ty * 32 + (rho & 31), nmax);
+                wo[ty][jj] = (uint32_t)(n * p.Kp * 2 + c * 16);
+            }
+        }
+    };
+    auto issue = [&](int ty, int kt) {
+        char* base = smem + ((kt & 1) * 4 + ty) * HT;
+        const char* ub = (ty < 2 ? abase : wbase) + (int64_t)kt * 128;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            uint32_t o = ty < 2 ? xo[ty][jj] : wo[ty - 2][jj];
+            asm volatile("" : "+v"(o));          // the zero-extension stays in this block: SGPR base + 32-bit VGPR offset addressing
+            const char* s = ub + o;
+            if (!(ABL & 2)) __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
+        }
+    };
+    // bias / scale / shift of an N-tile -> constant strip `par`: one 16-byte-per-lane DMA each by waves 0, 1, 2 (older than
+    // every operand DMA of the tile, so the tile's first counted wait covers them)
+    auto issue_consts = [&](int n0, int par) {
+        if (wave < 3) {
+            const float* s = (wave == 0 ? p.bias : wave == 1 ? p.scale : p.shift) + n0 + lane_now() * 4;
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + RING + par * CST + wave * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_prologue = [&]() {
+        issue(2, 0); issue(0, 0); issue(3, 0); issue(1, 0);
+        issue(2, 1); issue(0, 1); issue(3, 1);
+    };
+    auto wait_left = [&](int left) {              // allow `left` half-tiles (2 DMAs each) of this wave to stay in flight
+        if (left >= 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (left == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // five half-tiles AND the previous tile's NST stores (issued after this tile's first 14 DMAs) may stay in flight
+    auto wait_relaxed = [&]() {
+        if (NST == 16) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        else if (NST == 24) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+    };
+
+    const int nkt = p.Kp / 64;                    // >= 4 (host check)
+
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;      // debug builds: cycles in {tile-start wait, K loop, next-tile issue, epilogue}
+#define PW3_STAMP(i) if (DBG3 && (p.debug & 16384) && p.ts) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
+    if (DBG3 && (p.debug & 16384) && p.ts) tprev = __builtin_readcyclecounter();
+    const unsigned long long tstart = tprev;
+
+    int w = perm;                                 // (the host launches G <= ntiles workgroups)
+    int tm, tn;
+    tile_of(w, tm, tn);
+    set_src(tm * 256, tn * 256);
+    issue_consts(tn * 256, 0);
+    issue_prologue();
+    bool relaxed = false;                         // the queue holds exactly NST stores behind this tile's first 14 DMAs
+    int ntile_done = 0;
+    int kbias = 0;                                // K tiles >= nkt of the DMA stream belong to the next tile: its K tile index = k - kbias
+    bf16x8 wlo[2][2];                             // W-lo fragments of the K tile about to be multiplied (carried from tile to tile)
+    // ---- first tile only: W-lo(0), X-lo(0) (and the constants) of every wave have landed; later tiles' first half-tiles arrive
+    // inside the previous tile's last two K tiles, with the stream's ordinary counted waits
+    wait_left(5);
+    __builtin_amdgcn_s_barrier();
+    {
+        const int lane = lane_now();
+        const int r16 = lane & 15, q4 = lane >> 4;
+        const int woff = (wn * 32 + r16) * 128, wkey = ((wn * 32 + r16) >> 1) & 7;
+        const char* b = smem + 2 * HT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = *reinterpret_cast<const bf16x8*>(b + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4));
+    }
+
+    for (int it = 0;; ++it) {
+        const int m0 = tm * 256, n0 = tn * 256, par = it & 1;
+        const char* cb = smem + RING + par * CST;
+        const int w_next = w + G;
+        const bool more = w_next < ntiles;
+        int tm_n = 0, tn_n = 0;
+        if (more) tile_of(w_next, tm_n, tn_n);
+        PW3_STAMP(0)
+        if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
+        const int lane = lane_now();
+        const int r16 = lane & 15, q4 = lane >> 4;      // 16x16x32 fragment coordinates
+        const int xoff = (wm * 64 + r16) * 128, woff = (wn * 32 + r16) * 128;
+        const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 32 + r16) >> 1) & 7;
+
+        // accumulators acc16[i][j][e] = channel n0 + wn*64 + j*16 + 4*q4 + e of frame m0 + wm*128 + i*16 + r16; they start at the bias
+        f32x4 acc16[8][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cb + (wn * 64 + j * 16 + 4 * q4) * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc16[i][j] = b0;
+        }
+        bf16x8 xf[4][2], whi[2][2], wnx[2][2];
+        // ---- four-phase K tiles (gemm_pw2.hip).  MODE 0: the stream goes on (every issue exists; past this tile's last K tile it
+        // fetches the NEXT tile's first K tiles: kbias); MODE 1: the workgroup's last tile drains.  RLX: bit g set = phase g of
+        // this K tile may use the relaxed count.  HOOK runs after phase 0 (the switch of the DMA addressing to the next tile).
+#define PW3_PHASE_END(gidx)                                                                         \
+    if (rem == 0) {                                                                                 \
+        constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
+        const int kk_ = kt + (((gidx) + 6) >> 2);                                                   \
+        if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
+        if (((rlx >> (gidx)) & 1) && relaxed) wait_relaxed();                                       \
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                      \
+        __builtin_amdgcn_s_barrier();                                                               \
+    } else {                                                                                        \
+        /* the tile's last two K tiles: `left_` phases remain (this one included).  Its own last half-tile goes out in the first */ \
+        /* of them; after that the stream fetches the next tile (kbias), or, on the workgroup's last tile, drains with counted waits */ \
+        constexpr int left_ = 4 * rem - (gidx);                                                     \
+        constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
+        const int kk_ = kt + (((gidx) + 6) >> 2) - kbias;                                           \
+        if (left_ > 7 || more) {                                                                    \
+            if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
+        }                                                                                           \
+        if (more) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                 \
+        else wait_left((left_ < 8 ? left_ : 8) - 3);                                                \
+        __builtin_amdgcn_s_barrier();                                                               \
+    }
+#define PW3_MFMA(I0, WARR, J0)                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    if (!(ABL & 1))                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                  \
+    __builtin_amdgcn_s_barrier();
+#define PW3_KTILE(REM_, KT_, WCUR, WNXT, RLX_, HOOK)                                       \
+    {                                                                                               \
+        constexpr int rem = (REM_);                /* 0: inside the tile; 2, 1: K tiles left, this one included */ \
+        constexpr int rlx = (RLX_);                                                                 \
+        const int kt = (KT_);                                                                       \
+        const char* bb = smem + (kt & 1) * 4 * HT;                                                  \
+        /* phase 0: X-lo(kt) x W-lo(kt) */                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+        PW3_PHASE_END(0)                                                                            \
+        PW3_MFMA(0, WCUR, 0)                                                                        \
+        HOOK                                                                                        \
+        /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                if (!(ABL & 16)) whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+        PW3_PHASE_END(1)                                                                            \
+        PW3_MFMA(0, whi, 2)                                                                         \
+        /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
+        PW3_PHASE_END(2)                                                                            \
+        PW3_MFMA(4, whi, 2)                                                                         \
+        /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
+        {   /* (on the workgroup's last K tile this reads a buffer nobody refilled: unused) */     \
+            const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                    \
+                    if (!(ABL & 16)) WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
+        }                                                                                           \
+        PW3_PHASE_END(3)                                                                            \
+        PW3_MFMA(4, WCUR, 0)                                                                        \
+    }
+#define PW3_ROLL                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = wnx[j][ks];
+        // the tile's phases 0 .. 4 wait for half-tiles 3 .. 7 of its first K tiles: the stores of the previous epilogue sit behind them
+        PW3_KTILE(0, 0, wlo, wnx, 15, )
+        PW3_ROLL
+        PW3_KTILE(0, 1, wlo, wnx, 1, )
+        PW3_ROLL
+        int kt0 = 2;
+        for (; kt0 + 2 < nkt; ++kt0) {              // steady state: every issue exists, five half-tiles stay in flight
+            PW3_KTILE(0, kt0, wlo, wnx, 0, )
+            PW3_ROLL
+        }
+        // the stream runs on: after X-hi of this tile's last K tile (phase 0 of K tile nkt - 2) every issue fetches the next tile
+        // (nkt is even: buffer parities continue), and the last phase leaves its W-lo(0) in wlo
+        PW3_KTILE(2, kt0, wlo, wnx, 0,
+                  if (more) { set_src(tm_n * 256, tn_n * 256); issue_consts(tn_n * 256, par ^ 1); kbias = nkt; })
+        PW3_ROLL
+        ++kt0;
+        PW3_KTILE(1, kt0, wlo, wnx, 0, )
+        PW3_ROLL
+        kbias = 0;
+#undef PW3_KTILE
+#undef PW3_PHASE_END
+#undef PW3_MFMA
+#undef PW3_ROLL
+        if (wm == 0) __builtin_amdgcn_s_barrier();      // even out the barrier count: both groups take the epilogue together
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);              // the stores below stay BEHIND the K loop's DMAs in the wave's queue (vmcnt bookkeeping)
+        PW3_STAMP(1)
+
+        // ---- epilogue from the accumulators ---------------------------------------------------------------------------
+        const int lane_e = lane_now();
+        const int r16e = lane_e & 15, q4e = lane_e >> 4;
+        {
+            char* Yb = reinterpret_cast<char*>(p.Y);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                f32x4 sc[2], sh[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int nl = wn * 64 + (2 * jp + jj) * 16 + 4 * q4e;
+                    sc[jj] = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
+                    sh[jj] = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
+                }
+                // after the swaps lane (q4e, r16e) holds channels c0 .. c0 + 7 of frame r16e (+ 16 i): 16 contiguous bytes
+                const int c0 = n0 + wn * 64 + jp * 32 + (q4e & 1) * 16 + (q4e >> 1) * 8;
+                char* yl = Yb + ((int64_t)(m0 + wm * 128 + r16e) * p.ldy + c0) * 2;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v0[4], v1[4];
+                    if (ABL & 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = acc16[i][2 * jp][e]; v1[e] = acc16[i][2 * jp + 1][e]; }
+                    } else {
+                        act4<EPI>(v0, acc16[i][2 * jp], sc[0], sh[0]);
+                        act4<EPI>(v1, acc16[i][2 * jp + 1], sc[1], sh[1]);
+                    }
+                    if (CS) {           // the column sums below take the activated fp32 values
+                        acc16[i][2 * jp] = f32x4{v0[0], v0[1], v0[2], v0[3]};
+                        acc16[i][2 * jp + 1] = f32x4{v1[0], v1[1], v1[2], v1[3]};
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(bf16_pack2(v0[0], v0[1]), bf16_pack2(v1[0], v1[1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(bf16_pack2(v0[2], v0[3]), bf16_pack2(v1[2], v1[3]), false, false);
+                    const int m = m0 + wm * 128 + i * 16 + r16e;
+                    if (m < p.M && !(ABL & 8))
+                        *reinterpret_cast<u32x4*>(yl + (int64_t)i * 16 * p.ldy * 2) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        }
+        if (CS) {
+            // per-utterance column sums of this wave's 128 frames x 64 channels:
+            //   colsum[((tm*2 + wm)*2 + seg) * N + n], seg 0 = the utterance of the tile's first row, seg 1 = the next one
+            const int lo = wm * 128;
+            const int rb = (m0 / p.T + 1) * p.T - m0;         // first tile row that belongs to the next utterance
+            const int rend = min(256, p.M - m0);
+            const bool whole = (lo + 128 <= rend) && (lo + 128 <= rb || lo >= rb);      // wave-uniform: one segment, every row valid
+            float* csp = p.colsum + ((int64_t)(tm * 2 + wm) * 2) * p.N + n0 + wn * 64 + 4 * q4e;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            // (the zeros that are STORED are made per use: hoisted out of the tile loop they were spilled, and every reload of a spill
+            //  is a vector-memory load whose wait also waits for the tile's stores)
+            auto fresh_zero4 = [&]() { float z = 0.f; asm volatile("" : "+v"(z)); return f32x4{z, z, z, z}; };
+            // (sums and sums of squares in separate passes over the accumulators: one set of partial sums live at a time)
+            if (whole) {
+                const int sg = lo >= rb ? 1 : 0;
+#pragma unroll
+                for (int kind = 0; kind < CS; ++kind) {
+                    float* cs = csp + (kind ? p.colsum_stride : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 s = zero4;
+                        if (!(ABL & 64)) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) s += kind ? acc16[i][j] * acc16[i][j] : acc16[i][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s[e] = row16_sum(s[e]);
+                        }
+                        if (r16e == 0) {
+                            *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)sg * p.N) = s;
+                            *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)(1 - sg) * p.N) = fresh_zero4();
+                        }
+                    }
+                }
+            } else if (lo + 128 <= rend) {
+                // an utterance boundary inside this wave's 128 valid rows: total and second-segment sums (one weight per 16-row
+                // block, set up once), first segment = total - second (fp32: the difference carries ~1e-7 of the total)
+                float w1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w1[i] = (lo + i * 16 + r16e >= rb) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int kind = 0; kind < CS; ++kind) {
+                    float* cs = csp + (kind ? p.colsum_stride : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 sa = zero4, s1 = zero4;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const f32x4 v = kind ? acc16[i][j] * acc16[i][j] : acc16[i][j];
+                            sa += v; s1 += v * w1[i];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { sa[e] = row16_sum(sa[e]); s1[e] = row16_sum(s1[e]); }
+                        if (r16e == 0) {
+                            *reinterpret_cast<f32x4*>(cs + j * 16) = sa - s1;
+                            *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
+                        }
+                    }
+                }
+            } else {
+                // rows past M (the last M-tile only): every row weighted on its own
+#pragma unroll
+                for (int kind = 0; kind < CS; ++kind) {
+                    float* cs = csp + (kind ? p.colsum_stride : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int row = lo + i * 16 + r16e;
+                            const float w0 = (row < rb && row < rend) ? 1.0f : 0.0f;
+                            const float w1 = (row >= rb && row < rend) ? 1.0f : 0.0f;
+                            const f32x4 v = kind ? acc16[i][j] * acc16[i][j] : acc16[i][j];
+                            s0 += v * w0; s1 += v * w1;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s0[e] = row16_sum(s0[e]); s1[e] = row16_sum(s1[e]); }
+                        if (r16e == 0) {
+                            *reinterpret_cast<f32x4*>(cs + j * 16) = s0;
+                            *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        PW3_STAMP(3)
+        ++ntile_done;
+        if (!more) break;
+        // every row of the tile just stored was inside M: each wave issued exactly NST stores behind the K loop's DMAs
+        relaxed = !(ABL & 128) && !(ABL & 8) && (m0 + 256 <= p.M);
+        w = w_next; tm = tm_n; tn = tn_n;
+    }
+    if (DBG3 && (p.debug & 16384) && p.ts) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tend = __builtin_readcyclecounter();
+        if ((tid & 63) == 0) {          // one record per wave: [workgroup][wave][8]
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ts) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+            for (int i = 0; i < 4; ++i) o[i] = tacc[i];
+            o[4] = (unsigned long long)ntile_done; o[5] = tend - tstart;
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            o[6] = tstart; o[7] = xcc;
+        }
+    }
+#undef PW3_STAMP
+}
+
+template <int EPI, int CS>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS>), PW3_LDS)) return e;
+    const int cap = pw3_grid_cap(p.num_cu);
+    const int grid = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS>), dim3(grid), dim3(512), PW3_LDS, stream, p);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_cs(const GemmParams& p, hipStream_t stream) {
+    if (!p.colsum) return launch_inst<EPI, 0>(p, stream);
+    return p.colsum_sq ? launch_inst<EPI, 2>(p, stream) : launch_inst<EPI, 1>(p, stream);
+}
+
+}  // namespace
+
+// The persistent kernel takes the plain pointwise layers of the 256 x 256 kernel's contract (no conv-gather, no residual) with
+// whole N tiles, at least four K tiles, all three per-channel vectors present, and more tiles than CUs (below that a persistent
+// workgroup has no second tile to overlap anything with).
+bool gemm_pw3_supported(const GemmParams& p, bool bf16) {
+    if (!gemm_pw2_supported(p, bf16)) return false;
+    if (p.taps > 1 || p.R || p.A3) return false;
+    if (p.N % 256 != 0 || p.Kp < 256) return false;
+    if (!p.bias || !p.scale || !p.shift) return false;
+    if (p.act2 != ACT_NONE || !(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU)) return false;
+    if (p.num_cu <= 0 || p.num_cu > 1024) return false;
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    return ntiles > pw3_grid_cap(p.num_cu);
+}
+
+// developer switch SVHIP_PW3_CUS=n (read at every call, like the library's other test switches): launch at most n workgroups, so that
+// a small test problem walks several tiles per workgroup (relaxed / strict waits, constant strips of both parities, masked last
+// tile); 0 disables the persistent kernel
+int pw3_grid_cap(int num_cu) {
+    const char* e = getenv("SVHIP_PW3_CUS");
+    const int env = e ? atoi(e) : -1;
+    if (env == 0) return 1 << 30;
+    return env > 0 ? (env < num_cu ? env : num_cu) : num_cu;
+}
+
+hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pw3_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
+    switch (p.act1) {
+        case ACT_NONE: return launch_cs<EPI_NONE>(p, stream);
+        case ACT_RELU: return launch_cs<EPI_RELU>(p, stream);
+        case ACT_GELU: return launch_cs<EPI_GELU>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace svhip

@@ -59,8 +59,9 @@ struct GemmParams {
     const float* bias_utt = nullptr;
     const float* scale = nullptr;
     const float* shift = nullptr;
-    // pw2 only: per-utterance column sums of the (bf16-rounded) output, taken from the LDS output tile:
-    //   colsum[((tile_m*8 + rg)*2 + seg) * N + n] = sum over the rows of 32-row group rg that belong to
+    // pw2 / pw3 only: per-utterance column sums of the output (pw2: of the bf16-rounded LDS output tile, 8 row groups of 32 rows
+    // per tile; pw3: of the activated fp32 accumulators, 2 row groups of 128 rows — gemm_colsum_groups says which):
+    //   colsum[((tile_m*RG + rg)*2 + seg) * N + n] = sum over the rows of row group rg that belong to
     //   utterance (tile_m*256 / T + seg); with colsum_sq the sums of squares follow at offset colsum_stride.
     float* colsum = nullptr;
     int colsum_sq = 0;
@@ -100,13 +101,22 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
 //   PW_NARROW  gemm_pw's 256 x 128 tile: a pw2 grid of at most half the CUs finishes in one round either way, and the half-size
 //              tile takes about half as long (RawNet2 blocks 6 / 7, 86 tiles: 370 -> 470 - 510 TFLOP/s)
 //   PW         gemm_pw with its default tile;  GENERIC  the register-staged kernel of gemm.hip
-enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3 };
+//   PW3        the persistent form of PW2 with the epilogue taken from the accumulators (gemm_pw3.hip): plain pointwise layers
+//              with more tiles than CUs (ECAPA's tdnn1 / tdnn2 / mfa)
+enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3, ROUTE_PW3 = 4 };
 GemmRoute gemm_route(const GemmParams& p, bool bf16);
 bool gemm_pw_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow = false);
 // bf16 256 x 256 role-staggered variant for the big layers (gemm_pw2.hip); launch_gemm_pw routes to it
 bool gemm_pw2_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
+// persistent variant (gemm_pw3.hip); pw3_grid_cap: workgroups it launches at most (the CU count, or the developer override
+// SVHIP_PW3_CUS, which lets small test problems run more than one tile per workgroup)
+bool gemm_pw3_supported(const GemmParams& p, bool bf16);
+hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream);
+int pw3_grid_cap(int num_cu);
+// row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
+int gemm_colsum_groups(const GemmParams& p, bool bf16);
 
 // ---------------------------------------------------------------------------------------------
 // Fused Res2Net chain (bf16 path): one workgroup per utterance runs the 7 dependent dilated convs
@@ -168,13 +178,13 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
                                 int B, int N, int K, int act, hipStream_t stream);
 // s[b, :] = sigmoid(W2 relu(W1 mean[b, :] + b1) + b2); W1 [H][C], W2T = W2 transposed [H][C]
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
-                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream);
+                         const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream, int row_groups = 8);
 // out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
                            bool bf16, int B, int T, int C, hipStream_t stream);
 // reduce the pw2 column-sum partials: out (B, C) = mean over T  [and out (B, 2C) = [mean | std] with sq]
 hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
-                                  float* out, float eps, hipStream_t stream);
+                                  float* out, float eps, hipStream_t stream, int row_groups = 8);
 // fp32 matrix -> (hi bf16 << 16 | lo bf16) words (the pre-split weight operand of gemm_pw's F32X3 path)
 hipError_t launch_split_words(const float* src, void* dst, int64_t n, hipStream_t stream);
 // eval-mode crops of int16 PCM files (back to back in `pcm`) -> (n_files * num_eval, L) fp32, 1/32768 scaling

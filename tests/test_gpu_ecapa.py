@@ -170,3 +170,35 @@ def test_bf16_geometry_sweep(C, L, B):
     a, b = outs["f32"], outs["bf16"]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.isfinite(b).all() and cos.min() >= 0.998, (C, L, B, cos)
+
+
+@pytest.mark.parametrize("C,B,cus", [(512, 8, 5), (512, 5, 3), (1024, 6, 8), (256, 16, 4)])
+def test_persistent_gemm_matches_the_per_tile_kernel(C, B, cus, monkeypatch):
+    """gemm_pw3 (persistent workgroups, epilogue from the accumulators) against gemm_pw2 (one workgroup per tile, LDS output image)
+    on the same layers.  SVHIP_PW3_CUS caps the persistent grid so that a small batch walks several tiles per workgroup: both
+    constant strips, the relaxed and the strict vmcnt counts (first tile, tile after a masked last M-tile), utterance boundaries
+    inside a wave's 128 rows and outside.  The GEMM outputs are the same arithmetic (bit-identical tdnn1 output); the column sums
+    are fp32 sums of unrounded values instead of bf16-rounded ones, so everything behind an SE gate agrees to bf16 round-off."""
+    T = 401
+    mel = synth.synth_mel(B, 80, T, seed=31)
+    outs, stages, launches = {}, {}, {}
+    for mode in ("0", str(cus)):
+        monkeypatch.setenv("SVHIP_PW3_CUS", mode)
+        eng, _ = make_engine(C, T, B, "bf16", 7)
+        eng.profile(True)
+        outs[mode] = eng.embed_features(mel)
+        launches[mode] = eng.profile_results()
+        stages[mode] = {n: stage_cf(eng, n, B, T).astype(np.float32) for n in STAGES}
+        eng.profile(False)
+        eng.close()
+    assert "gemm_pw3" not in launches["0"]
+    assert launches[str(cus)]["gemm_pw3"]["launches"] >= 6          # tdnn1 / tdnn2 of the three blocks (+ mfa when its grid is large enough)
+    a, b = outs["0"], outs[str(cus)]
+    assert np.isfinite(b).all()
+    cos = np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert float(cos.min()) >= 0.99999, cos
+    assert float(np.abs(a - b).max()) <= 5e-3 * float(np.abs(a).max())
+    for n in STAGES:
+        x, y = stages["0"][n], stages[str(cus)][n]
+        assert float(np.abs(x - y).max()) <= 2e-2 * max(1.0, float(np.abs(x).max())), n
+        assert abs(float(np.abs(x).sum()) - float(np.abs(y).sum())) <= 1e-3 * float(np.abs(x).sum()), n

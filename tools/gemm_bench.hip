@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 #include "kernels.h"
 #include "common.h"
 using namespace svhip;
@@ -110,7 +111,57 @@ int main(int argc, char** argv) {
                 checksum_bf16<<<1024, 256, 0, st>>>((const uint16_t*)Y, (size_t)s.M * s.N, dcs);
                 CK(hipMemcpyAsync(hcs, dcs, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
             }
-            printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s  cs %.6e %.6e\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, hcs[0], hcs[1]);
+            printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s  cs %.6e %.6e  [%s]\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, hcs[0], hcs[1],
+                   gemm_route(p, bf16) == ROUTE_PW3 ? "pw3" : gemm_route(p, bf16) == ROUTE_PW2 ? "pw2" : "other");
+            if ((debug & 128) && p.colsum && gemm_pw2_supported(p, bf16)) {
+                // per-utterance column sums from the partials (the arithmetic of colsum_finalize_kernel), as an order-sensitive checksum:
+                // the 8-row-group layout of pw2 and the 2-row-group layout of pw3 must agree to bf16 rounding of the summed values
+                const int RG = gemm_colsum_groups(p, bf16), Tn = p.T, Bn = s.M / Tn;
+                const size_t nfl = (size_t)2 * csr;
+                std::vector<float> hp(nfl);
+                CK(hipMemcpy(hp.data(), csum, nfl * 4, hipMemcpyDeviceToHost));
+                double a1 = 0, a2 = 0, q1 = 0;
+                for (int b = 0; b < Bn; ++b) {
+                    const int r0 = b * Tn, r1 = r0 + Tn - 1;
+                    for (int n = 0; n < s.N; n += 7) {
+                        double sm = 0, sq = 0;
+                        for (int tm = r0 / 256; tm <= r1 / 256; ++tm) {
+                            const int seg = b - (tm * 256) / Tn;
+                            if (seg < 0 || seg > 1) continue;
+                            for (int rg = 0; rg < RG; ++rg) {
+                                const size_t o = ((size_t)(tm * RG + rg) * 2 + seg) * s.N + n;
+                                sm += hp[o];
+                                if (debug & 256) sq += hp[csr + o];
+                            }
+                        }
+                        a1 += sm * ((b * 31 + n) % 13 + 1); a2 += fabs(sm); q1 += sq * ((b + n) % 5 + 1);
+                    }
+                }
+                printf("    colsum (RG %d): weighted sum %.9e  abs sum %.9e  sq %.9e\n", RG, a1, a2, q1);
+            }
+            if ((debug & 16384) && gemm_route(p, bf16) == ROUTE_PW3) {      // stage cycle totals of the persistent kernel, per wave
+                const int nwg = 256;
+                unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 512)); CK(hipMemset(dts, 0, (size_t)nwg * 512));
+                p.ts = dts;
+                CK(launch_gemm(p, bf16, st)); CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hts((size_t)nwg * 64);
+                CK(hipMemcpy(hts.data(), dts, (size_t)nwg * 512, hipMemcpyDeviceToHost));
+                p.ts = nullptr; CK(hipFree(dts));
+                for (int wv = 0; wv < 8; ++wv) {
+                    double sum[4] = {0, 0, 0, 0}, tot = 0, tiles = 0; int nw = 0;
+                    for (int w = 0; w < nwg; ++w) {
+                        const unsigned long long* o = &hts[((size_t)w * 8 + wv) * 8];
+                        if (!o[4]) continue;
+                        ++nw; tiles += (double)o[4]; tot += (double)o[5];
+                        for (int i = 0; i < 4; ++i) sum[i] += (double)o[i];
+                    }
+                    if (tiles > 0)
+                        printf("    pw3 wave %d: %d WGs, %.2f tiles/WG; cycles per tile: start wait %.0f | K loop %.0f | next-tile issue %.0f | epilogue %.0f | sum %.0f (kernel %.0f per WG = %.2f GHz)\n",
+                               wv, nw, tiles / nw, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, (sum[0] + sum[1] + sum[2] + sum[3]) / tiles, tot / nw,
+                               tot / nw / (ms * 1e6));
+                }
+                continue;
+            }
             if (debug & 16384) {          // stage timestamps of one launch (non-persistent pw2 kernel)
                 const int nwg = ((s.M + 255) / 256) * ((s.N + 255) / 256);
                 unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 64)); CK(hipMemset(dts, 0, (size_t)nwg * 64));
