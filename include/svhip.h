@@ -126,7 +126,10 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
  *                  one crop per row).
  *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150) — fp32 MFMA.
  *   asnorm_stats : per row of E: S = cohort @ e (utils.py:142), top-`top` largest, population
- *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  Cohort scores exist only as <= 2 GiB slabs.
+ *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  For D in {192, 256}, top <= 256 and K >= 4 top the cohort
+ *                  scores never reach memory (fused selection in the fp32 MFMA kernel, csrc/asnorm_fused.hip); otherwise, and for
+ *                  the embeddings that kernel cannot decide, they exist only as <= 2 GiB slabs.  svhip_asnorm_last_fallback():
+ *                  how many embeddings of the last call took the slab path after the fused kernel (-1: the whole call did).
  *   asnorm_pairs : out[p] = 0.5*((s-mu[a])/sd[a] + (s-mu[b])/sd[b]), s = E[a].E[b] (utils.py:148-160).
  * Pointers follow `flags` (indices are int32, device or host like the other inputs). */
 int svhip_l2norm(svhip_handle* h, float* E, int64_t N, int32_t D, int32_t flags);
@@ -139,6 +142,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
 int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* mu,
                        const float* sigma, const int32_t* ia, const int32_t* ib, int64_t P,
                        float* out, int32_t flags);
+int64_t svhip_asnorm_last_fallback(const svhip_handle* h);
 
 /* Verification metrics over a scored trial list: the sort-and-accumulate core of the reference's
  * evaluation tail, which it runs as Python list sorts and loops (src/utils.py:221-275) and sklearn calls (utils.py:74-121).

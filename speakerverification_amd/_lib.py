@@ -60,6 +60,7 @@ _SIGNATURES = {
     "svhip_score_matrix": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
     "svhip_asnorm_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "svhip_asnorm_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
+    "svhip_asnorm_last_fallback": (C.c_int64, [_P]),
     "svhip_roc_points": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P, _P, _P, C.c_int32]),
     "svhip_error_rates": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32]),
     "svhip_min_dcf": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),

@@ -139,6 +139,14 @@ struct svhip_handle {
     // handle's stream) and a ring of pinned host / device metadata slots, each guarded by an event, so that SVHIP_ASYNC calls
     // can return before the copy has run
     void* crop_pcm = nullptr; size_t crop_pcm_cap = 0;
+    // scoring / metrics scratch: handle-owned slots, grown on demand (no hipMalloc / hipFree per call once warm)
+    enum { SCR_IN0 = 0, SCR_IN1, SCR_IN2, SCR_IN3, SCR_IN4, SCR_OUT0, SCR_OUT1, SCR_OUT2, SCR_SLAB, SCR_SPLIT, SCR_CAND, SCR_CNT, SCR_MB,
+           SCR_FLAG, SCR_GATHER, SCR_WS, SCR_COUNT };
+    void* scr[SCR_COUNT] = {};
+    size_t scr_cap[SCR_COUNT] = {};
+    hipStream_t aux_stream = nullptr;         // second stream of the scoring entry points (candidate statistics under the next MFMA launch)
+    hipEvent_t aux_ev[4] = {};
+    int last_asnorm_flagged = -1;             // embeddings the fused AS-norm kernel handed to the slab path in the last call (-1: slab path)
     struct CropSlot { char* host = nullptr; char* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
     CropSlot crop_slot[4];
     int crop_next = 0;
@@ -1203,6 +1211,9 @@ int svhip_destroy(svhip_handle* h) {
     if (h->comm) (void)svhip_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->crop_pcm) (void)hipFree(h->crop_pcm);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+    for (hipEvent_t e : h->aux_ev) if (e) (void)hipEventDestroy(e);
+    for (void* q : h->scr) if (q) (void)hipFree(q);
     for (auto& sl : h->crop_slot) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.dev) (void)hipFree(sl.dev);
@@ -1439,21 +1450,34 @@ int svhip_synth_waveforms(svhip_handle* h, uint64_t seed, int64_t first_utt, int
 
 // ---- scoring ------------------------------------------------------------------------------------------
 namespace {
-struct TempBuf {      // device staging for host-pointer calls
-    svhip_handle* h; void* d = nullptr;
-    ~TempBuf() { if (d) (void)hipFree(d); }
+// a scratch slot of at least `bytes` (grown by half again; the old block is freed only after the stream has drained)
+int scratch(svhip_handle* h, int slot, size_t bytes, void** out) {
+    if (h->scr_cap[slot] < bytes || !h->scr[slot]) {
+        if (h->scr[slot]) { SV_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scr[slot]); h->scr[slot] = nullptr; h->scr_cap[slot] = 0; }
+        const size_t cap = std::max<size_t>(bytes + bytes / 2, 256);
+        if (hipMalloc(&h->scr[slot], cap) != hipSuccess) {
+            if (hipMalloc(&h->scr[slot], std::max<size_t>(bytes, 256)) != hipSuccess) { h->scr[slot] = nullptr; SV_FAIL(h, SVHIP_ERR_NOMEM, "scratch slot %d: %zu bytes", slot, bytes); }
+            h->scr_cap[slot] = std::max<size_t>(bytes, 256);
+        } else {
+            h->scr_cap[slot] = cap;
+        }
+    }
+    *out = h->scr[slot];
+    return SVHIP_OK;
+}
+struct TempBuf {      // device staging for host-pointer calls, in a scratch slot of the handle
+    svhip_handle* h; int slot;
     int in(const void* src, size_t bytes, bool is_dev, const void** out) {
         if (is_dev) { *out = src; return SVHIP_OK; }
-        SV_HIP(h, hipMalloc(&d, bytes ? bytes : 16));
+        void* d;
+        if (int rc = scratch(h, slot, bytes, &d)) return rc;
         SV_HIP(h, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream));
         *out = d;
         return SVHIP_OK;
     }
     int out(void* dst, size_t bytes, bool is_dev, void** o) {
         if (is_dev) { *o = dst; return SVHIP_OK; }
-        SV_HIP(h, hipMalloc(&d, bytes ? bytes : 16));
-        *o = d;
-        return SVHIP_OK;
+        return scratch(h, slot, bytes, o);
     }
 };
 }  // namespace
@@ -1462,7 +1486,7 @@ int svhip_l2norm(svhip_handle* h, float* E, int64_t N, int32_t D, int32_t flags)
     if (!h || !E || N < 0 || D <= 0) return SVHIP_ERR_INVALID;
     SV_HIP(h, hipSetDevice(h->cfg.device));
     const bool dev = flags & SVHIP_IN_DEVICE;
-    TempBuf t{h};
+    TempBuf t{h, svhip_handle::SCR_IN0};
     const void* d;
     int rc = t.in(E, (size_t)N * D * 4, dev, &d);
     if (rc) return rc;
@@ -1483,7 +1507,8 @@ static int pairs_common(svhip_handle* h, int mode, const float* E, int64_t N, in
         for (int64_t p = 0; p < P; ++p)
             if (ia[p] < 0 || ia[p] >= N || ib[p] < 0 || ib[p] >= N) SV_FAIL(h, SVHIP_ERR_INVALID, "pair %lld indexes outside [0, %lld)", (long long)p, (long long)N);
     }
-    TempBuf tE{h}, tA{h}, tB{h}, tM{h}, tS{h}, tO{h};
+    TempBuf tE{h, svhip_handle::SCR_IN0}, tA{h, svhip_handle::SCR_IN1}, tB{h, svhip_handle::SCR_IN2}, tM{h, svhip_handle::SCR_IN3},
+        tS{h, svhip_handle::SCR_IN4}, tO{h, svhip_handle::SCR_OUT0};
     const void *dE, *dA, *dB, *dM = nullptr, *dS = nullptr;
     void* dO;
     int rc;
@@ -1530,11 +1555,11 @@ static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64
     return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
 }
 
-// F32X3 handles: B as split words in a temporary the caller frees after the stream has drained (nullptr on exact handles)
+// F32X3 handles: B as split words in a scratch slot of the handle (nullptr on exact handles)
 static int split_b(svhip_handle* h, const float* dB, int64_t Nb, int D, void** out) {
     *out = nullptr;
     if (!h->x3) return SVHIP_OK;
-    SV_HIP(h, hipMalloc(out, (size_t)Nb * D * 4));
+    if (int rc = scratch(h, svhip_handle::SCR_SPLIT, (size_t)Nb * D * 4, out)) return rc;
     return run(h, "split_words", 0, [&]() { return launch_split_words(dB, *out, Nb * D, h->stream); });
 }
 
@@ -1542,7 +1567,7 @@ int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float*
     if (!h || !A || !B || !out || Na <= 0 || Nb <= 0 || D <= 0) return SVHIP_ERR_INVALID;
     SV_HIP(h, hipSetDevice(h->cfg.device));
     const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
-    TempBuf tA{h}, tB{h}, tO{h};
+    TempBuf tA{h, svhip_handle::SCR_IN0}, tB{h, svhip_handle::SCR_IN1}, tO{h, svhip_handle::SCR_OUT0};
     const void *dA, *dB;
     void* dO;
     int rc;
@@ -1550,12 +1575,31 @@ int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float*
     if ((rc = tB.in(B, (size_t)Nb * D * 4, din, &dB))) return rc;
     if ((rc = tO.out(out, (size_t)Na * Nb * 4, dout, &dO))) return rc;
     void* bsplit = nullptr;
-    if ((rc = split_b(h, (const float*)dB, Nb, D, &bsplit))) { if (bsplit) (void)hipFree(bsplit); return rc; }
+    if ((rc = split_b(h, (const float*)dB, Nb, D, &bsplit))) return rc;
     rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb, bsplit);
     if (!rc && !dout) { const hipError_t e = hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream); if (e != hipSuccess) rc = SVHIP_ERR_HIP; }
-    if (bsplit || !(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
-    if (bsplit) (void)hipFree(bsplit);
+    if (!(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
     return rc;
+}
+
+// the slab path: cohort scores of `rows` embeddings into an HBM scratch (rows x K fp32), slab by slab, reduced per row.
+// Used for shapes the fused kernel does not take (small cohorts, top > 256, other embedding widths, F32X3 handles) and for
+// the embeddings the fused kernel flags.
+static int asnorm_stats_slab(svhip_handle* h, const float* dE, int64_t N, int D, const float* dC, int K, int top, float* dM, float* dS) {
+    const int64_t ldk = (K + 3) & ~3;                             // row stride of the slab (16-byte rows for the DMA GEMM)
+    const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 31) / (ldk * 4)));
+    void* csplit = nullptr;
+    void* slab = nullptr;
+    int rc;
+    if ((rc = split_b(h, dC, K, D, &csplit))) return rc;
+    if ((rc = scratch(h, svhip_handle::SCR_SLAB, (size_t)slab_rows * ldk * 4, &slab))) return rc;
+    for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
+        const int64_t rows = std::min(slab_rows, N - r0);
+        rc = score_gemm(h, "asnorm_cohort_gemm", dE + r0 * D, rows, dC, K, D, (float*)slab, ldk, csplit);
+        if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats((const float*)slab, rows, K, (int)ldk, top, dM + r0, dS + r0, h->stream); });
+        if (rc) return rc;
+    }
+    return SVHIP_OK;
 }
 
 int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, const float* cohort, int32_t K, int32_t top,
@@ -1564,9 +1608,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     if (top < 0) top = K + top;             // python slice semantics of S[:top] (utils.py:143); top=-1 drops the smallest
     if (top > K) top = K;
     if (top <= 0) SV_FAIL(h, SVHIP_ERR_INVALID, "top must select at least one cohort score");
+    if (N >= ((int64_t)1 << 31)) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "at most 2^31 - 1 embeddings per call");
     SV_HIP(h, hipSetDevice(h->cfg.device));
     const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
-    TempBuf tE{h}, tC{h}, tM{h}, tS{h};
+    TempBuf tE{h, svhip_handle::SCR_IN0}, tC{h, svhip_handle::SCR_IN1}, tM{h, svhip_handle::SCR_OUT0}, tS{h, svhip_handle::SCR_OUT1};
     const void *dE, *dC;
     void *dM, *dS;
     int rc;
@@ -1574,29 +1619,82 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     if ((rc = tC.in(cohort, (size_t)K * D * 4, din, &dC))) return rc;
     if ((rc = tM.out(mu, (size_t)N * 4, dout, &dM))) return rc;
     if ((rc = tS.out(sigma, (size_t)N * 4, dout, &dS))) return rc;
-    // cohort scores are produced slab by slab into an HBM scratch (rows x K fp32) and reduced per row
-    const int64_t ldk = (K + 3) & ~3;                             // row stride of the slab (16-byte rows for the DMA GEMM)
-    const int64_t slab_rows = std::min<int64_t>(N, std::max<int64_t>(128, ((int64_t)1 << 31) / (ldk * 4)));
-    float* slab = nullptr;
-    void* csplit = nullptr;
-    if ((rc = split_b(h, (const float*)dC, K, D, &csplit))) { if (csplit) (void)hipFree(csplit); return rc; }
-    if (hipMalloc((void**)&slab, (size_t)slab_rows * ldk * 4) != hipSuccess) { if (csplit) { (void)hipStreamSynchronize(h->stream); (void)hipFree(csplit); } SV_FAIL(h, SVHIP_ERR_NOMEM, "cohort score slab"); }
-    for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
-        const int64_t rows = std::min(slab_rows, N - r0);
-        rc = score_gemm(h, "asnorm_cohort_gemm", (const float*)dE + r0 * D, rows, (const float*)dC, K, D, slab, ldk, csplit);
-        if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats(slab, rows, K, (int)ldk, top, (float*)dM + r0, (float*)dS + r0, h->stream); });
-        if (rc) break;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dE) | reinterpret_cast<uintptr_t>(dC)) & 15) == 0;
+    if (!h->x3 && aligned && asnorm_fused_supported(D, K, top) && !getenv("SVHIP_ASNORM_SLAB")) {
+        // fused path: the scores never leave the MFMA accumulators (csrc/asnorm_fused.hip)
+        // chunks of 131 072 embeddings: the candidate statistics of chunk c run on a second stream under the MFMA kernel of
+        // chunk c + 1 (two candidate buffers; the kernels meet through events)
+        const int64_t chunk = std::min<int64_t>(N, 131072);
+        const int nbuf = N > chunk ? 2 : 1;
+        void *mb, *cand, *cnt, *flag;
+        const size_t mb_bytes = (size_t)(D + 32) * D * 4;          // [MB | slice partials of its computation]
+        const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 2;
+        if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + cohort_moments_scratch_bytes(D), &mb))) return rc;
+        if ((rc = scratch(h, svhip_handle::SCR_CAND, cand_elems * 4 * nbuf, &cand))) return rc;
+        if ((rc = scratch(h, svhip_handle::SCR_CNT, cnt_elems * 4 * nbuf, &cnt))) return rc;
+        if ((rc = scratch(h, svhip_handle::SCR_FLAG, (size_t)(N + 1) * 4, &flag))) return rc;
+        if (nbuf == 2 && !h->aux_stream) {
+            SV_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 4; ++i) SV_HIP(h, hipEventCreateWithFlags(&h->aux_ev[i], hipEventDisableTiming));
+        }
+        int32_t* nflag = (int32_t*)flag;                    // [0] = number of flagged embeddings, [1 ..] their indices
+        SV_HIP(h, hipMemsetAsync(nflag, 0, 4, h->stream));
+        if ((rc = run(h, "asnorm_cohort_moments", 0, [&]() { return launch_cohort_moments((const float*)dC, K, D, (float*)mb, (float*)((char*)mb + mb_bytes), h->stream); }))) return rc;
+        AsnormFusedParams fp;
+        fp.cohort = (const float*)dC; fp.K = K; fp.MB = (const float*)mb; fp.z = asnorm_tail_z(K, top);
+        int c = 0;
+        for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
+            const int64_t rows = std::min(chunk, N - r0);
+            const int b = c & (nbuf - 1);
+            fp.E = (const float*)dE + r0 * D; fp.N = rows;
+            fp.cand = (float*)cand + b * cand_elems; fp.cnt = (int32_t*)cnt + b * cnt_elems;
+            if (nbuf == 2 && c >= 2) SV_HIP(h, hipStreamWaitEvent(h->stream, h->aux_ev[2 + b], 0));       // the statistics of chunk c - 2 have read this buffer
+            if ((rc = run(h, "asnorm_fused", 2.0 * rows * K * D, [&]() { return launch_asnorm_fused(fp, D, h->stream); }))) return rc;
+            hipStream_t st2 = h->stream;
+            if (nbuf == 2) {
+                SV_HIP(h, hipEventRecord(h->aux_ev[b], h->stream));
+                SV_HIP(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[b], 0));
+                st2 = h->aux_stream;
+            }
+            h->cur = st2;
+            rc = run(h, "asnorm_cand_stats", 0, [&]() {
+                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2);
+            });
+            h->cur = h->stream;
+            if (rc) return rc;
+            if (nbuf == 2) SV_HIP(h, hipEventRecord(h->aux_ev[2 + b], h->aux_stream));
+        }
+        if (nbuf == 2) for (int b = 0; b < std::min(c, 2); ++b) SV_HIP(h, hipStreamWaitEvent(h->stream, h->aux_ev[2 + b], 0));
+        int32_t nf = 0;
+        SV_HIP(h, hipMemcpyAsync(&nf, nflag, 4, hipMemcpyDeviceToHost, h->stream));
+        SV_HIP(h, hipStreamSynchronize(h->stream));
+        if (nf > 0) {
+            // cohort scores too far from normal for the threshold (fewer than `top` candidates, or a list overflowed): these embeddings
+            // are gathered and take the slab path; results are scattered back
+            void* g;
+            const size_t gbytes = (size_t)nf * D * 4 + 2 * (size_t)nf * 4 + 64;
+            if ((rc = scratch(h, svhip_handle::SCR_GATHER, gbytes, &g))) return rc;
+            float* gE = (float*)g;
+            float* gM = gE + (size_t)nf * D;
+            float* gS = gM + nf;
+            if ((rc = run(h, "asnorm_gather", 0, [&]() { return launch_gather_rows((const float*)dE, nflag + 1, nf, D, gE, h->stream); }))) return rc;
+            if ((rc = asnorm_stats_slab(h, gE, nf, D, (const float*)dC, K, top, gM, gS))) return rc;
+            if ((rc = run(h, "asnorm_scatter", 0, [&]() { return launch_scatter_stats(gM, gS, nflag + 1, nf, (float*)dM, (float*)dS, h->stream); }))) return rc;
+        }
+        h->last_asnorm_flagged = nf;
+    } else {
+        if ((rc = asnorm_stats_slab(h, (const float*)dE, N, D, (const float*)dC, K, top, (float*)dM, (float*)dS))) return rc;
+        h->last_asnorm_flagged = -1;
     }
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(slab);
-    if (csplit) (void)hipFree(csplit);
-    if (rc) return rc;
     if (!dout) {
-        SV_HIP(h, hipMemcpy(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost));
-        SV_HIP(h, hipMemcpy(sigma, dS, (size_t)N * 4, hipMemcpyDeviceToHost));
+        SV_HIP(h, hipMemcpyAsync(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+        SV_HIP(h, hipMemcpyAsync(sigma, dS, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
     }
+    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
     return SVHIP_OK;
 }
+
+int64_t svhip_asnorm_last_fallback(const svhip_handle* h) { return h ? h->last_asnorm_flagged : -1; }
 
 // ---- introspection ---------------------------------------------------------------------------------------
 // ---- verification metrics (metrics.hip) ------------------------------------------------------------------------------------
@@ -1604,11 +1702,10 @@ namespace {
 // shared front half: stage scores / labels, sort, scan.  Labels must be 0 / 1 (host labels are checked).
 struct MetricsRun {
     svhip_handle* h;
-    TempBuf tS{nullptr}, tL{nullptr};
+    TempBuf tS{nullptr, svhip_handle::SCR_IN0}, tL{nullptr, svhip_handle::SCR_IN1};
     void* ws = nullptr;
     size_t ws_bytes = 0;
     explicit MetricsRun(svhip_handle* hh) : h(hh) { tS.h = hh; tL.h = hh; }
-    ~MetricsRun() { if (ws) (void)hipFree(ws); }
     int start(const float* scores, const int32_t* labels, int64_t P, bool din, bool nan_to_num, const char* label) {
         if (P >= ((int64_t)1 << 31)) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "trial lists are limited to 2^31 - 1 entries");
         if (!din)
@@ -1620,7 +1717,7 @@ struct MetricsRun {
         if ((rc = tS.in(scores, (size_t)P * 4, din, &dS))) return rc;
         if ((rc = tL.in(labels, (size_t)P * 4, din, &dL))) return rc;
         ws_bytes = metrics_workspace_bytes(P);
-        SV_HIP(h, hipMalloc(&ws, ws_bytes));
+        if ((rc = scratch(h, svhip_handle::SCR_WS, ws_bytes, &ws))) return rc;
         return run(h, label, 0, [&]() { return metrics_sort_scan((const float*)dS, (const int32_t*)dL, P, nan_to_num, ws, ws_bytes, h->stream); });
     }
 };
@@ -1633,7 +1730,7 @@ int svhip_roc_points(svhip_handle* h, const float* scores, const int32_t* labels
     MetricsRun m(h);
     int rc;
     if ((rc = m.start(scores, labels, P, din, true, "metrics_sort"))) return rc;
-    TempBuf tT{h}, tF{h}, tP{h};
+    TempBuf tT{h, svhip_handle::SCR_OUT0}, tF{h, svhip_handle::SCR_OUT1}, tP{h, svhip_handle::SCR_OUT2};
     void *dT, *dF, *dP;
     if ((rc = tT.out(thr, (size_t)P * 4, dout, &dT)) || (rc = tF.out(fps, (size_t)P * 8, dout, &dF)) || (rc = tP.out(tps, (size_t)P * 8, dout, &dP))) return rc;
     int32_t* n_dev = nullptr;
@@ -1657,7 +1754,7 @@ int svhip_error_rates(svhip_handle* h, const float* scores, const int32_t* label
     MetricsRun m(h);
     int rc;
     if ((rc = m.start(scores, labels, P, din, false, "metrics_sort"))) return rc;
-    TempBuf tA{h}, tB{h}, tC{h};
+    TempBuf tA{h, svhip_handle::SCR_OUT0}, tB{h, svhip_handle::SCR_OUT1}, tC{h, svhip_handle::SCR_OUT2};
     void *dA, *dB, *dC;
     if ((rc = tA.out(fnrs, (size_t)P * 8, dout, &dA)) || (rc = tB.out(fprs, (size_t)P * 8, dout, &dB)) || (rc = tC.out(thresholds, (size_t)P * 4, dout, &dC))) return rc;
     if ((rc = run(h, "metrics_rates", 0, [&]() { return metrics_error_rates(P, m.ws, m.ws_bytes, (double*)dA, (double*)dB, (float*)dC, h->stream); }))) return rc;
@@ -1677,12 +1774,11 @@ int svhip_min_dcf(svhip_handle* h, const float* scores, const int32_t* labels, i
     int rc;
     if ((rc = m.start(scores, labels, P, flags & SVHIP_IN_DEVICE, false, "metrics_sort"))) return rc;
     void* res = nullptr;
-    SV_HIP(h, hipMalloc(&res, 16));
+    if ((rc = scratch(h, svhip_handle::SCR_OUT0, 16, &res))) return rc;
     rc = run(h, "metrics_min_dcf", 0, [&]() { return metrics_min_dcf(P, m.ws, m.ws_bytes, p_target, c_miss, c_fa, (double*)res, (float*)((char*)res + 8), h->stream); });
     char host[16];
     hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host, res, 16, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(res);
     if (rc) return rc;
     SV_HIP(h, e);
     memcpy(min_dcf, host, 8);

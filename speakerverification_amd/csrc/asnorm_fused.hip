@@ -1,0 +1,314 @@
+// asnorm_fused.hip — AS-norm cohort statistics WITHOUT the N x K score matrix (gfx950).
+//
+// Reference: src/utils.py:142-146 — per embedding e: S = cohort @ e, sort descending, keep [:top], mean / population std.
+// The slab path (score.hip + the fp32 GEMM) wrote all N x K scores to HBM and read them back (28.8 GB each way for 1.2 M
+// embeddings against 5 994 cohort speakers).  Here the scores live only in MFMA accumulators:
+//
+//   * a wave owns 32 embeddings as the B operand of v_mfma_f32_32x32x2_f32 (exact fp32), D / 2 VGPRs per lane, loaded once;
+//     cohort rows stream through LDS in blocks of 32 (the A operand; one 16-byte-per-lane LDS-DMA image per block, XOR-swizzled
+//     on the source chunk so that the ds_read_b128 lane groups are conflict-free), shared by the workgroup's four waves;
+//   * with the cohort as A, a lane's 16 accumulators are 16 cohort scores of ONE embedding (C/D map: column = lane & 31), so the
+//     selection is lane-local: a score above the embedding's threshold tau is appended to that lane's candidate list in a
+//     handle-owned buffer (two lists of 256 per embedding: lanes l and l + 32), everything else is dropped;
+//   * tau needs the row's first two score moments BEFORE the pass.  They are exact and cheap:  mean_k(e . c_k) = e . cbar and
+//     mean_k (e . c_k)^2 = e^T M e with M = C^T C / K (D x D), so M's rows and cbar go through the same MFMA loop as D / 32 + 1
+//     leading pseudo-cohort blocks; tau = mean + z sd with z the normal quantile that leaves ~1.6 top candidates;
+//   * asnorm_cand_stats_kernel then selects the exact top-`top` of each embedding's <= 512 candidates (score_select.h) —
+//     every score above tau is a candidate, so the answer is exact whenever top <= count and no list overflowed; the rare
+//     embedding for which that fails (cohort scores far from normal) is flagged and redone by the slab path.
+//
+// Work per embedding: 2 K D FLOP on the fp32 matrix pipe (157 TFLOP/s peak), ~K/32 x 24 KB of LDS-DMA per 128 embeddings from an
+// L2 / Infinity-Cache resident cohort, ~1.6 top x 4 bytes of candidate stores.
+#include "common.h"
+#include "kernels.h"
+#include "score_select.h"
+
+namespace svhip {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+constexpr int AF_CAPL = ASNORM_CAND_PER_LANE;      // candidate slots per lane (2 lanes per embedding)
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void asnorm_fused_kernel(AsnormFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = D / 4;                       // 16-byte chunks per cohort row
+    constexpr int BLK = 32 * D * 4;                 // one block of 32 cohort rows
+    constexpr int NDMA = 32 * CH / 256;             // DMA instructions per thread per block
+    constexpr int NP = D / 32 + 1;                  // pseudo-cohort blocks: rows of M, then cbar
+    static_assert(D % 64 == 0 && (32 * CH) % 256 == 0, "block image must be whole 4 KiB DMA rounds with 16-aligned chunk groups");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;         // embedding within the wave's 32 / half of the k range (and of the cohort rows of a block)
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + j;
+    const bool valid = row < p.N;
+    const float* __restrict__ erow = p.E + (valid ? row : p.N - 1) * D;
+
+    // B operand: e[k], k = h * D/2 + s, for MFMA k-step s (both operands use the same k assignment, so any is as good as 0, 1, 2 ..)
+    float eb[D / 2];
+#pragma unroll
+    for (int t = 0; t < D / 8; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(erow + h * (D / 2) + t * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) eb[t * 4 + u] = v[u];
+    }
+
+    const int nc = (p.K + 31) / 32;
+    const int nb = NP + nc;
+    // per-lane source offsets of the NDMA chunks this lane moves per block (block-invariant: row within the block, swizzled chunk)
+    int srow[NDMA], scol[NDMA];
+#pragma unroll
+    for (int q = 0; q < NDMA; ++q) {
+        const int pidx = q * 256 + tid;               // position of this lane's chunk in the block image
+        const int i = pidx / CH, cs = pidx - i * CH;
+        srow[q] = i;
+        scol[q] = (cs ^ (i & 15)) * 4;                // the image is lane-linear: the swizzle goes on the source
+    }
+    auto issue = [&](int b, int buf) {
+        const bool pseudo = b < NP;
+        const float* base = pseudo ? p.MB : p.cohort;
+        const int r0 = pseudo ? b * 32 : (b - NP) * 32;
+        const int limit = pseudo ? D + 31 : p.K - 1;
+        const float* bb = base + (int64_t)r0 * D;
+        const bool ragged = r0 + 31 > limit;          // wave-uniform: only the cohort's last block clamps its rows
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            const int i = ragged ? min(srow[q], limit - r0) : srow[q];
+            const float* s = bb + i * D + scol[q];
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + buf * BLK + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    // A fragments (16-byte reads: four k-steps each) are requested NG1 groups ahead of their MFMAs (left alone hipcc issues each
+    // ds_read right in front of the wait of the four MFMAs that use it).
+    // Read-ahead depth, measured on one box with two builds (tools/build_variant.sh -DAF_NG1=n; 1.2 M x 5 994, ms end to end):
+    // none 26.1 - 26.4 (another box), 1 group 26.7 - 26.9, half a block (12) 27.5 - 29.3: the partner wave already covers the LDS
+    // latency, and the deeper variants only cost registers.  PMC of this kernel (profiles/r03_asnorm_pmc.txt): matrix pipe busy
+    // 0.80 of the CU cycles at 2.13 - 2.23 GHz, no LDS bank conflicts, LDS array 5 % active.
+#ifdef AF_NG1
+    constexpr int NG = CH / 2, NG1 = AF_NG1;
+#else
+    constexpr int NG = CH / 2, NG1 = 1;
+#endif
+    f32x4 af[NG];
+    auto rd = [&](int buf, int t) {
+        return *reinterpret_cast<const f32x4*>(smem + buf * BLK + j * (D * 4) + (((h * NG + t) ^ (j & 15)) << 4));      // cohort row j of the block (A: row = lane & 31)
+    };
+    auto read_first = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < NG1; ++t) af[t] = rd(buf, t);
+    };
+    auto mfma_block = [&](int buf) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            if (t + NG1 < NG) af[t + NG1] = rd(buf, t + NG1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][u], eb[t * 4 + u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return acc;
+    };
+
+    float second = 0.0f, tau = 0.0f;
+    int cnt = 0;
+    float* candl = p.cand + ((valid ? row : 0) * 2 + h) * AF_CAPL;
+    // acc[r] = score of cohort row 32 b' + (r & 3) + 8 (r >> 2) + 4 h against embedding j
+    auto process = [&](const f32x16& a, int b) {
+        if (b < NP - 1) {               // rows of M: (M e)_i . e_i
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + 32 * b + 8 * g + 4 * h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) second = fmaf(a[4 * g + u], ev[u], second);
+            }
+        } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of the h = 0 lanes
+            const float m = __shfl(a[0], j, 64);
+            const float sec = second + __shfl_xor(second, 32, 64);
+            tau = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+        } else {
+            const int kb = (b - NP) * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = kb + (r & 3) + 8 * (r >> 2);
+                const float v = a[r];
+                if (i < p.K && v > tau) {
+                    if (cnt < AF_CAPL && valid) candl[cnt] = v;
+                    ++cnt;
+                }
+            }
+        }
+    };
+
+#ifdef AF_STAGGER
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(AF_STAGGER);      // developer A/B: co-resident workgroups half a block apart (measured: +-0)
+#endif
+    issue(0, 0);
+    f32x16 accp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+    for (int b = 0; b < nb; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block b has landed (and the candidate stores of one block ago, long since)
+        __syncthreads();                                       // ... for every wave; nobody still reads the other buffer
+        if (b + 1 < nb) issue(b + 1, (b + 1) & 1);
+        read_first(b & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (b > 0) process(accp, b - 1);                       // selection of the previous block (the first reads land meanwhile)
+        accp = mfma_block(b & 1);
+    }
+    process(accp, nb - 1);
+    if (valid) p.cnt[row * 2 + h] = cnt;
+}
+
+// one wave per embedding: exact statistics of the top-`top` of its candidates; rows that cannot be decided are flagged
+__global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cnt, int64_t rows,
+                                                                int top, float* __restrict__ mu, float* __restrict__ sigma,
+                                                                int64_t row_base, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c0 = cnt[row * 2], c1 = cnt[row * 2 + 1];
+    if (c0 + c1 < top || c0 > AF_CAPL || c1 > AF_CAPL) {
+        if (lane == 0) flagged[atomicAdd(nflag, 1)] = (int32_t)(row_base + row);
+        return;
+    }
+    const float* c = cand + row * 2 * AF_CAPL;
+    uint32_t ck[2 * AF_CAPL / 64];
+#pragma unroll
+    for (int q = 0; q < 2 * AF_CAPL / 64; ++q) {
+        const int idx = lane + 64 * q;
+        float v = 0.0f;
+        bool in = false;
+        if (idx < c0) { v = c[idx]; in = true; }
+        else if (idx - c0 < c1) { v = c[AF_CAPL + idx - c0]; in = true; }
+        ck[q] = in ? fkey(v) : 0u;
+    }
+    float m, sd;
+    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd);
+    if (lane == 0) { mu[row_base + row] = m; sigma[row_base + row] = sd; }
+}
+
+// MB = [M ; cbar ; 0]: M[i][j] = (1/K) sum_k C[k][i] C[k][j] (D x D), cbar[j] = (1/K) sum_k C[k][j].
+// Stage 1: grid (D / 32, D / 32 + 1, MOM_SLICES): a 32 x 32 tile of C^T C over one slice of the cohort rows (thread = column j, 4 rows i;
+// the extra block row sums the columns themselves); stage 2 adds the slices in a fixed order (no atomics: same bits every run).
+constexpr int MOM_SLICES = 16;
+__global__ __launch_bounds__(256) void cohort_moments_part_kernel(const float* __restrict__ C, int K, int D, float* __restrict__ part) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + tx;
+    const int per = (K + MOM_SLICES - 1) / MOM_SLICES;
+    const int k0 = blockIdx.z * per, k1 = min(K, k0 + per);
+    float* out = part + (int64_t)blockIdx.z * (D + 32) * D;
+    if (blockIdx.y == gridDim.y - 1) {          // cbar (row D), zeros below
+        float s = 0.0f;
+        if (ty == 0) for (int k = k0; k < k1; ++k) s += C[(int64_t)k * D + j];
+        for (int r = ty; r < 32; r += 8) out[(int64_t)(D + r) * D + j] = r == 0 ? s : 0.0f;
+        return;
+    }
+    const int i0 = blockIdx.y * 32 + ty * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < k1; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(C + (int64_t)k * D + i0);
+        const float b = C[(int64_t)k * D + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = fmaf(a[u], b, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[(int64_t)(i0 + u) * D + j] = acc[u];
+}
+__global__ __launch_bounds__(256) void cohort_moments_sum_kernel(const float* __restrict__ part, int n, float inv_k, float* __restrict__ MB) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+#pragma unroll
+    for (int z = 0; z < MOM_SLICES; ++z) s += part[(int64_t)z * n + i];
+    MB[i] = s * inv_k;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ E, const int32_t* __restrict__ ids, int n, int D,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * D) return;
+    const int r = (int)(i / D), k = (int)(i - (int64_t)r * D);
+    out[i] = E[(int64_t)ids[r] * D + k];
+}
+__global__ __launch_bounds__(256) void scatter_stats_kernel(const float* __restrict__ m, const float* __restrict__ s, const int32_t* __restrict__ ids,
+                                                            int n, float* __restrict__ mu, float* __restrict__ sigma) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    mu[ids[i]] = m[i];
+    sigma[ids[i]] = s[i];
+}
+
+template <int D>
+hipError_t launch_fused_d(const AsnormFusedParams& p, hipStream_t stream) {
+    static DeviceOnce attr;
+    const int lds = 2 * 32 * D * 4;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(asnorm_fused_kernel<D>), lds)) return e;
+    hipLaunchKernelGGL((asnorm_fused_kernel<D>), dim3((unsigned)((p.N + 127) / 128)), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool asnorm_fused_supported(int D, int K, int top) {
+    return (D == 192 || D == 256) && top >= 1 && top <= 256 && K >= 4 * top && K >= 64;
+}
+
+// Upper-tail normal quantile z with P(x > mean + z sd) = frac (Abramowitz-Stegun 26.2.22), frac <= 0.5
+float asnorm_tail_z(int K, int top) {
+    const float frac = fminf(0.5f, 1.6f * (float)top / (float)K);
+    const float tq = sqrtf(-2.0f * logf(fmaxf(frac, 1e-6f)));
+    return tq - (2.30753f + 0.27061f * tq) / (1.0f + 0.99229f * tq + 0.04481f * tq * tq);
+}
+
+size_t cohort_moments_scratch_bytes(int D) { return (size_t)MOM_SLICES * (D + 32) * D * sizeof(float); }
+
+hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, float* part, hipStream_t stream) {
+    if (D % 32 != 0 || K <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cohort_moments_part_kernel, dim3(D / 32, D / 32 + 1, MOM_SLICES), dim3(256), 0, stream, cohort, K, D, part);
+    const int n = (D + 32) * D;
+    hipLaunchKernelGGL(cohort_moments_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part, n, 1.0f / (float)K, MB);
+    return hipGetLastError();
+}
+
+hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t stream) {
+    if (p.N <= 0) return hipSuccess;
+    if (!asnorm_fused_supported(D, p.K, 1) || !p.E || !p.cohort || !p.MB || !p.cand || !p.cnt) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(p.E) | reinterpret_cast<uintptr_t>(p.cohort) | reinterpret_cast<uintptr_t>(p.MB)) & 15) return hipErrorInvalidValue;
+    switch (D) {
+        case 192: return launch_fused_d<192>(p, stream);
+        case 256: return launch_fused_d<256>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(asnorm_cand_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
+                       flagged, nflag);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const float* E, const int32_t* ids, int n, int D, float* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(((int64_t)n * D + 255) / 256)), dim3(256), 0, stream, E, ids, n, D, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* ids, int n, float* mu, float* sigma, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, m, s, ids, n, mu, sigma);
+    return hipGetLastError();
+}
+
+}  // namespace svhip

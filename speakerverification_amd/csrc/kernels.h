@@ -282,6 +282,31 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
 // S (rows x K, row stride ld) fp32 cohort scores -> mean / population std of the `top` largest per row
 hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int top, float* mu, float* sigma, hipStream_t stream);
 
+// Fused AS-norm cohort statistics (asnorm_fused.hip): scores stay in the MFMA accumulators; per embedding two candidate lists of
+// ASNORM_CAND_PER_LANE scores above a moment-based threshold, then the exact top-`top` statistics of the candidates.
+constexpr int ASNORM_CAND_PER_LANE = 256;
+struct AsnormFusedParams {
+    const float* E = nullptr;       // (N, D) embeddings of this launch
+    int64_t N = 0;
+    const float* cohort = nullptr;  // (K, D)
+    int K = 0;
+    const float* MB = nullptr;      // (D + 32, D): rows of M = C^T C / K, then the cohort mean, then zeros (launch_cohort_moments)
+    float z = 0.0f;                 // threshold = row mean + z * row std (asnorm_tail_z)
+    float* cand = nullptr;          // (N, 2, ASNORM_CAND_PER_LANE) candidate scores
+    int32_t* cnt = nullptr;         // (N, 2) scores above the threshold seen by each of the two lanes (may exceed the list size)
+};
+bool asnorm_fused_supported(int D, int K, int top);
+float asnorm_tail_z(int K, int top);
+// `part`: cohort_moments_scratch_bytes(D) of scratch (slice partials, summed in a fixed order)
+size_t cohort_moments_scratch_bytes(int D);
+hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, float* part, hipStream_t stream);
+hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t stream);
+// mu / sigma [row_base + r] for r < rows; embeddings that cannot be decided from their candidates: flagged[atomicAdd(nflag, 1)] = index
+hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream);
+hipError_t launch_gather_rows(const float* E, const int32_t* ids, int n, int D, float* out, hipStream_t stream);
+hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* ids, int n, float* mu, float* sigma, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // Verification metrics (metrics.hip): one workspace of metrics_workspace_bytes(P) holds the sorted trial list
 // ---------------------------------------------------------------------------------------------

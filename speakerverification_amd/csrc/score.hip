@@ -8,6 +8,7 @@
 // (whole-row gathers), partial dot products are reduced with 4 xor-shuffles.
 #include "common.h"
 #include "kernels.h"
+#include "score_select.h"
 
 namespace svhip {
 
@@ -69,52 +70,6 @@ __global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ E, 
             out[p] = 0.5f * ((dab - mu[a]) / sigma[a] + (dab - mu[b]) / sigma[b]);
         }
     }
-}
-
-__device__ __forceinline__ uint32_t fkey(float v) {       // order-preserving float -> uint map
-    const uint32_t u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-__device__ __forceinline__ int wave_isum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// Exact mean / population std of the `top` largest of n sortable keys held as `per` keys per lane
-// (unused slots = key 0, the smallest): 32-step bitwise search for the top-th largest key, ties at the
-// threshold counted exactly.
-template <int PER>
-__device__ __forceinline__ void select_stats(const uint32_t (&k)[PER], int top, float& mean_out, float& sd_out) {
-    uint32_t prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = prefix | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) cnt += (k[j] >= cand);
-        if (wave_isum(cnt) >= top) prefix = cand;
-    }
-    const float vth = fkey_inv(prefix);
-    float sum = 0.0f;
-    int cgt = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (k[j] > prefix) { sum += fkey_inv(k[j]); ++cgt; }
-    sum = wave_sum(sum);
-    cgt = wave_isum(cgt);
-    const float nt = (float)(top - cgt);
-    const float mean = (sum + nt * vth) / (float)top;
-    float sq = 0.0f;
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-        if (k[j] > prefix) { const float d = fkey_inv(k[j]) - mean; sq = fmaf(d, d, sq); }
-    sq = wave_sum(sq);
-    const float dth = vth - mean;
-    mean_out = mean;
-    sd_out = sqrtf((sq + nt * dth * dth) / (float)top);
 }
 
 constexpr int TOPK_CAP = 512;            // candidate slots per row (8 per lane)

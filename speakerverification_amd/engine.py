@@ -383,6 +383,11 @@ class Engine:
                                              (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
         return mu, sd
 
+    @property
+    def asnorm_last_fallback(self) -> int:
+        """embeddings of the last asnorm_stats call that took the slab path after the fused kernel (-1: the whole call did)"""
+        return int(self.lib.svhip_asnorm_last_fallback(self.h))
+
     def asnorm_pairs(self, E, mu, sigma, ia, ib, out=None):
         N, D = E.shape
         P = int(ia.shape[0])

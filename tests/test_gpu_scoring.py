@@ -174,3 +174,78 @@ def test_scoring_size_sweep(eng, N, D, P, K, top):
     raw = (E[ia] * E[ib]).sum(1)
     want = 0.5 * ((raw - mu[ia]) / sd[ia] + (raw - mu[ib]) / sd[ib])
     assert float(np.abs(sc - want).max()) <= 2e-3 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("N,D,K,top", [(517, 192, 5994, 200), (130, 256, 1000, 50), (1000, 256, 2000, 256), (64, 192, 801, 200),
+                                       (3, 192, 64, 1), (129, 192, 5995, 200)])
+def test_fused_asnorm_kernel_shapes(eng, N, D, K, top):
+    """csrc/asnorm_fused.hip (scores selected in the MFMA accumulators, never stored): every embedding width it is built for,
+    ragged N / K (masked rows of the last workgroup, masked cohort rows of the last block), top at both ends of its range."""
+    rng = np.random.Generator(np.random.PCG64(N * 7 + D + K))
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    cohort = rng.standard_normal((K, D)).astype(np.float32)
+    cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
+    cohort[3] = cohort[5]                              # ties
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback >= 0               # the fused path ran
+    rmu, rsd = o_scoring.asnorm_stats(E, cohort, top)
+    assert float(np.abs(mu - rmu).max()) <= 1e-6
+    if top > 1:
+        assert float(np.abs(sd - rsd).max() / rsd.min()) <= 1e-4
+
+
+def test_fused_asnorm_hands_odd_embeddings_to_the_slab_path(eng):
+    """The fused kernel's threshold assumes roughly normal cohort scores.  Embeddings for which it keeps fewer than `top`
+    candidates (a cohort of near-duplicates: no spread) or overflows a candidate list (a heavy upper tail) must be flagged and
+    answered by the slab path — same numbers as the oracle either way."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    D, K, top = 192, 2000, 200
+    cohort = rng.standard_normal((K, D)).astype(np.float32)
+    cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
+    E = rng.standard_normal((300, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    # heavy upper tail: 700 cohort rows are copies of one direction (plus noise); embeddings near that direction see 700 high scores
+    hot = cohort[0].copy()
+    noise = rng.standard_normal((700, D)).astype(np.float32) * 0.02
+    cohort[100:800] = hot + noise
+    cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
+    E[10] = hot
+    E[11] = hot + 0.05 * E[11]
+    E[11] /= np.linalg.norm(E[11])
+    E[12] = 0.0                                         # every score equal (zero): no candidate is above the threshold
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback >= 1, eng.asnorm_last_fallback
+    rmu, rsd = o_scoring.asnorm_stats(E, cohort, top)
+    assert float(np.abs(mu - rmu).max()) <= 2e-6
+    ok = rsd > 1e-6
+    assert float((np.abs(sd - rsd)[ok] / rsd[ok]).max()) <= 1e-4
+    assert float(np.abs(sd[~ok]).max(initial=0.0)) <= 1e-6
+
+
+def test_fused_asnorm_at_scale():
+    """BASELINE config 4's shape on the device: 262 144 embeddings (two 131 072-row launches: the chunking of the candidate buffer)
+    against 5 994 cohort speakers, top 200; sampled rows against the float64 oracle, and the slab path as a second opinion."""
+    eng = Engine(model="none", max_batch=1)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, K, D, top = 262_144 + 77, 5994, 192, 200
+    E = torch.randn((N, D), generator=g, device=dev)
+    eng.l2norm_(E)
+    cohort = torch.randn((K, D), generator=g, device=dev)
+    eng.l2norm_(cohort)
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback == 0
+    assert bool(torch.isfinite(mu).all()) and bool(torch.isfinite(sd).all())
+    idx = np.r_[0:64, 131_000:131_200, N - 100:N]
+    rmu, rsd = o_scoring.asnorm_stats(E[idx].cpu().numpy(), cohort.cpu().numpy(), top)
+    assert float(np.abs(mu[idx].cpu().numpy() - rmu).max()) <= 1e-6
+    assert float(np.abs(sd[idx].cpu().numpy() - rsd).max() / rsd.min()) <= 1e-4
+    os.environ["SVHIP_ASNORM_SLAB"] = "1"
+    try:
+        mu2, sd2 = eng.asnorm_stats(E[:50_000], cohort, top)
+    finally:
+        del os.environ["SVHIP_ASNORM_SLAB"]
+    assert eng.asnorm_last_fallback == -1
+    assert float((mu2 - mu[:50_000]).abs().max()) <= 1e-6 and float((sd2 - sd[:50_000]).abs().max()) <= 1e-6
+    eng.close()

@@ -18,6 +18,10 @@ with torch.cuda.stream(s):
     out = torch.empty(P, device=dev)
     eng.asnorm_stats(E[:100000], C, 200)
     eng.score_pairs(E, ia, ib, out)
+    for rep in range(3):          # end to end, no per-kernel events
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.asnorm_stats(E, C, 200)
+        torch.cuda.synchronize(); print("asnorm_stats end to end %.2f ms (fallback %d)" % ((time.perf_counter() - t0) * 1e3, eng.asnorm_last_fallback))
     eng.profile(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     mu, sd = eng.asnorm_stats(E, C, 200)
