@@ -144,6 +144,18 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                        float* out, int32_t flags);
 int64_t svhip_asnorm_last_fallback(const svhip_handle* h);
 
+/* Whole-trial scores over the crops of two files (what ModelHandling.evaluateFromList needs per trial, src/model.py:413-448):
+ * F is the (n_files, n_crops, D) embedding block, ia / ib index files, out[p] is
+ *   SVHIP_TRIAL_COSINE : mean_i | cos(F[a, i], F[b, i]) |, per-norm clamp 1e-5              (utils.py:163-164)
+ *   SVHIP_TRIAL_PNORM  : mean_i || F[a, i] - F[b, i] + 1e-6 ||_2                            (utils.py:167-169)
+ *   SVHIP_TRIAL_PDIST  : - mean_{i,d} sqrt( sum_j (F[a, i, d] - F[b, j, d] + 1e-6)^2 )      (model.py:425-431, cohorts_path = None)
+ * mean_crops: out (n_files, D) = mean over the crops (the AS-norm statement runs on crop means).
+ * Pointers follow `flags`. */
+enum { SVHIP_TRIAL_COSINE = 0, SVHIP_TRIAL_PNORM = 1, SVHIP_TRIAL_PDIST = 2 };
+int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_files, int32_t n_crops, int32_t D,
+                       const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags);
+int svhip_mean_crops(svhip_handle* h, const float* F, int64_t n_files, int32_t n_crops, int32_t D, float* out, int32_t flags);
+
 /* Verification metrics over a scored trial list: the sort-and-accumulate core of the reference's
  * evaluation tail, which it runs as Python list sorts and loops (src/utils.py:221-275) and sklearn calls (utils.py:74-121).
  * scores fp32, labels int32 in {0, 1}, P trials (< 2^31); pointers follow `flags`, the scalar results are host pointers.

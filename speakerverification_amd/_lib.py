@@ -16,6 +16,7 @@ OK = 0
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
 F32, BF16, I64, F32X3 = 0, 1, 2, 3
 IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
+TRIAL_COSINE, TRIAL_PNORM, TRIAL_PDIST = 0, 1, 2
 COMM_ID_BYTES = 128
 
 
@@ -61,6 +62,8 @@ _SIGNATURES = {
     "svhip_asnorm_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "svhip_asnorm_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_asnorm_last_fallback": (C.c_int64, [_P]),
+    "svhip_score_trials": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
+    "svhip_mean_crops": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_roc_points": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P, _P, _P, C.c_int32]),
     "svhip_error_rates": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32]),
     "svhip_min_dcf": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),

@@ -105,6 +105,7 @@ struct svhip_handle {
     int num_cu = 256;
     int rn_T1 = 0;
     const void* rn_dbg_x = nullptr; int rn_dbg_T = 0, rn_dbg_C = 0;   // SVHIP_RN_STOP developer hook (tests)
+    void* rn_snap = nullptr; size_t rn_snap_cap = 0; int rn_snap_T = 0, rn_snap_C = 0;      // SVHIP_RN_SNAP=2: copy of block 2's pre-activation (stage "rn_snap")
 
     // workspace (device)
     float* d_wav = nullptr;       // (Bmax, L)
@@ -961,6 +962,22 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
          *o = off(h->rn_buf[3], b0 * per_utt, e), *sc = off(h->rn_buf[4], b0 * per_utt, e), *xn = off(h->rn_buf[5], b0 * per_utt, e);
     const char* stop_env = getenv("SVHIP_RN_STOP");          // developer hook: stop after N blocks, expose x as stage "rn_x"
     const int stop_after = stop_env ? atoi(stop_env) : -1;
+    // developer hook (tests): SVHIP_RN_SNAP=2 keeps a copy of lrelu(bn1(x)) as block 2 will read it — the first tensor that both the
+    // fused 128-channel blocks and the separate kernel sequence materialise — as stage "rn_snap"
+    const char* snap_env = getenv("SVHIP_RN_SNAP");
+    const int snap_at = snap_env ? atoi(snap_env) : -1;
+    auto snapshot = [&](const void* src, int Tn, int Cn) -> int {
+        const size_t bytes = (size_t)B * Tn * Cn * e;
+        if (h->rn_snap_cap < bytes) {
+            void* q = nullptr;
+            SV_HIP(h, hipMalloc(&q, bytes));
+            h->allocs.push_back(q);
+            h->rn_snap = q; h->rn_snap_cap = bytes;
+        }
+        SV_HIP(h, hipMemcpyAsync(h->rn_snap, src, bytes, hipMemcpyDeviceToDevice, st));
+        h->rn_snap_T = Tn; h->rn_snap_C = Cn;
+        return SVHIP_OK;
+    };
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
@@ -1007,6 +1024,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         void* xdst = (first < 8 && h->rn_blocks[first].has_shortcut && stop_after < 0) ? nullptr : x;
         if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, xdst, bf, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = Kp.cout;
+        if (snap_at == first && b0 == 0 && (rc = snapshot(pre, T, Kp.cout))) return rc;
     }
     for (int bi = first; bi < 8; ++bi) {
         svhip_handle::RnBlock& K = h->rn_blocks[bi];
@@ -1060,6 +1078,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         }
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
+        if (snap_at == bi + 1 && b0 == 0 && npre && (rc = snapshot(npre, T, K.cout))) return rc;
     }
     // aggregation: attentive statistics pooling                                          RawNet2_custom.py:215-224
     const int M = B * T;
@@ -1540,6 +1559,47 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     return pairs_common(h, 1, E, N, D, mu, sigma, ia, ib, P, out, flags);
 }
 
+int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_files, int32_t n_crops, int32_t D, const int32_t* ia,
+                       const int32_t* ib, int64_t P, float* out, int32_t flags) {
+    if (!h || !F || !ia || !ib || !out || n_files <= 0 || n_crops <= 0 || D <= 0 || P < 0) return SVHIP_ERR_INVALID;
+    if (mode < SVHIP_TRIAL_COSINE || mode > SVHIP_TRIAL_PDIST) SV_FAIL(h, SVHIP_ERR_INVALID, "unknown trial scoring mode %d", mode);
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    if (!din)
+        for (int64_t p = 0; p < P; ++p)
+            if (ia[p] < 0 || ia[p] >= n_files || ib[p] < 0 || ib[p] >= n_files) SV_FAIL(h, SVHIP_ERR_INVALID, "trial %lld indexes outside [0, %lld)", (long long)p, (long long)n_files);
+    TempBuf tF{h, svhip_handle::SCR_IN0}, tA{h, svhip_handle::SCR_IN1}, tB{h, svhip_handle::SCR_IN2}, tO{h, svhip_handle::SCR_OUT0};
+    const void *dF, *dA, *dB;
+    void* dO;
+    int rc;
+    if ((rc = tF.in(F, (size_t)n_files * n_crops * D * 4, din, &dF))) return rc;
+    if ((rc = tA.in(ia, (size_t)P * 4, din, &dA))) return rc;
+    if ((rc = tB.in(ib, (size_t)P * 4, din, &dB))) return rc;
+    if ((rc = tO.out(out, (size_t)P * 4, dout, &dO))) return rc;
+    if ((rc = run(h, "score_trials", 2.0 * P * n_crops * D, [&]() {
+             return launch_trial_crops(mode, (const float*)dF, n_crops, D, (const int32_t*)dA, (const int32_t*)dB, P, (float*)dO, h->stream);
+         }))) return rc;
+    if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
+int svhip_mean_crops(svhip_handle* h, const float* F, int64_t n_files, int32_t n_crops, int32_t D, float* out, int32_t flags) {
+    if (!h || !F || !out || n_files <= 0 || n_crops <= 0 || D <= 0) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    const bool din = flags & SVHIP_IN_DEVICE, dout = flags & SVHIP_OUT_DEVICE;
+    TempBuf tF{h, svhip_handle::SCR_IN0}, tO{h, svhip_handle::SCR_OUT0};
+    const void* dF;
+    void* dO;
+    int rc;
+    if ((rc = tF.in(F, (size_t)n_files * n_crops * D * 4, din, &dF))) return rc;
+    if ((rc = tO.out(out, (size_t)n_files * D * 4, dout, &dO))) return rc;
+    if ((rc = run(h, "mean_crops", 0, [&]() { return launch_mean_crops((const float*)dF, n_files, n_crops, D, (float*)dO, h->stream); }))) return rc;
+    if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)n_files * D * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
+    return SVHIP_OK;
+}
+
 // out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed).  On an
 // SVHIP_F32X3 handle the products are split-bf16 MFMA triples: `dBsplit` is B as (hi << 16 | lo) words (split_b below).
 static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO, int64_t ldo,
@@ -1802,6 +1862,7 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     else if (n == "asp") { src = h->d_pool_raw; rows = B; cols = ld = 2 * C3; f32 = true; }
     else if (n == "asp_bn") { src = h->d_pool_bn; rows = B; cols = ld = 2 * C3; f32 = true; }
     else if (n == "rn_x") { src = h->rn_dbg_x; rows = (size_t)B * h->rn_dbg_T; cols = ld = h->rn_dbg_C; }
+    else if (n == "rn_snap") { src = h->rn_snap; rows = (size_t)B * h->rn_snap_T; cols = ld = h->rn_snap_C; }
     else if (n == "mel") { src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true; }
     else SV_FAIL(h, SVHIP_ERR_INVALID, "unknown stage %s", name);
     *count = (int64_t)(rows * cols);

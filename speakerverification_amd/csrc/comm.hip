@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -36,12 +37,19 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // SVHIP_RCCL_LIB names the library instead of the default search (deployments with a private RCCL; tests of the failure path)
+        const char* forced = getenv("SVHIP_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        std::string why;
         for (const char* n : names) {
+            if (forced) n = forced;
             r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (r.so) break;
+            const char* m = dlerror();                  // (one call: dlerror() clears the message it returns)
+            if (why.empty()) why = m ? m : "?";
+            if (forced) break;
         }
-        if (!r.so) { r.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.so) { r.err = "cannot load librccl: " + why; return; }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));

@@ -279,6 +279,11 @@ hipError_t launch_l2norm(float* E, int64_t N, int D, hipStream_t stream);
 hipError_t launch_score_pairs(const float* E, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out, hipStream_t stream);
 hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const float* sigma, const int32_t* ia,
                                const int32_t* ib, int64_t P, float* out, hipStream_t stream);
+// whole-trial forms over the aligned crops of two files, F (n_files, n_crops, D): mode 0 mean |cos|, 1 mean p-2 distance (+1e-6),
+// 2 minus the mean pairwise distance over the (n, D, n) broadcast (src/utils.py:163-169, src/model.py:425-431)
+hipError_t launch_trial_crops(int mode, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
+                              hipStream_t stream);
+hipError_t launch_mean_crops(const float* F, int64_t n_files, int n_crops, int D, float* out, hipStream_t stream);
 // S (rows x K, row stride ld) fp32 cohort scores -> mean / population std of the `top` largest per row
 hipError_t launch_topk_stats(const float* S, int64_t rows, int K, int ld, int top, float* mu, float* sigma, hipStream_t stream);
 

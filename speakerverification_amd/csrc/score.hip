@@ -72,6 +72,64 @@ __global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ E, 
     }
 }
 
+// ---- whole-trial forms over the crops of two files: F (n_files, n_crops, D), 16 lanes per trial ---------------------------
+//   MODE 0: mean_i | cos(R_i, C_i) |  (crop-aligned, per-norm clamp 1e-5)                        src/utils.py:163-164
+//   MODE 1: mean_i || R_i - C_i + 1e-6 ||_2                                                      src/utils.py:167-169
+//   MODE 2: - mean_{i,d} sqrt( sum_j (R[i,d] - C[j,d] + 1e-6)^2 )  — F.pairwise_distance of ref (n, D, 1) against com (1, D, n)
+//           takes the 2-norm over the LAST axis of the broadcast (n, D, n) difference (src/model.py:425-431)
+template <int MODE>
+__global__ __launch_bounds__(256) void trial_crops_kernel(const float* __restrict__ F, int n_crops, int D, const int32_t* __restrict__ ia,
+                                                          const int32_t* __restrict__ ib, int64_t P, float* __restrict__ out) {
+    const int sub = threadIdx.x & 15;
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool ok = p < P;
+    const int64_t a = ok ? ia[p] : 0, b = ok ? ib[p] : 0;
+    const float* __restrict__ fa = F + a * n_crops * D;
+    const float* __restrict__ fb = F + b * n_crops * D;
+    float acc = 0.0f;
+    if (MODE == 2) {
+        for (int d = sub; d < D; d += 16)
+            for (int i = 0; i < n_crops; ++i) {
+                const float r = fa[(int64_t)i * D + d];
+                float q = 0.0f;
+                for (int j = 0; j < n_crops; ++j) { const float t = (r - fb[(int64_t)j * D + d]) + 1e-6f; q = fmaf(t, t, q); }
+                acc += sqrtf(q);
+            }
+        acc = group16_sum(acc);
+        if (ok && sub == 0) out[p] = -acc / ((float)n_crops * (float)D);
+        return;
+    }
+    for (int i = 0; i < n_crops; ++i) {
+        const float* __restrict__ ea = fa + (int64_t)i * D;
+        const float* __restrict__ eb = fb + (int64_t)i * D;
+        float dab = 0.f, daa = 0.f, dbb = 0.f;
+        for (int k = sub; k < D; k += 16) {
+            const float x = ea[k], y = eb[k];
+            if (MODE == 0) { dab = fmaf(x, y, dab); daa = fmaf(x, x, daa); dbb = fmaf(y, y, dbb); }
+            else { const float t = (x - y) + 1e-6f; dab = fmaf(t, t, dab); }
+        }
+        dab = group16_sum(dab);
+        if (MODE == 0) {
+            daa = group16_sum(daa); dbb = group16_sum(dbb);
+            acc += fabsf(dab / (fmaxf(sqrtf(daa), 1e-5f) * fmaxf(sqrtf(dbb), 1e-5f)));
+        } else {
+            acc += sqrtf(dab);
+        }
+    }
+    if (ok && sub == 0) out[p] = acc / (float)n_crops;
+}
+
+// crop means: F (n_files, n_crops, D) -> out (n_files, D)   (np.mean over the crops: the AS-norm statement on crop means)
+__global__ __launch_bounds__(256) void mean_crops_kernel(const float* __restrict__ F, int64_t n_files, int n_crops, int D, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_files * D) return;
+    const int64_t f = i / D;
+    const int d = (int)(i - f * D);
+    float s = 0.0f;
+    for (int c = 0; c < n_crops; ++c) s += F[(f * n_crops + c) * D + d];
+    out[i] = s / (float)n_crops;
+}
+
 constexpr int TOPK_CAP = 512;            // candidate slots per row (8 per lane)
 
 // Register-resident variant: one wavefront per row, the row lives in NV float4 registers per lane (K <= 256*NV),
@@ -264,6 +322,25 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
                                const int32_t* ib, int64_t P, float* out, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(pair_kernel<1>, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, stream, E, D, ia, ib, P, mu, sigma, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_trial_crops(int mode, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
+                              hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    if (n_crops <= 0 || D <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((P + 15) / 16)), block(256);
+    if (mode == 0) hipLaunchKernelGGL(trial_crops_kernel<0>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
+    else if (mode == 1) hipLaunchKernelGGL(trial_crops_kernel<1>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
+    else if (mode == 2) hipLaunchKernelGGL(trial_crops_kernel<2>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_crops(const float* F, int64_t n_files, int n_crops, int D, float* out, hipStream_t stream) {
+    if (n_files <= 0) return hipSuccess;
+    if (n_crops <= 0 || D <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mean_crops_kernel, dim3((unsigned)((n_files * D + 255) / 256)), dim3(256), 0, stream, F, n_files, n_crops, D, out);
     return hipGetLastError();
 }
 

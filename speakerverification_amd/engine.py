@@ -36,6 +36,22 @@ def _count(inputs=(), outputs=()):
             TRANSFER_STATS["d2h_bytes"] += b.nbytes
 
 
+def to_device(a, device=0):
+    """host array -> CUDA tensor (torch owns the memory: plumbing), counted as PCIe traffic"""
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(f"cuda:{device}")
+    TRANSFER_STATS["h2d_bytes"] += t.numel() * t.element_size()
+    return t
+
+
+def to_host(t):
+    """CUDA tensor -> numpy, counted as PCIe traffic (numpy arrays pass through)"""
+    if _is_torch(t):
+        if t.is_cuda:
+            TRANSFER_STATS["d2h_bytes"] += t.numel() * t.element_size()
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
 class _Buf:
     """Pointer view of a numpy array (host) or a torch tensor (host or device)."""
 
@@ -301,6 +317,7 @@ class Engine:
         b = _Buf(E, np.float32, writable=True)
         self._order_after_torch(b)
         self._ck(self.lib.svhip_l2norm(self.h, b.ptr, N, D, _lib.IN_DEVICE | _lib.OUT_DEVICE if b.device else 0))
+        _count([b], [b])
         return E
 
     def _same_space(self, *bufs):
@@ -319,6 +336,33 @@ class Engine:
         dev = self._same_space(e, a, b, o)
         self._ck(self.lib.svhip_score_pairs(self.h, e.ptr, N, D, a.ptr, b.ptr, P, o.ptr,
                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        _count([e, a, b], [o])
+        return out
+
+    TRIAL_MODES = {"cosine": _lib.TRIAL_COSINE, "pnorm": _lib.TRIAL_PNORM, "pdist": _lib.TRIAL_PDIST}
+
+    def score_trials(self, F, ia, ib, mode="cosine", out=None):
+        """whole-trial scores over the crops of two files: F (n_files, n_crops, D), ia / ib file indices (svhip_score_trials)"""
+        n_files, n_crops, D = F.shape
+        P = int(ia.shape[0])
+        if out is None:
+            out = self._out(F, (P,))
+        f, a, b, o = _Buf(F, np.float32), _Buf(ia, np.int32), _Buf(ib, np.int32), _Buf(out, np.float32, writable=True)
+        dev = self._same_space(f, a, b, o)
+        self._ck(self.lib.svhip_score_trials(self.h, self.TRIAL_MODES[mode], f.ptr, n_files, n_crops, D, a.ptr, b.ptr, P, o.ptr,
+                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        _count([f, a, b], [o])
+        return out
+
+    def mean_crops(self, F, out=None):
+        """(n_files, n_crops, D) -> (n_files, D) crop means"""
+        n_files, n_crops, D = F.shape
+        if out is None:
+            out = self._out(F, (n_files, D))
+        f, o = _Buf(F, np.float32), _Buf(out, np.float32, writable=True)
+        dev = self._same_space(f, o)
+        self._ck(self.lib.svhip_mean_crops(self.h, f.ptr, n_files, n_crops, D, o.ptr, (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        _count([f], [o])
         return out
 
     def score_matrix(self, A, B, out=None):
@@ -381,6 +425,7 @@ class Engine:
         dev = self._same_space(e, c, m, s)
         self._ck(self.lib.svhip_asnorm_stats(self.h, e.ptr, N, D, c.ptr, K, int(top), m.ptr, s.ptr,
                                              (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        _count([e, c], [m, s])
         return mu, sd
 
     @property
@@ -398,6 +443,7 @@ class Engine:
         dev = self._same_space(e, m, s, a, b, o)
         self._ck(self.lib.svhip_asnorm_pairs(self.h, e.ptr, N, D, m.ptr, s.ptr, a.ptr, b.ptr, P, o.ptr,
                                              (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        _count([e, m, s, a, b], [o])
         return out
 
     # ---- introspection ------------------------------------------------------------------------------------------

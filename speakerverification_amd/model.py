@@ -28,7 +28,7 @@ import numpy as np
 from . import distributed as sv_dist
 from . import scoring
 from .audio import loadWAV, read_pcm16
-from .engine import _is_torch
+from .engine import _is_torch, to_device, to_host
 
 try:
     import torch
@@ -39,6 +39,10 @@ except Exception:  # pragma: no cover
 # losses whose test_normalize is False in the reference (src/losses/Prototypical.py:21); every other
 # loss sets it True (src/losses/*.py), which is what reaches the hot path (src/model.py:90-94,421-423)
 _NO_TEST_NORMALIZE = {"Prototypical"}
+
+
+def _host(x):
+    return x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
 
 
 class WrappedModel:
@@ -156,7 +160,7 @@ class ModelHandling:
         self.device = f"{device}:{gpu}"
         self.embed_batch = int(kwargs.get("embed_batch", 256))     # crops per device call (cross-file batching)
         self.device_crop = bool(kwargs.get("device_crop", True))   # 16-bit PCM files: crop on the device (svhip_crop_pcm16)
-        self._libcomm = None                                       # RCCL communicator under the C ABI (distributed eval)
+        self.device_feats = bool(kwargs.get("device_feats", True)) # keep enrol -> score on the device when a GPU is there
 
     # ---- training-only surface ---------------------------------------------------------------------------
     def fit(self, *a, **k):
@@ -187,24 +191,42 @@ class ModelHandling:
             return callable(getattr(S, "forward", None)) and getattr(S, "accepts_device_wave", False)
         return hasattr(S, "embed_wave") and enc._fusable()
 
-    def _embed_files(self, files, num_eval):
+    def _feats_on_device(self):
+        """evaluateFromList / testFromList keep the (n_files, num_eval, nOut) block in HBM from the embed calls to the scoring
+        kernels when there is a GPU to hold it (only the P scores come back); CPU test doubles keep numpy."""
+        return self.device_feats and torch is not None and torch.cuda.is_available()
+
+    def _embed_files(self, files, num_eval, on_device=False):
         """crops of several files travel in one batch (the reference runs one file per forward,
-        src/model.py:386-394).  Returns a dense (n_files, num_eval, nOut) float32 block.
+        src/model.py:386-394).  Returns a dense (n_files, num_eval, nOut) float32 block: a numpy array, or with
+        on_device=True a CUDA tensor that never visits the host.
 
         16-bit PCM files take the device path: the int16 samples are uploaded once, `svhip_crop_pcm16` cuts the eval-mode
         crops (audio_loader.py:110-150) straight into an HBM buffer, and the embed call consumes that buffer as a device
-        pointer in batches of `embed_batch` crops across files — no fp32 crop crosses PCIe; only embeddings come back.
+        pointer in batches of `embed_batch` crops across files — no fp32 crop crosses PCIe.
         Other sources (float / 24-bit files, ndarrays, num_eval == 0) keep the host path (loadWAV)."""
         feats = None
         max_audio = int(self.audio_spec["sentence_len"] * self.audio_spec["sample_rate"])
         use_dev = self._device_path_ok(num_eval)
         pending, owners = [], []            # host path: fp32 crops
         pcm_pending, pcm_owners = [], []    # device path: int16 files
+        ncrop = max(1, num_eval)
 
         def store(idx_n, emb):
             nonlocal feats
+            D = emb.shape[-1]
             if feats is None:
-                feats = np.zeros((len(files), max(1, num_eval), emb.shape[-1]), np.float32)
+                feats = (torch.zeros((len(files), ncrop, D), dtype=torch.float32, device=f"cuda:{self.gpu}") if on_device
+                         else np.zeros((len(files), ncrop, D), np.float32))
+            if on_device and not (_is_torch(emb) and emb.is_cuda):
+                emb = to_device(np.ascontiguousarray(_host(emb), np.float32), self.gpu)      # host-path files: only their embeddings go up
+            elif not on_device:
+                emb = to_host(emb) if _is_torch(emb) else np.asarray(emb)
+            # files of one flush are consecutive and (almost always) full: one block copy; otherwise file by file
+            idx0 = idx_n[0][0]
+            if all(n == ncrop for _, n in idx_n) and [i for i, _ in idx_n] == list(range(idx0, idx0 + len(idx_n))):
+                feats[idx0:idx0 + len(idx_n)] = emb.reshape(len(idx_n), ncrop, D)
+                return
             pos = 0
             for idx, n in idx_n:
                 feats[idx, :n] = emb[pos:pos + n]
@@ -227,8 +249,7 @@ class ModelHandling:
             for i in range(0, n, self.embed_batch):
                 o = self.__model__.forward(crops[i:i + self.embed_batch])
                 outs.append(o.reshape(-1, o.shape[-1]))
-            emb = torch.cat(outs, 0).cpu().numpy() if len(outs) > 1 else outs[0].cpu().numpy()
-            store(pcm_owners, emb)
+            store(pcm_owners, torch.cat(outs, 0) if len(outs) > 1 else outs[0])
             pcm_pending.clear()
             pcm_owners.clear()
 
@@ -267,31 +288,29 @@ class ModelHandling:
 
     # ---- evaluation ----------------------------------------------------------------------------------------------
     def _score(self, feats, ia, ib, scoring_mode, cohorts, cohorts_path):
-        if self.__model__.module.test_normalize:
-            flat = np.ascontiguousarray(feats.reshape(-1, feats.shape[-1]))
-            scoring.scoring_engine(self.gpu).l2norm_(flat)                  # F.normalize(p=2, dim=1), model.py:421-423
-            feats = flat.reshape(feats.shape)
+        """(n_files, n_crops, D) embeddings (numpy, or a CUDA tensor that stays where it is) + trial indices -> P float32 scores
+        on the host.  Normalisation and every scoring mode are library kernels; with device embeddings the PCIe traffic is the
+        index lists up, the P scores down (and the cohort up, for 'norm')."""
+        on_dev = _is_torch(feats) and feats.is_cuda
+        if self.__model__.module.test_normalize:                            # F.normalize(p=2, dim=1), model.py:421-423
+            if on_dev:
+                feats = feats.contiguous()
+                scoring.scoring_engine(self.gpu).l2norm_(feats.view(-1, feats.shape[-1]))
+            else:
+                flat = np.ascontiguousarray(np.asarray(feats, np.float32).reshape(-1, feats.shape[-1]))
+                scoring.scoring_engine(self.gpu).l2norm_(flat)
+                feats = flat.reshape(feats.shape)
         if cohorts_path is None:
             # model.py:425-431: F.pairwise_distance(ref (n,D,1), com (1,D,n)) takes the 2-norm over the LAST axis of the
-            # broadcast (n, D, n) difference, i.e. over the crops j of `com`: dist[i,d] = sqrt(sum_j (r[i,d] + eps - c[j,d])^2),
-            # score = -mean(dist).  Expanded: n a^2 - 2 a sum_j c_j + sum_j c_j^2 with a = r + eps, which needs O(P n D)
-            # memory instead of the O(P n D n) broadcast (a 580 k-trial validation list would need ~180 GB that way).
-            out = np.empty(len(ia), np.float32)
-            n = feats.shape[1]
-            for p0 in range(0, len(ia), 4096):
-                a = feats[ia[p0:p0 + 4096]].astype(np.float64) + 1e-6                   # (P, n, D)
-                c = feats[ib[p0:p0 + 4096]].astype(np.float64)
-                s1, s2 = c.sum(axis=1)[:, None, :], (c * c).sum(axis=1)[:, None, :]
-                q = n * a * a - 2.0 * a * s1 + s2
-                out[p0:p0 + 4096] = -np.sqrt(np.maximum(q, 0.0)).mean(axis=(1, 2))
-            return out
-        if scoring_mode == "norm":
-            return scoring.score_trials(feats, ia, ib, "norm", cohorts=cohorts, top=200, device=self.gpu)
-        if scoring_mode == "cosine":
-            return scoring.score_trials(feats, ia, ib, "cosine", device=self.gpu)
-        if scoring_mode == "pnorm":
-            return scoring.score_trials(feats, ia, ib, "pnorm", device=self.gpu)
-        raise ValueError(f"unknown scoring_mode {scoring_mode}")
+            # broadcast (n, D, n) difference, i.e. over the crops j of `com`; score = -mean.  One kernel over the trial list
+            # (svhip_score_trials, SVHIP_TRIAL_PDIST): O(P n^2 D) work, no (P, n, D, n) temporary.
+            mode = "pdist"
+        elif scoring_mode in ("norm", "cosine", "pnorm"):
+            mode = scoring_mode
+        else:
+            raise ValueError(f"unknown scoring_mode {scoring_mode}")
+        s = scoring.score_trials(feats, ia, ib, mode, cohorts=cohorts, top=200, device=self.gpu)
+        return np.asarray(to_host(s), np.float32)
 
     def evaluateFromList(self, listfilename, distributed=False, dataloader_options=None,
                          cohorts_path="checkpoint/dump_cohorts.npy", num_eval=10, scoring_mode="cosine", **kwargs):
@@ -307,11 +326,13 @@ class ModelHandling:
         setfiles = sorted(set(files))
         rank, world = sv_dist.rank_world() if distributed else (0, 1)
         lo, hi, _ = sv_dist.shard_bounds(len(setfiles), rank, world)
-        local = self._embed_files(setfiles[lo:hi], num_eval)
+        on_dev = self._feats_on_device()
+        local = self._embed_files(setfiles[lo:hi], num_eval, on_device=on_dev)
         if distributed and sv_dist.is_distributed():
             nOut = self.__model__.module.model["nOut"]
             if local is None:
-                local = np.zeros((0, max(1, num_eval), nOut), np.float32)
+                local = (torch.zeros((0, max(1, num_eval), nOut), dtype=torch.float32, device=f"cuda:{self.gpu}") if on_dev
+                         else np.zeros((0, max(1, num_eval), nOut), np.float32))
             feats = self._gather_rows(local, len(setfiles))            # ONE collective (reference: all_gather_object)
         else:
             feats = local
@@ -338,7 +359,7 @@ class ModelHandling:
             per = max(1, max(counts))
             pad = np.zeros((per, 1), np.float32)
             pad[:len(s_loc), 0] = s_loc
-            allp = self._gather_rows(pad, per * world, exact=True).reshape(world, per)
+            allp = np.asarray(to_host(self._gather_rows(pad, per * world, exact=True))).reshape(world, per)
             if rank == 0:
                 s = np.empty(len(ia), np.float32)
                 for r in range(world):
@@ -351,16 +372,20 @@ class ModelHandling:
             return [], [], []
         return all_scores, all_labels, all_trials
 
-    def _gather_rows(self, local: np.ndarray, n_total: int, exact=False) -> np.ndarray:
-        """the path's exchange step.  On GPUs: RCCL under the C ABI (svhip_allgather_rows on the scoring engine's stream;
-        torch.distributed only ships the RCCL id once).  Without a GPU (gloo CPU tests): torch.distributed all_gather_into_tensor.
-        exact=True: every rank passes exactly n_total / world rows."""
+    def _gather_rows(self, local, n_total: int, exact=False):
+        """the path's exchange step.  With an Engine that owns RCCL (a real one on a GPU): svhip_allgather_rows on the scoring
+        engine's stream, host or device rows alike; torch.distributed only ships the RCCL id once, and the communicator is cached
+        next to the engine (scoring.lib_comm), not per ModelHandling.  Otherwise (gloo CPU tests with a stand-in engine):
+        torch.distributed all_gather_into_tensor.  exact=True: every rank passes exactly n_total / world rows."""
         rank, world = sv_dist.rank_world()
-        if torch is not None and torch.cuda.is_available():
-            if self._libcomm is None:
-                self._libcomm = sv_dist.LibComm(scoring.scoring_engine(self.gpu), rank, world)
-            return self._libcomm.all_gather_rows(np.ascontiguousarray(local, np.float32), n_total)
-        return sv_dist.all_gather_rows(torch.from_numpy(np.ascontiguousarray(local)), n_total).numpy()
+        eng = scoring.scoring_engine(self.gpu)
+        # (an engine without comm_init is a CPU stand-in; more ranks than GPUs means ranks share a device, which RCCL refuses)
+        if hasattr(eng, "comm_init") and torch is not None and torch.cuda.is_available() and world <= torch.cuda.device_count():
+            comm = scoring.lib_comm(self.gpu, rank, world)
+            if not _is_torch(local):
+                local = np.ascontiguousarray(local, np.float32)
+            return comm.all_gather_rows(local, n_total)
+        return sv_dist.all_gather_rows(torch.from_numpy(np.ascontiguousarray(_host(local))), n_total).numpy()
 
     def testFromList(self, test_list="evaluation_test.txt", thresh_score=0.5, distributed=False, dataloader_options=None,
                      cohorts_path=None, num_eval=10, scoring_mode="norm", output_file=None):
@@ -379,7 +404,7 @@ class ModelHandling:
                 files += [row[0], row[1]]
                 lines.append(row)
         setfiles = sorted(set(files))
-        feats = self._embed_files(setfiles, num_eval)
+        feats = self._embed_files(setfiles, num_eval, on_device=self._feats_on_device())
         index = {f: i for i, f in enumerate(setfiles)}
         ia = np.asarray([index[r[0]] for r in lines], np.int32)
         ib = np.asarray([index[r[1]] for r in lines], np.int32)

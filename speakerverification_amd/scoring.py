@@ -26,6 +26,19 @@ def scoring_engine(device=0) -> Engine:
     return _engines[device]
 
 
+_comms = {}
+
+
+def lib_comm(device, rank, world):
+    """the RCCL communicator of a device's scoring engine (svhip_comm_*): created once per process and device — svhip_comm_init
+    refuses a second communicator on a handle — and reused by every ModelHandling; destroyed with the engine."""
+    from . import distributed as sv_dist
+    key = (device, rank, world)
+    if key not in _comms:
+        _comms[key] = sv_dist.LibComm(scoring_engine(device), rank, world)
+    return _comms[key]
+
+
 def _np(x):
     return x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
 
@@ -50,36 +63,39 @@ def asnorm_pairs(E, mu, sigma, ia, ib, device=0):
 
 def score_trials(feats, ia, ib, mode="cosine", cohorts=None, top=200, device=0):
     """Score a whole trial list.  ``feats``: (n_files, n_crops, D) float32 (already L2-normalised when
-    the loss sets test_normalize); ``ia``/``ib``: file indices per trial.
+    the loss sets test_normalize) — a numpy array, or a CUDA tensor, in which case everything stays on the device and a CUDA
+    tensor of P scores comes back; ``ia``/``ib``: file indices per trial.
       cosine: mean_i |cos(R_i, C_i)| over aligned crops                          (utils.py:163-164)
       norm  : adaptive S-norm on crop means with the top-`top` cohort scores     (utils.py:135-160)
       pnorm : mean_i ||R_i - C_i + 1e-6||_2                                      (utils.py:167-169)
-    Returns float32 numpy scores (one per trial)."""
-    feats = np.ascontiguousarray(_np(feats), dtype=np.float32)
+      pdist : -mean pairwise distance over the (n, D, n) broadcast               (model.py:425-431, cohorts_path=None)
+    Every mode is a device kernel (svhip_score_trials / svhip_mean_crops + svhip_asnorm_*)."""
+    from . import engine as _engine
+    on_dev = _is_torch(feats) and feats.is_cuda
+    if not on_dev:
+        feats = np.ascontiguousarray(_np(feats), dtype=np.float32)
     if feats.ndim == 2:
         feats = feats[:, None, :]
-    n_files, n_crops, D = feats.shape
     ia = np.ascontiguousarray(ia, dtype=np.int32)
     ib = np.ascontiguousarray(ib, dtype=np.int32)
     eng = scoring_engine(device)
     if len(ia) == 0:
         return np.zeros((0,), np.float32)
-    if mode == "cosine":
-        E = feats.reshape(n_files * n_crops, D)
-        crops = np.arange(n_crops, dtype=np.int32)[None, :]
-        pa = (ia[:, None] * n_crops + crops).reshape(-1)
-        pb = (ib[:, None] * n_crops + crops).reshape(-1)
-        s = eng.score_pairs(E, pa, pb).reshape(len(ia), n_crops)
-        return s.mean(axis=1).astype(np.float32)
+    if on_dev:                                # indices follow the embeddings into HBM (8 P bytes over PCIe)
+        feats = feats.contiguous()
+        ia, ib = _engine.to_device(ia, feats.device.index), _engine.to_device(ib, feats.device.index)
+    if mode in ("cosine", "pnorm", "pdist"):
+        return eng.score_trials(feats, ia, ib, mode)
     if mode in ("norm", "zt_norm"):
         if cohorts is None:
             raise ValueError("scoring_mode 'norm' needs a cohort matrix")
-        Em = np.ascontiguousarray(feats.mean(axis=1), dtype=np.float32)          # crop means (SURVEY Appendix A)
-        mu, sd = eng.asnorm_stats(Em, np.ascontiguousarray(_np(cohorts), dtype=np.float32), top)
+        Em = eng.mean_crops(feats)                                              # crop means (SURVEY Appendix A)
+        if on_dev:
+            cohorts = cohorts if (_is_torch(cohorts) and cohorts.is_cuda) else _engine.to_device(np.ascontiguousarray(_np(cohorts), np.float32), feats.device.index)
+        else:
+            cohorts = np.ascontiguousarray(_np(cohorts), dtype=np.float32)
+        mu, sd = eng.asnorm_stats(Em, cohorts, top)
         return eng.asnorm_pairs(Em, mu, sd, ia, ib)
-    if mode == "pnorm":
-        d = feats[ia] - feats[ib] + 1e-6
-        return np.sqrt((d * d).sum(-1)).mean(axis=1).astype(np.float32)
     raise ValueError(f"unknown scoring mode {mode}")
 
 
@@ -105,8 +121,14 @@ def ZT_norm_similarity(ref, com, cohorts, top=-1, **kwargs):
 
 
 def pnorm_similarity(ref, com, p=2, **kwargs):
-    d = _np(ref).astype(np.float32) - _np(com).astype(np.float32) + 1e-6
-    return np.mean(np.power(np.power(np.abs(d), p).sum(-1), 1.0 / p))
+    r, c = np.ascontiguousarray(_np(ref), np.float32), np.ascontiguousarray(_np(com), np.float32)
+    if r.ndim == 1:
+        r, c = r[None], c[None]
+    if p != 2:                               # utils.py:167 is only ever called with p = 2 (model.py:446)
+        raise NotImplementedError("pnorm_similarity: only p = 2 is on the hot path")
+    F = np.ascontiguousarray(np.stack([r, c]), dtype=np.float32)                 # (2 files, n crops, D)
+    eng = scoring_engine(kwargs.get("device", 0))
+    return float(eng.score_trials(F, np.array([0], np.int32), np.array([1], np.int32), "pnorm")[0])
 
 
 def similarity_measure(method="cosine", ref=None, com=None, **kwargs):

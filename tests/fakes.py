@@ -22,6 +22,24 @@ class FakeScoringEngine:
         mu, sd = o_scoring.asnorm_stats(np.asarray(E), np.asarray(cohort), top)
         return mu.astype(np.float32), sd.astype(np.float32)
 
+    def score_trials(self, F, ia, ib, mode="cosine", out=None):
+        """svhip_score_trials by the reference's own per-trial statements (oracle / torch)"""
+        import torch.nn.functional as TF
+        F = np.asarray(F, np.float32)
+        t = torch.from_numpy(F)
+        res = np.empty(len(ia), np.float32)
+        for p, (a, b) in enumerate(zip(np.asarray(ia), np.asarray(ib))):
+            if mode == "cosine":
+                res[p] = o_scoring.cosine_similarity(t[a], t[b])
+            elif mode == "pnorm":
+                res[p] = o_scoring.pnorm_similarity(t[a], t[b])
+            else:           # pdist: model.py:425-431
+                res[p] = -float(torch.mean(TF.pairwise_distance(t[a].unsqueeze(-1), t[b].unsqueeze(-1).transpose(0, 2))))
+        return res
+
+    def mean_crops(self, F, out=None):
+        return np.asarray(F, np.float32).mean(axis=1)
+
     def asnorm_pairs(self, E, mu, sd, ia, ib, out=None):
         E = np.asarray(E, np.float64)
         s = np.sum(E[ia] * E[ib], axis=1)

@@ -81,3 +81,27 @@ def test_comm_entry_points_fail_cleanly_without_a_handle():
     assert lib.svhip_comm_init(None, None, 0, 1) == -1
     assert lib.svhip_allgather_rows(None, None, 0, 0, None, 0) == -1
     assert lib.svhip_comm_destroy(None) == -1
+
+
+def test_comm_reports_a_missing_rccl_instead_of_crashing():
+    """with no loadable RCCL the comm entry points must return SVHIP_ERR_UNSUPPORTED and leave a message
+    (svhip.h's promise), not crash while building that message.  The loader runs once per process, so: a child process with
+    SVHIP_RCCL_LIB pointing at nothing."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from speakerverification_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.svhip_comm_unique_id(buf)\n"
+        "msg = lib.svhip_comm_last_error()\n"
+        "print(rc, (msg or b'').decode())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVHIP_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rc, _, msg = r.stdout.strip().partition(" ")
+    assert int(rc) == -5, r.stdout                      # SVHIP_ERR_UNSUPPORTED
+    assert "cannot load librccl" in msg and "nonexistent" in msg

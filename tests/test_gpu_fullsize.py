@@ -73,6 +73,73 @@ def test_scaling_and_silence(big):
     assert np.isfinite(z).all() and cos_rows(z[:1], z[1:]).min() >= 0.99995      # rows differ only by their tile cut
 
 
+@pytest.fixture(scope="module")
+def big_rn():
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(), seed=1)
+    eng = Engine(model="rawnet2", compute="bf16", embed_dim=320, max_batch=256)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    wav = synth.synth_waveforms(256, 32000, seed=20220830)
+    yield eng, sd, wav
+    eng.close()
+
+
+def test_rawnet2_full_batch_properties(big_rn):
+    """BASELINE configs[2] at full size (B = 256: rn_block128 gives each workgroup exactly one utterance, rn_sinc runs two
+    persistent workgroups per CU over 256 x N items) — until now only bench.py's isfinite() looked at this regime.
+    Deterministic; rows do not depend on their place in the batch nor on the batch size; 16 rows track the fp32 engine."""
+    eng, sd, wav = big_rn
+    a = eng.embed_wave(wav)
+    b = eng.embed_wave(wav)
+    assert a.shape == (256, 320) and np.isfinite(a).all()
+    assert np.array_equal(a, b)
+    perm = np.random.Generator(np.random.PCG64(11)).permutation(256)
+    shuffled = eng.embed_wave(wav[perm])
+    assert cos_rows(shuffled, a[perm]).min() >= 0.9999
+    small = eng.embed_wave(wav[:8])
+    assert cos_rows(small, a[:8]).min() >= 0.9999
+    f32 = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=16)
+    f32.load_state_dict(sd)
+    f32.finalize()
+    ref = f32.embed_wave(wav[:16])
+    f32.close()
+    c = cos_rows(a[:16], ref)
+    print("rawnet2 bf16 B=256 vs f32: cos", c.min(), "max err / scale", np.abs(a[:16] - ref).max() / np.abs(ref).max())
+    assert c.min() >= 0.99
+    assert np.abs(a[:16] - ref).max() <= 0.15 * np.abs(ref).max()
+
+
+def test_bench_shard_path_at_world_one(capsys):
+    """`bench.py --config shard` (BASELINE configs[4]'s code path: utterances generated on the device, embedded in
+    batches, ONE all-gather, row-sharded cosine + AS-norm scoring) was in no test.  2 000 utterances at world size 1: the record's
+    own checks, and the first 64 embeddings against the counter-RNG oracle's waveforms through the fp32 (1e-4-parity) engine."""
+    import argparse
+    import json
+    import bench
+    from oracle import synthwave as o_synth
+    args = argparse.Namespace(gpus=1, steps=1, warmup=1, compute="bf16", batch=256, model="ecapa", config="shard", utts_per_gpu=2000,
+                              no_cpu_baseline=True, no_scoring=False, no_extras=True)
+    dev = torch.device("cuda", 0)
+    ranks = bench.Ranks(args)
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        line, shard = bench.run_shard(args, ranks, dev, keep=True)
+        torch.cuda.synchronize()
+    printed = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert printed["config"]["utterances_per_gpu"] == 2000 and printed["n_gpus"] == 1 and printed["scaling"] == "weak"
+    assert line["finite"] and line["shard"]["own_block_intact"] and line["shard"]["scores_finite"]
+    assert line["shard"]["gathered_rows"] == 2000 and line["steps"] == 8 and line["value"] > 0
+    assert line["roofline"]["launches"] > 0 and 0 < line["roofline"]["frac"] < 1
+    emb = shard[:64].cpu().numpy()
+    wav = o_synth.synth_waveforms(bench.SEED_SHARD, 0, 64, bench.SAMPLES)
+    f32 = Engine(model="ecapa", compute="f32", channels=bench.CHANNELS, max_batch=64)
+    f32.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=bench.CHANNELS), seed=1))
+    f32.finalize()
+    ref = f32.embed_wave(wav)
+    f32.close()
+    assert cos_rows(emb, ref).min() >= 0.999
+    assert np.abs(emb - ref).max() <= 0.03 * np.abs(ref).max()
+
+
 def test_c_abi_error_behaviour():
     """Status codes and messages of the boundary (include/svhip.h): never a crash, never a silent success."""
     lib = _lib.load()

@@ -81,7 +81,12 @@ def test_evaluate_from_list_distributed_matches_single_process(nccl_group, tmp_p
     kw = dict(listfilename=trial_path, dataloader_options={}, cohorts_path="unused", num_eval=2, scoring_mode="cosine")
     single = mh.evaluateFromList(distributed=False, **kw)
     multi = mh.evaluateFromList(distributed=True, **kw)
-    assert mh._libcomm is not None and mh._libcomm.world == 1          # the RCCL communicator was really used
+    comm = scoring._comms.get((0, 0, 1))
+    assert comm is not None and comm.world == 1                        # the RCCL communicator was really used (cached next to the engine)
+    # a second ModelHandling in the same process reuses it (svhip_comm_init refuses a second communicator on a handle)
+    mh2 = ModelHandling(net, **dict(ARGS, save_folder=tmp))
+    again = mh2.evaluateFromList(distributed=True, **kw)
+    assert np.array_equal(np.array(again[0]), np.array(single[0])) and scoring._comms[(0, 0, 1)] is comm
     assert multi[1] == single[1] and multi[2] == single[2]
     assert np.array_equal(np.array(multi[0]), np.array(single[0]))
     g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
@@ -105,7 +110,7 @@ def test_only_int16_pcm_crosses_pcie(tmp_path):
     assert feats.shape == (len(files), num_eval, 192) and np.isfinite(feats).all()
     assert pcm_bytes <= h2d <= pcm_bytes + 64 * len(files), (h2d, pcm_bytes)      # the int16 samples + offsets / lengths
     assert h2d < crop_bytes / 10                                          # the host path would have shipped 10.2 MB of fp32 crops
-    assert d2h == 0                                                       # embeddings come back through torch (.cpu()), crops never
+    assert d2h == feats.nbytes                                            # host result requested: the embeddings come back, crops never
     # the device path and the host path (device_crop=False) agree to fp32 round-off (same crops, same kernels)
     mh.device_crop = False
     host = mh._embed_files(files, num_eval)
@@ -160,3 +165,82 @@ def test_load_tensor_rejects_null_data():
     rc = eng.lib.svhip_load_tensor(eng.h, b"blocks.0.norm.norm.num_batches_tracked", None, shape, 0, _lib.I64)
     assert rc == -1 and b"null data" in eng.lib.svhip_last_error(eng.h)
     eng.close()
+
+
+def test_enrol_to_score_stays_on_the_device(tmp_path, golden_dir):
+    """evaluateFromList keeps the (n_files, num_eval, 192) block in HBM from the embed calls through
+    normalisation to the scoring kernel.  PCIe traffic of a whole evaluation: the int16 PCM and the trial indices up, the P
+    scores down — nothing else (src/model.py:386-448 moves every embedding to the host and back per trial)."""
+    tmp = str(tmp_path)
+    net = WrappedModel(SpeakerEncoder(**ARGS))
+    mh = ModelHandling(net, **dict(ARGS, save_folder=tmp))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E_SEED_W)
+    net.module.load_state_dict({"__S__." + k: v for k, v in sd.items()})
+    files, trial_path, lines = make_e2e_files(tmp)
+    P = len(lines)
+    pcm_bytes = sum(os.path.getsize(f) - 44 for f in files)
+    g = np.load(os.path.join(golden_dir, "e2e_config1.npz"))
+    for mode, key, extra_up in (("cosine", "scores_ne2", 0),):
+        kw = dict(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path="unused", num_eval=2, scoring_mode=mode)
+        mh.evaluateFromList(**kw)                                          # warm: engines, scratch
+        before = dict(sv_engine.TRANSFER_STATS)
+        sc, lab, tr = mh.evaluateFromList(**kw)
+        h2d = sv_engine.TRANSFER_STATS["h2d_bytes"] - before["h2d_bytes"]
+        d2h = sv_engine.TRANSFER_STATS["d2h_bytes"] - before["d2h_bytes"]
+        assert d2h == 4 * P, (d2h, P)                                      # the scores, nothing else
+        assert pcm_bytes + 8 * P <= h2d <= pcm_bytes + 8 * P + 64 * len(files) + extra_up, (h2d, pcm_bytes, P)
+        assert float(np.abs(np.array(sc) - g[key]).max()) <= 1e-4
+    # 'norm': the cohort goes up as well, the cohort statistics never come down
+    cohort = synth.synth_embeddings(300, seed=5)
+    cpath = os.path.join(tmp, "cohort.npy")
+    np.save(cpath, cohort)
+    kw = dict(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path=cpath, num_eval=2, scoring_mode="norm")
+    host = ModelHandling(net, **dict(ARGS, save_folder=tmp, device_feats=False)).evaluateFromList(**kw)
+    mh.evaluateFromList(**kw)
+    before = dict(sv_engine.TRANSFER_STATS)
+    sc, _, _ = mh.evaluateFromList(**kw)
+    d2h = sv_engine.TRANSFER_STATS["d2h_bytes"] - before["d2h_bytes"]
+    h2d = sv_engine.TRANSFER_STATS["h2d_bytes"] - before["h2d_bytes"]
+    assert d2h == 4 * P
+    assert h2d <= pcm_bytes + 8 * P + 64 * len(files) + cohort.nbytes
+    assert float(np.abs(np.array(sc) - np.array(host[0])).max()) <= 1e-4 * max(1.0, float(np.abs(np.array(host[0])).max()))
+    # cohorts_path=None (pairwise-distance scoring) and pnorm through the same device-resident path against the host-array path
+    for kw2 in (dict(cohorts_path=None, scoring_mode="cosine"), dict(cohorts_path="unused", scoring_mode="pnorm")):
+        kw = dict(listfilename=trial_path, distributed=False, dataloader_options={}, num_eval=2, **kw2)
+        a = mh.evaluateFromList(**kw)[0]
+        b = ModelHandling(net, **dict(ARGS, save_folder=tmp, device_feats=False)).evaluateFromList(**kw)[0]
+        assert float(np.abs(np.array(a) - np.array(b)).max()) <= 1e-6
+
+
+def test_prepare_embed_matches_embed_utterance(tmp_path):
+    """VERDICT r2 #6 / src/model.py:610-670: prepare('embed') for a directory tree of speakers (embeds.pt (num_eval, nOut,
+    n_class) + classes.npy) and for a list of sources (mean embedding); rows must equal the per-file embed_utterance means."""
+    import shutil
+    tmp = str(tmp_path)
+    net = WrappedModel(SpeakerEncoder(**ARGS))
+    mh = ModelHandling(net, **dict(ARGS, save_folder=tmp))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E_SEED_W)
+    net.module.load_state_dict({"__S__." + k: v for k, v in sd.items()})
+    files, _, _ = make_e2e_files(tmp)
+    root = os.path.join(tmp, "spk")
+    for s in range(2):
+        os.makedirs(os.path.join(root, f"speaker{s}"))
+        for f in files[3 * s:3 * s + 3]:
+            shutil.copy(f, os.path.join(root, f"speaker{s}", os.path.basename(f)))
+    out = os.path.join(tmp, "prep")
+    os.makedirs(out)
+    assert mh.prepare(save_path=out, prepare_type="embed", num_eval=4, source=root) is True
+    embeds = torch.load(os.path.join(out, "embeds.pt"))
+    classes = np.load(os.path.join(out, "classes.npy"), allow_pickle=True).item()
+    assert tuple(embeds.shape) == (4, 192, 2) and sorted(classes.values()) == ["speaker0", "speaker1"]
+    for idx, name in classes.items():
+        s = int(name[-1])
+        want = np.stack([mh.embed_utterance(f, num_eval=4, normalize=True).numpy() for f in sorted(files[3 * s:3 * s + 3])], 0).mean(0)
+        got = embeds[:, :, idx].numpy()
+        assert float(np.abs(got - want).max()) <= 1e-6
+        assert np.allclose(np.linalg.norm(want, axis=1) <= 1.0 + 1e-6, True)
+    m = mh.prepare(save_path=None, prepare_type="embed", num_eval=4, source=[files[0], files[1]])
+    want = np.stack([mh.embed_utterance(f, num_eval=4, normalize=True).numpy() for f in files[:2]], 0).mean(0)
+    assert tuple(m.shape) == (4, 192) and float(np.abs(m.numpy() - want).max()) <= 1e-6
+    with pytest.raises(ValueError):
+        mh.prepare(save_path=None, prepare_type="embed", num_eval=4, source=None)

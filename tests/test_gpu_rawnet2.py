@@ -50,7 +50,7 @@ def test_rawnet2_bf16_close(golden_dir):
     print("rawnet2 bf16 rel", rel, "cos", cos)
     # bf16 storage through 8 un-normalised residual blocks + a bf16 sinc front-end: stated tolerance is
     # cosine >= 0.99 to the fp32 reference embedding and max error <= 15 % of the embedding scale
-    assert rel <= 0.15 and float(cos.min()) >= 0.99
+    assert rel <= 0.15 and float(cos.min()) >= 0.994          # (pinned just under the measured values: 0.99965 / 0.99461)
 
 
 def test_rawnet2_rejects_other_lengths():
@@ -155,3 +155,85 @@ def test_bf16_sample_counts_that_are_not_a_multiple_of_8(L):
     a, b = outs["f32"], outs["bf16"]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.isfinite(b).all() and cos.min() >= 0.99, cos
+
+
+def _ulps_bf16(a, b):
+    """|a - b| in units of the bf16 spacing (8 significant bits) at the scale of the element's ROW (one frame, 128 channels): the
+    tensor is lrelu(bn(x)), so an element may sit at a zero crossing where its own magnitude says nothing about the rounding
+    of the x it came from"""
+    m = np.maximum(np.abs(a), np.abs(b)).max(axis=-1, keepdims=True)
+    ulp = np.exp2(np.floor(np.log2(np.maximum(m, 1e-30))) - 7)
+    return np.abs(a - b) / ulp
+
+
+@pytest.mark.parametrize("L,B", [(32000, 3), (32000, 40), (20000, 7)])
+def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor(L, B, monkeypatch):
+    """the embedding-level bars (cosine >= 0.9, 3 % of the scale) could hide a wrong halo row or a mis-swizzled channel
+    block in one tile.  SVHIP_RN_SNAP=2 keeps lrelu(bn1(x)) as block 2 reads it — the first tensor that both the fused
+    128-channel kernels (rn_block128 x 2 + gates) and the separate kernel sequence store — and the two must agree element for
+    element to bf16 round-off: same storage points, only the summation order of the AFMS column means differs, which moves a gate
+    by ~1e-6 and so flips the rounding of a few elements by one ulp.  Geometries: one utterance per several workgroups (first tile
+    at t0 = 0, short last tile), 40 utterances (workgroups that span an utterance boundary), a length whose tiles do not divide."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=2)
+    wav = synth.synth_waveforms(B, L, seed=5)
+    monkeypatch.setenv("SVHIP_RN_SNAP", "2")
+    snaps = {}
+    for name, unfused in (("unfused", True), ("fused", False)):
+        if unfused:
+            monkeypatch.setenv("SVHIP_RN_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("SVHIP_RN_UNFUSED", raising=False)
+        eng = Engine(model="rawnet2", compute="bf16", embed_dim=320, max_batch=B, samples=L)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        eng.embed_wave(wav)
+        labels = set(eng.profile_results())
+        eng.profile(False)
+        assert ("rn_block128" in labels) == (not unfused), labels
+        snaps[name] = eng.get_stage("rn_snap").reshape(B, -1, 128)
+        eng.close()
+    a, b = snaps["fused"], snaps["unfused"]
+    assert a.shape == b.shape and a.shape[1] == ((L - 250) // 3) // 9
+    u = _ulps_bf16(a, b)
+    frac = float((a != b).mean())
+    print(f"L={L} B={B}: {frac:.4%} of the elements differ, max {u.max():.2f} bf16 ulps")
+    assert float(u.max()) <= 2.0, (float(u.max()), np.unravel_index(u.argmax(), u.shape))
+    assert frac <= 0.05
+    # every frame region is covered by the comparison: first / last frames of the first and last utterance are non-trivial
+    for bi in (0, B - 1):
+        for t in (0, a.shape[1] - 1):
+            assert np.abs(b[bi, t]).max() > 0
+
+
+@pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "bf16", 50, 3),
+                                                   ("ecapa", "bf16", 64, 2), ("ecapa", "f32", 70, 2)])
+def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, lanes, monkeypatch):
+    """SVHIP_LANES slices a batch over up to four streams (offsets into every per-utterance workspace buffer, lane
+    streams and events); no test or bench set it.  On fp32 handles the sliced forward must return the same bits as the
+    single-stream one (every reduction is per utterance, in a fixed order).  On bf16 handles the time sums (SE squeeze, ASP
+    statistics, AFMS means) are accumulated per GEMM tile / per workgroup item range, and an utterance's cut moves with its
+    position in its slice: equal to fp32-sum round-off, not to the bit."""
+    if model == "rawnet2":
+        sd = synth.synth_state_dict(synth.rawnet2_param_spec(), seed=4)
+        kw = dict(model="rawnet2", embed_dim=320)
+    else:
+        sd = synth.synth_state_dict(synth.ecapa_param_spec(C=256), seed=4)
+        kw = dict(model="ecapa", channels=256)
+    wav = synth.synth_waveforms(B, 32000, seed=6)
+    outs = {}
+    for n in (1, lanes):
+        monkeypatch.setenv("SVHIP_LANES", str(n))
+        eng = Engine(compute=compute, max_batch=B, **kw)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[n] = eng.embed_wave(wav).reshape(B, -1)
+        eng.close()
+    assert np.isfinite(outs[1]).all()
+    if compute == "f32":
+        assert np.array_equal(outs[1], outs[lanes])
+    else:
+        a, b = outs[1], outs[lanes]
+        cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        assert cos.min() >= 0.9999, cos.min()
+        assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()

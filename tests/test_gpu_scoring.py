@@ -249,3 +249,34 @@ def test_fused_asnorm_at_scale():
     assert eng.asnorm_last_fallback == -1
     assert float((mu2 - mu[:50_000]).abs().max()) <= 1e-6 and float((sd2 - sd[:50_000]).abs().max()) <= 1e-6
     eng.close()
+
+
+@pytest.mark.parametrize("n_files,n_crops,D,P", [(6, 3, 192, 40), (40, 10, 192, 500), (3, 1, 64, 7), (5, 2, 100, 16)])
+def test_whole_trial_scoring_modes(eng, n_files, n_crops, D, P):
+    """svhip_score_trials / svhip_mean_crops against the reference's per-trial expressions (torch on the CPU): cosine and pnorm
+    over aligned crops (utils.py:163-169), the cohorts_path=None pairwise distance over the (n, D, n) broadcast
+    (model.py:425-431), crop means; host arrays and device tensors."""
+    import torch.nn.functional as TF
+    rng = np.random.Generator(np.random.PCG64(n_files * 100 + n_crops))
+    F = rng.standard_normal((n_files, n_crops, D)).astype(np.float32)
+    F /= np.linalg.norm(F, axis=2, keepdims=True)
+    ia = rng.integers(0, n_files, P).astype(np.int32)
+    ib = rng.integers(0, n_files, P).astype(np.int32)
+    ib[0] = ia[0]
+    t = torch.from_numpy(F)
+    want = {
+        "cosine": [o_scoring.cosine_similarity(t[a], t[b]) for a, b in zip(ia, ib)],
+        "pnorm": [o_scoring.pnorm_similarity(t[a], t[b]) for a, b in zip(ia, ib)],
+        "pdist": [-float(torch.mean(TF.pairwise_distance(t[a].unsqueeze(-1), t[b].unsqueeze(-1).transpose(0, 2)))) for a, b in zip(ia, ib)],
+    }
+    Fd, iad, ibd = torch.from_numpy(F).cuda(), torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda()
+    for mode, w in want.items():
+        got = eng.score_trials(F, ia, ib, mode)
+        assert got.shape == (P,) and float(np.abs(got - np.array(w, np.float32)).max()) <= 2e-6, mode
+        gd = eng.score_trials(Fd, iad, ibd, mode)
+        assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got), mode
+    m = eng.mean_crops(F)
+    assert m.shape == (n_files, D) and float(np.abs(m - F.mean(axis=1)).max()) <= 1e-6
+    assert np.array_equal(eng.mean_crops(Fd).cpu().numpy(), m)
+    with pytest.raises(Exception):
+        eng.score_trials(F, np.array([n_files], np.int32), np.array([0], np.int32), "cosine")      # index out of range
