@@ -274,12 +274,15 @@ def make_engine(model, compute, B, local, embed=None):
 def dominant_label(model, compute, B=256):
     if model == "rawnet2":
         return "rn_block128"              # the fused 128-channel residual blocks: 41 % of the model's FLOPs in two launches
-    if compute != "bf16":
-        return "gemm_pw"                  # f32 / f32x3: the LDS-DMA kernel on fp32 operands
     # tdnn1 / tdnn2 / mfa: the persistent 256 x 256 kernel once a layer has more tiles than the chip has CUs (gemm_route), else
-    # the per-tile one
+    # the per-tile one; f32x3 handles: its X3 form (split-bf16 MFMA triples on pre-split operands); f32: the LDS-DMA fp32 kernel
     tiles = -(-B * 401 // 256) * (CHANNELS // 256)
-    return "gemm_pw3" if tiles > 256 and CHANNELS % 256 == 0 else "gemm_pw2"
+    persistent = tiles > 256 and CHANNELS % 256 == 0
+    if compute == "f32x3":
+        return "gemm_pw3x3" if persistent else "gemm_pw"
+    if compute != "bf16":
+        return "gemm_pw"
+    return "gemm_pw3" if persistent else "gemm_pw2"
 
 
 def roofline_of(prof, label, compute):
@@ -754,6 +757,7 @@ def run_batch(args, ranks, dev):
                              ("rawnet2_3_streams", lambda: multi_stream_bench("rawnet2", "bf16", B, local, dev, wavs)),
                              ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
                              ("ecapa_f32x3", lambda: sub_bench("ecapa", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
+                             ("rawnet2_f32x3", lambda: sub_bench("rawnet2", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
                              ("fusion", lambda: fusion_bench(B, local, dev, wavs)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:

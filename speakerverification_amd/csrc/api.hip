@@ -31,6 +31,8 @@ struct ConvLayer {            // one conv1d as a GEMM operand set (device pointe
     int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, dil = 1, cin = 0;
     void* W = nullptr;        // packed [Np][Kp] in the compute dtype
     void* Wsplit = nullptr;   // SVHIP_F32X3 handles: the same matrix as (hi bf16 << 16 | lo bf16) words, for gemm_pw's split path
+    void* Ws32 = nullptr;     // SVHIP_F32X3 handles, pointwise layers with N % 256 == 0 and K % 64 == 0: the S32 split layout (per row, per
+                              // 32 k: 32 hi bf16 | 32 lo bf16) of gemm_pw3's X3 form
     float* bias = nullptr;    // [N] or null
     float* scale = nullptr;   // folded BatchNorm (eval): y = x*scale + shift, or null
     float* shift = nullptr;
@@ -112,6 +114,8 @@ struct svhip_handle {
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
+    void* s32_buf = nullptr;      // SVHIP_F32X3: the A operand of the current big GEMM in the S32 split layout (M x 3C x 4 bytes)
+    void* cat_s32 = nullptr;      // SVHIP_F32X3: the SE-Res2Net block outputs (the CAT buffer) in the S32 layout, written by se_apply
     float* d_colsum = nullptr;    // pw2 column-sum partials, per lane: [sum | sumsq] x (tiles*4) x 3C floats
     int64_t colsum_region = 0;    // floats per (lane, kind) region
     bool last_colsum_done = false;
@@ -480,6 +484,19 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
             uint32_t* dsplit;
             if ((rc = dev_upload(h, &dsplit, ws))) return rc;
             L.Wsplit = dsplit;
+            if (taps == 1 && N % 256 == 0 && L.K == L.Kp && L.K % 64 == 0 && L.K >= 128) {
+                std::vector<uint16_t> s32((size_t)N * L.K * 2);
+                for (int n = 0; n < N; ++n)
+                    for (int k = 0; k < L.K; ++k) {
+                        const uint32_t wv = ws[(size_t)n * L.Kp + k];
+                        const size_t o = (size_t)n * L.K * 2 + (size_t)(k >> 5) * 64 + (k & 31);
+                        s32[o] = (uint16_t)(wv >> 16);
+                        s32[o + 32] = (uint16_t)(wv & 0xffffu);
+                    }
+                uint16_t* d32;
+                if ((rc = dev_upload(h, &d32, s32))) return rc;
+                L.Ws32 = d32;
+            }
         }
     }
     if (!bname.empty()) {
@@ -741,6 +758,8 @@ int alloc_workspace(svhip_handle* h) {
         if ((rc = dev_alloc(h, &h->d_ctx, B * 128))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_raw, B * 2 * C3))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_bn, B * 2 * C3))) return rc;
+        if (h->x3 && (rc = dev_alloc(h, reinterpret_cast<char**>(&h->s32_buf), M * C3 * 4 + 256))) return rc;
+        if (h->x3 && C % 32 == 0 && (rc = dev_alloc(h, reinterpret_cast<char**>(&h->cat_s32), M * C3 * 4 + 256))) return rc;
         h->colsum_region = (int64_t)((M + 255) / 256 + 2) * 16 * C3;
         if ((rc = dev_alloc(h, &h->d_colsum, (size_t)4 * h->colsum_region))) return rc;
     }
@@ -751,7 +770,7 @@ int alloc_workspace(svhip_handle* h) {
 int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void* A, int lda, void* Y, int ldy, int M,
               int act1, int act2 = ACT_NONE, const void* A2 = nullptr, int lda2 = 0, const float* bias_utt = nullptr,
               int ld_bu = 0, bool out_f32 = false, int T = 0, int pad_mode = PAD_REFLECT, const void* R = nullptr, int ldr = 0,
-              float* colsum = nullptr, int colsum_sq = 0, int64_t colsum_stride = 0) {
+              float* colsum = nullptr, int colsum_sq = 0, int64_t colsum_stride = 0, const void* A_s32 = nullptr, int lda_s32 = 0) {
     GemmParams p;
     p.colsum = colsum; p.colsum_sq = colsum_sq; p.colsum_stride = colsum_stride;
     h->last_colsum_done = false;
@@ -763,13 +782,26 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
     const bool bf = h->bf16;
+    hipStream_t st = h->cur;
+    (void)label;
+    p.num_cu = h->num_cu;
+    if (h->x3 && L.Ws32 && h->s32_buf && !A2 && !bias_utt && !out_f32 && !R) {
+        // the GELU layers of an F32X3 handle on the persistent 256 x 256 kernel: A is split into the S32 layout by one elementwise
+        // pass, W was split at load time
+        GemmParams q = p;
+        q.A = A_s32 ? A_s32 : h->s32_buf; q.lda = A_s32 ? lda_s32 : L.K; q.W = L.Ws32; q.x3 = 2;
+        if (gemm_pw3x3_supported(q)) {
+            int rc = A_s32 ? SVHIP_OK      // (the producer already wrote the split form: se_apply)
+                           : run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(A), lda, h->s32_buf, M, L.K, st); });
+            if (rc) return rc;
+            if (q.colsum) { h->last_colsum_done = true; h->last_colsum_groups = 2; }
+            return run(h, "gemm_pw3x3", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3x3(q, st); });
+        }
+    }
     if (h->x3) {              // gemm_pw takes the pre-split weights, the generic kernel (A2 / ragged shapes) the fp32 ones
         p.x3 = 1;
         if (gemm_pw_supported(p, false) && L.Wsplit) p.W = L.Wsplit;
     }
-    hipStream_t st = h->cur;
-    (void)label;
-    p.num_cu = h->num_cu;
     if (p.colsum) {                       // only the pw2 / pw3 epilogues produce the partials; otherwise the caller falls back
         if (gemm_pw2_supported(p, bf) && p.taps == 1) { h->last_colsum_done = true; h->last_colsum_groups = gemm_colsum_groups(p, bf); }
         else p.colsum = nullptr;
@@ -818,7 +850,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     float* d_pool_bn = h->d_pool_bn + (size_t)b0 * 2 * C3;
     float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     (void)d_s1;
-    float* cs_base = (bf && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
+    float* cs_base = ((bf || h->x3) && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
     int rc;
     if ((rc = run(h, "prologue", 0, [&]() {
              return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st);
@@ -826,8 +858,13 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     if ((rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
     const void* xin = X0;
     int ldin = C;
+    // F32X3: se_apply also leaves each block output in the S32 split layout (CAT's twin), so tdnn1 of the next block and mfa read
+    // their A operand without a conversion pass
+    char* cat32 = h->cat_s32 ? static_cast<char*>(h->cat_s32) + r0 * C3 * 4 : nullptr;
+    const void* xin32 = nullptr;
     for (int i = 0; i < 3; ++i) {
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, H1, C, M, ACT_GELU))) return rc;
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0, PAD_REFLECT,
+                            nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
         if (bf && res2net_chain_supported(C, T, h->res2[i][0].dil, h->res2[i][0].Kp)) {
             Res2Params rp;
             rp.H1 = H1; rp.H2 = H2; rp.ld = C; rp.T = T; rp.dil = h->res2[i][0].dil; rp.Kp = h->res2[i][0].Kp;
@@ -862,13 +899,15 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
                                       h->last_colsum_groups);
              }))) return rc;
         void* xout = off(CAT, (size_t)i * C, e);
-        if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st); })))
+        void* xout32 = cat32 ? cat32 + (size_t)i * C * 4 : nullptr;
+        if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st, xout32, C3); })))
             return rc;
         xin = xout;
+        xin32 = xout32;
         ldin = C3;
     }
     if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
-                        PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region))) return rc;
+                        PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region, cat32, C3))) return rc;
     if (h->last_colsum_done) {
         if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, true, B, T, C3, M, d_gstats, 1e-12f, st, h->last_colsum_groups); }))) return rc;
     } else {

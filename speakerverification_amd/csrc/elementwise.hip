@@ -317,10 +317,12 @@ __global__ __launch_bounds__(SE_MLP_THREADS) void se_mlp_kernel(const float* __r
 // so the gate s[b][c..] is loaded once per thread instead of once per output chunk (it was 2x the bytes of the output
 // through L1), and 4 frames' loads are in flight per thread.
 constexpr int SE_ROWS = 32;
+// (fp32 only: `s32` != null also writes the result in the S32 split layout — per row, per 32 channels: 32 hi bf16 | 32 lo bf16 —
+//  the A operand format of gemm_pw3's X3 form, so that the next GEMM needs no conversion pass)
 template <typename T>
 __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ s,
                                                        const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
-                                                       int Tn, int C) {
+                                                       int Tn, int C, char* __restrict__ s32, int ld32) {
     constexpr int VEC = Vec16<T>::N;
     const int cpr = C / VEC;                                  // chunks per row
     const int b = blockIdx.y;
@@ -339,6 +341,20 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), g[j], xv.get(j)));
             *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
+            if (VEC == 4 && s32) {
+                typedef bf16_t bf16x4_ __attribute__((ext_vector_type(4)));
+                bf16x4_ hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = o.get(j);
+                    const bf16_t hb = static_cast<bf16_t>(v);
+                    hi[j] = hb;
+                    lo[j] = static_cast<bf16_t>(v - static_cast<float>(hb));
+                }
+                char* q = s32 + m * (int64_t)ld32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
+                *reinterpret_cast<bf16x4_*>(q) = hi;
+                *reinterpret_cast<bf16x4_*>(q + 64) = lo;
+            }
         }
     }
 }
@@ -504,6 +520,38 @@ __global__ __launch_bounds__(256) void split_words_kernel(const float* __restric
     }
 }
 
+// fp32 rows -> the S32 split layout of gemm_pw3's X3 form: per row, per block of 32 k: 32 hi bf16 | 32 lo bf16 (128 bytes).
+// One thread = 8 consecutive k: 32 bytes in, 16 + 16 bytes out.
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K) {
+    const int per_row = K >> 3;
+    const int64_t n = M * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / per_row;
+        const int k0 = (int)(i - row * per_row) * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + row * ld + k0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + row * ld + k0 + 4);
+        typedef bf16_t bf16x8_ __attribute__((ext_vector_type(8)));
+        bf16x8_ hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = e < 4 ? a[e] : b[e - 4];
+            const bf16_t h = static_cast<bf16_t>(v);
+            hi[e] = h;
+            lo[e] = static_cast<bf16_t>(v - static_cast<float>(h));
+        }
+        char* o = dst + row * (int64_t)K * 4 + (k0 >> 5) * 128 + (k0 & 31) * 2;
+        *reinterpret_cast<bf16x8_*>(o) = hi;
+        *reinterpret_cast<bf16x8_*>(o + 64) = lo;
+    }
+}
+
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream) {
+    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
+    const int64_t g = (M * (K / 8) + 255) / 256;
+    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K);
+    return hipGetLastError();
+}
+
 hipError_t launch_split_words(const float* src, void* dst, int64_t n, hipStream_t stream) {
     if (!src || !dst || n <= 0) return hipErrorInvalidValue;
     const int64_t g = (n + 255) / 256;
@@ -542,12 +590,13 @@ hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void
 }
 
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
-                           bool bf16, int B, int T, int C, hipStream_t stream) {
+                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32, int ld32) {
     const int vec = bf16 ? 8 : 4;
     if (C % vec || ldh % vec || ldx % vec || ldo % vec || B <= 0 || T <= 0) return hipErrorInvalidValue;
+    if (s32 && (bf16 || C % 32 != 0 || ld32 % 32 != 0 || (reinterpret_cast<uintptr_t>(s32) & 127))) return hipErrorInvalidValue;
     dim3 grid((T + SE_ROWS - 1) / SE_ROWS, B), block(256);
-    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C);
-    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C);
+    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C, (char*)nullptr, 0);
+    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C, (char*)s32, ld32);
     return hipGetLastError();
 }
 

@@ -59,10 +59,17 @@ constexpr int ABL = PW3_ABL;
 constexpr int ABL = 0;
 #endif
 
-template <int EPI, int CS>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
+// X3 (SVHIP_F32X3 handles: fp32 storage, products as split-bf16 MFMA triples, ~2^-17 per product): A and W arrive in the "S32"
+// layout — per row, per block of 32 k: 32 hi bf16 | 32 lo bf16 (hi = bf16(v), lo = bf16(v - hi); 128 bytes, the bytes of the fp32
+// values they replace).  A 128-byte LDS row is then ONE 32-wide k block instead of a 64-wide one, the DMA stream, the ring, the
+// swizzle and the fragment reads are those of the bf16 kernel unchanged ("ks 0" reads the hi fragment, "ks 1" the lo one), and a
+// fragment pair takes three MFMAs (hi.hi + hi.lo + lo.hi) instead of two: 1.5 x the matrix work per byte staged, no conversion
+// instruction anywhere in the loop.  The epilogue is fp32: exact erf GELU, 16-byte fp32 stores straight from the accumulators.
+template <int EPI, int CS, bool X3>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NST = 16 + 8 * CS;                // vector-memory stores a wave issues in one tile's epilogue
+    constexpr int NST = (X3 ? 32 : 16) + 8 * CS;    // vector-memory stores a wave issues in one tile's epilogue
+    constexpr int ESZ = X3 ? 4 : 2;                 // bytes per k of an operand row
 
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     const int ntiles = ntm * ntn;
@@ -102,8 +109,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     for (int jj = 0; jj < 2; ++jj) dsto[jj] = (wave * 2 + jj) * 1024;
     auto set_src = [&](int m0, int n0) {
         const int lane = lane_now();
-        abase = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * 2;
-        wbase = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.Kp * 2;
+        abase = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * ESZ;
+        wbase = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.Kp * ESZ;
         const int mmax = p.M - 1 - m0, nmax = p.Wrows - 1 - n0;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
             for (int ty = 0; ty < 2; ++ty) {
                 const int m = min((rho >> 6) * 128 + ty * 64 + (rho & 63), mmax);
-                xo[ty][jj] = (uint32_t)(m * p.lda * 2 + c * 16);
+                xo[ty][jj] = (uint32_t)(m * p.lda * ESZ + c * 16);
                 const int n = min((rho >> 5) * 64 + ty * 32 + (rho & 31), nmax);
-                wo[ty][jj] = (uint32_t)(n * p.Kp * 2 + c * 16);
+                wo[ty][jj] = (uint32_t)(n * p.Kp * ESZ + c * 16);
             }
         }
     };
@@ -151,12 +158,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     };
     // five half-tiles AND the previous tile's NST stores (issued after this tile's first 14 DMAs) may stay in flight
     auto wait_relaxed = [&]() {
+        static_assert(NST == 16 || NST == 24 || NST == 32 || NST == 40 || NST == 48, "vmcnt(10 + NST)");
         if (NST == 16) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
         else if (NST == 24) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+        else if (NST == 32) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+        else if (NST == 40) asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(58)" ::: "memory");
     };
 
-    const int nkt = p.Kp / 64;                    // >= 4 (host check)
+    const int nkt = p.Kp * ESZ / 128;             // 128-byte K tiles per row: >= 4 and even (host check)
 
     unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;      // debug builds: cycles in {tile-start wait, K loop, next-tile issue, epilogue}
 #define PW3_STAMP(i) if (DBG3 && (p.debug & 16384) && p.ts) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
@@ -235,13 +245,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         else wait_left((left_ < 8 ? left_ : 8) - 3);                                                \
         __builtin_amdgcn_s_barrier();                                                               \
     }
+        // (X3: terms hi.hi, hi.lo, lo.hi of a fragment pair — [0] = hi, [1] = lo — term-major like the plain kernel's k steps)
 #define PW3_MFMA(I0, WARR, J0)                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                  \
     if (!(ABL & 1))                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+    _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks)                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
+                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][X3 ? (ks == 2) : ks], xf[i][X3 ? (ks == 1) : ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_s_barrier();
 #define PW3_KTILE(REM_, KT_, WCUR, WNXT, RLX_, HOOK)                                       \
@@ -313,7 +324,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         // ---- epilogue from the accumulators ---------------------------------------------------------------------------
         const int lane_e = lane_now();
         const int r16e = lane_e & 15, q4e = lane_e >> 4;
-        {
+        if (X3) {
+            // fp32 out: a lane's accumulator register group IS 16 contiguous bytes (4 channels of one frame)
+            float* Yf = reinterpret_cast<float*>(p.Y);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wn * 64 + j * 16 + 4 * q4e;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
+                float* yl = Yf + (int64_t)(m0 + wm * 128 + r16e) * p.ldy + n0 + nl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc16[i][j][e];
+                        if (!(ABL & 4)) {
+                            t = apply_act(t, EPI == EPI_GELU ? ACT_GELU : EPI == EPI_RELU ? ACT_RELU : ACT_NONE);     // nn.GELU() exact form
+                            t = fmaf(t, sc[e], sh[e]);
+                        }
+                        v[e] = t;
+                    }
+                    if (CS) acc16[i][j] = v;
+                    const int m = m0 + wm * 128 + i * 16 + r16e;
+                    if (m < p.M && !(ABL & 8)) *reinterpret_cast<f32x4*>(yl + (int64_t)i * 16 * p.ldy) = v;
+                }
+            }
+        } else {
             char* Yb = reinterpret_cast<char*>(p.Y);
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
@@ -456,21 +493,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #undef PW3_STAMP
 }
 
-template <int EPI, int CS>
+template <int EPI, int CS, bool X3>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS>), PW3_LDS)) return e;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS, X3>), PW3_LDS)) return e;
     const int cap = pw3_grid_cap(p.num_cu);
     const int grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS>), dim3(grid), dim3(512), PW3_LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS, X3>), dim3(grid), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
 }
 
-template <int EPI>
+template <int EPI, bool X3>
 hipError_t launch_cs(const GemmParams& p, hipStream_t stream) {
-    if (!p.colsum) return launch_inst<EPI, 0>(p, stream);
-    return p.colsum_sq ? launch_inst<EPI, 2>(p, stream) : launch_inst<EPI, 1>(p, stream);
+    if (!p.colsum) return launch_inst<EPI, 0, X3>(p, stream);
+    return p.colsum_sq ? launch_inst<EPI, 2, X3>(p, stream) : launch_inst<EPI, 1, X3>(p, stream);
 }
 
 }  // namespace
@@ -502,11 +539,30 @@ int pw3_grid_cap(int num_cu) {
 hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw3_supported(p, true) || p.M <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
     switch (p.act1) {
-        case ACT_NONE: return launch_cs<EPI_NONE>(p, stream);
-        case ACT_RELU: return launch_cs<EPI_RELU>(p, stream);
-        case ACT_GELU: return launch_cs<EPI_GELU>(p, stream);
+        case ACT_NONE: return launch_cs<EPI_NONE, false>(p, stream);
+        case ACT_RELU: return launch_cs<EPI_RELU, false>(p, stream);
+        case ACT_GELU: return launch_cs<EPI_GELU, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+// The X3 form (p.x3 == 2: A and W in the S32 split layout, fp32 out): the GELU layers of SVHIP_F32X3 handles
+bool gemm_pw3x3_supported(const GemmParams& p) {
+    if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.taps > 1) return false;
+    if (p.act1 != ACT_GELU || p.act2 != ACT_NONE) return false;
+    if (!p.bias || !p.scale || !p.shift) return false;
+    if (p.N % 256 != 0 || p.K != p.Kp || p.K % 64 != 0 || p.K < 128 || p.lda < p.K || p.lda % 32 != 0 || p.ldy % 4 != 0) return false;      // whole 32-k blocks, an even number of them
+    if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
+         reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
+    if (p.num_cu <= 0 || p.num_cu > 1024 || p.M <= 0 || p.Wrows < p.N) return false;
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    return ntiles > pw3_grid_cap(p.num_cu);
+}
+
+hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pw3x3_supported(p)) return hipErrorInvalidValue;
+    return launch_cs<EPI_GELU, true>(p, stream);
 }
 
 }  // namespace svhip

@@ -81,8 +81,9 @@ struct GemmParams {
     int taps = 1, dil = 1, cin = 0, pad_mode = 0;
     int act1 = 0, act2 = 0;
     int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
-    int x3 = 0;               // fp32 operands only: products as three bf16 MFMAs on hi / lo-split fragments.  gemm_pw then expects W as
-                              // (hi bf16 << 16 | lo bf16) words (ConvLayer::Wsplit); the generic kernel splits true fp32 W itself
+    int x3 = 0;               // fp32 operands only: products as three bf16 MFMAs on hi / lo-split fragments.  1: gemm_pw expects W as
+                              // (hi bf16 << 16 | lo bf16) words (ConvLayer::Wsplit), the generic kernel splits true fp32 W itself;
+                              // 2: A and W are both in the S32 split layout (gemm_pw3's X3 form, launch_gemm_pw3x3)
     int debug = 0;            // developer ablations (tools/gemm_bench): 1 no loads in the loop, 2 no MFMA, 4 no epilogue
     int Wrows = 0;            // allocated rows of W (loads clamp to Wrows-1); packed weights: N rounded up to 128
 };
@@ -115,6 +116,12 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream);
 int pw3_grid_cap(int num_cu);
+// the X3 form of the persistent kernel (x3 == 2): A (M, K) and W (N, K) in the S32 split layout (per row, per 32 k: 32 hi bf16 |
+// 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
+bool gemm_pw3x3_supported(const GemmParams& p);
+hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream);
+// fp32 (M, K) rows (stride ld) -> S32 layout (M, K) (4 bytes per element)
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream);
 // row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
 int gemm_colsum_groups(const GemmParams& p, bool bf16);
 
@@ -180,8 +187,9 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
                          const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream, int row_groups = 8);
 // out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
+// (fp32: s32 != null also writes out in the S32 split layout, row stride ld32 elements of 4 bytes: gemm_pw3's X3 A operand)
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
-                           bool bf16, int B, int T, int C, hipStream_t stream);
+                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32 = nullptr, int ld32 = 0);
 // reduce the pw2 column-sum partials: out (B, C) = mean over T  [and out (B, 2C) = [mean | std] with sq]
 hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
                                   float* out, float eps, hipStream_t stream, int row_groups = 8);

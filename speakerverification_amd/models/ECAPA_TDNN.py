@@ -11,6 +11,14 @@ from .. import synth
 from ._base import HipModule
 
 
+def _crop_samples(audio_spec):
+    """evaluation crops are sentence_len * sample_rate samples long (audio_loader.py:100-110)"""
+    try:
+        return int(audio_spec["sentence_len"] * audio_spec["sample_rate"])
+    except Exception:
+        return None
+
+
 class ECAPA_TDNN(HipModule):
     model_kind = "ecapa"
 
@@ -48,7 +56,7 @@ class ECAPA_TDNN(HipModule):
                          dict(channels=C, n_mels=n_mels, embed_dim=lin_neurons, log_input=self.log_input,
                               input_norm=self.input_norm, hop_length=hop, **fe),
                          device=device if device is not None else kwargs.get("device"), compute=compute,
-                         max_batch=max_batch)
+                         max_batch=max_batch, primary_samples=_crop_samples(kwargs.get("audio_spec")))
 
     def forward(self, x, lengths=None):
         """x: (B, n_mels, T) features, torch tensor (CPU / CUDA) or numpy.  lengths is ignored exactly as

@@ -29,7 +29,7 @@ class RawNet2(HipModule):
         max_batch = int(max_batch or kwargs.get("embed_batch", 256))
         super().__init__(synth.rawnet2_param_spec(nOut=nOut, nb_samp=self.nb_samp, att_dim=att_dim),
                          dict(embed_dim=nOut), device=device if device is not None else kwargs.get("device"),
-                         compute=compute, max_batch=max_batch)
+                         compute=compute, max_batch=max_batch, primary_samples=self.nb_samp)
 
     def forward(self, x):
         if x.ndim != 2 or x.shape[1] != self.nb_samp:

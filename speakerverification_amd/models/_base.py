@@ -32,7 +32,7 @@ class HipModule:
     accepts_device_wave = True      # forward / embed_wave take CUDA tensors as raw device pointers (no host copy)
     ENGINE_CACHE = 3                # handles kept alive at once (one per input geometry)
 
-    def __init__(self, spec, engine_kwargs, device=None, compute="f32", max_batch=256, seed=0):
+    def __init__(self, spec, engine_kwargs, device=None, compute="f32", max_batch=256, seed=0, primary_samples=None):
         from .. import synth
         self._spec = OrderedDict((n, tuple(s)) for n, s in spec)
         self._sd = synth.synth_state_dict(spec, seed=seed)        # random init, like a fresh nn.Module
@@ -41,7 +41,10 @@ class HipModule:
         self._max_batch = int(max_batch)
         self._device = _device_index(device)
         self._engines = OrderedDict()           # key -> Engine, most recently used last
-        self._primary = None                    # the geometry (samples) that gets the full max_batch workspace
+        # the geometry (samples) that gets the full max_batch workspace: the configured crop length when the constructor knows
+        # it (audio_spec), else the first length seen
+        self._primary_cfg = int(primary_samples) if primary_samples else None
+        self._primary = self._primary_cfg
         self.training = False
 
     # ---- nn.Module look-alikes --------------------------------------------------------------------
@@ -107,7 +110,7 @@ class HipModule:
         for eng in self._engines.values():
             eng.close()
         self._engines.clear()
-        self._primary = None
+        self._primary = self._primary_cfg
 
     @property
     def _engine(self):
@@ -115,8 +118,8 @@ class HipModule:
         return next(reversed(self._engines.values())) if self._engines else None
 
     def _get_engine(self, samples, stream=None, batch=None):
-        """One handle per input geometry.  The FIRST geometry seen (the fixed-length crops of evaluation) gets the full
-        `max_batch` workspace; any other length (whole-file evaluation, num_eval == 0: one forward per file, every file its
+        """One handle per input geometry.  The configured crop length (audio_spec: sentence_len * sample_rate; without it the
+        FIRST geometry seen) gets the full `max_batch` workspace; any other length (whole-file evaluation, num_eval == 0: one forward per file, every file its
         own length) gets a workspace sized for the rows of that call, and at most ENGINE_CACHE handles stay alive — a
         one-minute file no longer allocates a max_batch x 10^4-frame workspace, and a repeated length is not rebuilt."""
         if self._primary is None:

@@ -202,3 +202,52 @@ def test_persistent_gemm_matches_the_per_tile_kernel(C, B, cus, monkeypatch):
         x, y = stages["0"][n], stages[str(cus)][n]
         assert float(np.abs(x - y).max()) <= 2e-2 * max(1.0, float(np.abs(x).max())), n
         assert abs(float(np.abs(x).sum()) - float(np.abs(y).sum())) <= 1e-3 * float(np.abs(x).sum()), n
+
+
+@pytest.mark.parametrize("C,cus", [(512, 3), (1024, 5), (256, 2)])
+def test_f32x3_persistent_gemm_matches_reference(golden_dir, C, cus, monkeypatch):
+    """SVHIP_F32X3 handles run tdnn1 / tdnn2 / mfa on the persistent 256 x 256 kernel in its X3 form (operands in the S32 split
+    layout: hi.hi + hi.lo + lo.hi bf16 MFMA triples, fp32 storage, exact erf GELU, column sums from the accumulators) once a
+    layer has more tiles than the grid; SVHIP_PW3_CUS caps the grid so that the golden fixtures' small batch takes that route.
+    Same bars as the exact fp32 path: 1e-4 of the embedding scale, 1e-4 absolute on L2-normalised embeddings, and the
+    per-stage checksums of the reference."""
+    monkeypatch.setenv("SVHIP_PW3_CUS", str(cus))
+    if C == 256:
+        sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=11)
+        mel = synth.synth_mel(3, 80, 401, seed=12)
+        outs = {}
+        for compute in ("f32", "f32x3"):
+            eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=3)
+            eng.load_state_dict(sd)
+            eng.finalize()
+            eng.profile(True)
+            outs[compute] = eng.embed_features(mel)
+            labels = eng.profile_results()
+            eng.close()
+            assert ("gemm_pw3x3" in labels) == (compute == "f32x3"), labels
+        scale = float(np.abs(outs["f32"]).max())
+        assert float(np.abs(outs["f32"] - outs["f32x3"]).max()) <= 1e-4 * scale
+        return
+    g = np.load(os.path.join(golden_dir, f"ecapa_C{C}_T401.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    eng, _ = make_engine(C, T, B, "f32x3", int(g["seed_w"]))
+    mel = synth.synth_mel(B, 80, T, seed=int(g["seed_x"]))
+    eng.profile(True)
+    out = eng.embed_features(mel)
+    prof = eng.profile_results()
+    eng.profile(False)
+    assert prof["gemm_pw3x3"]["launches"] == 7 and prof["split_s32"]["launches"] == 4, prof.keys()      # (X0 and the three Res2Net outputs; se_apply writes the rest pre-split)
+    assert "se_mean" not in prof and "asp_gstats" not in prof          # the squeeze / global statistics come from the GEMM epilogue
+    ref = g["out"]
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(out - ref).max())
+    nrm = lambda a: a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+    err_n = float(np.abs(nrm(out) - nrm(ref)).max())
+    print(f"C={C} f32x3 on the persistent kernel: max|d_emb| = {err:.3e} (scale {scale:.1f}, relative {err / scale:.2e}); L2-normalised abs err {err_n:.3e}")
+    assert err <= 1e-4 * max(1.0, scale) and err_n <= 1e-4
+    for n in STAGES:
+        cs = g["cs_" + n]
+        got = stage_cf(eng, n, B, T).astype(np.float64)
+        assert abs(got.sum() - cs[0]) <= 1e-4 * cs[1] + 1e-3, n
+        assert abs(np.abs(got).sum() - cs[1]) <= 1e-4 * cs[1] + 1e-3, n
+    eng.close()

@@ -327,3 +327,16 @@ def test_libcomm_all_gather_rows_at_world_sizes_above_one(n, world, tail, as_tor
     assert sorted(w.inits) == sorted((b"\x07" * 128, r, world) for r in range(world))
     for r in range(world):
         assert res[r].shape == full.shape and np.array_equal(res[r], full), r
+
+
+def test_primary_engine_geometry_comes_from_the_configured_crop_length():
+    """the handle that gets the full max_batch workspace is the configured evaluation crop (audio_spec), not whichever
+    length happens to arrive first (a whole-file call would otherwise claim a max_batch x 10^4-frame workspace)."""
+    from speakerverification_amd.models import ECAPA_TDNN, RawNet2_custom
+    spec = {"sample_rate": 16000, "sentence_len": 2.0}
+    m = ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192], audio_spec=spec)
+    assert m._primary == 32000
+    m._drop_engine()
+    assert m._primary == 32000
+    assert ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192])._primary is None          # unknown until the first call
+    assert RawNet2_custom.MainModel(nOut=320, front_proc="sinc", aggregate="asp", audio_spec=spec)._primary == 32000
