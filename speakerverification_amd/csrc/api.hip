@@ -116,6 +116,8 @@ struct svhip_handle {
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
     void* s32_buf = nullptr;      // SVHIP_F32X3: the A operand of the current big GEMM in the S32 split layout (M x 3C x 4 bytes)
     void* cat_s32 = nullptr;      // SVHIP_F32X3: the SE-Res2Net block outputs (the CAT buffer) in the S32 layout, written by se_apply
+    void* h2_s32 = nullptr;       // SVHIP_F32X3: the Res2Net chain output (H2's twin, S32 only) and the two step-input buffers (M x C/8)
+    void* u_s32[2] = {};
     float* d_colsum = nullptr;    // pw2 column-sum partials, per lane: [sum | sumsq] x (tiles*4) x 3C floats
     int64_t colsum_region = 0;    // floats per (lane, kind) region
     bool last_colsum_done = false;
@@ -484,7 +486,9 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
             uint32_t* dsplit;
             if ((rc = dev_upload(h, &dsplit, ws))) return rc;
             L.Wsplit = dsplit;
-            if (taps == 1 && N % 256 == 0 && L.K == L.Kp && L.K % 64 == 0 && L.K >= 128) {
+            // pointwise GELU layers (gemm_pw3's X3 form) and the Res2Net convolutions (its R2 form: N == cin, k = 3)
+            if ((taps == 1 && N % 256 == 0 && L.K == L.Kp && L.K % 64 == 0 && L.K >= 128) ||
+                (taps == 3 && N == cin && (cin == 64 || cin == 128) && L.K == L.Kp)) {
                 std::vector<uint16_t> s32((size_t)N * L.K * 2);
                 for (int n = 0; n < N; ++n)
                     for (int k = 0; k < L.K; ++k) {
@@ -760,6 +764,10 @@ int alloc_workspace(svhip_handle* h) {
         if ((rc = dev_alloc(h, &h->d_pool_bn, B * 2 * C3))) return rc;
         if (h->x3 && (rc = dev_alloc(h, reinterpret_cast<char**>(&h->s32_buf), M * C3 * 4 + 256))) return rc;
         if (h->x3 && C % 32 == 0 && (rc = dev_alloc(h, reinterpret_cast<char**>(&h->cat_s32), M * C3 * 4 + 256))) return rc;
+        if (h->x3 && (C == 512 || C == 1024)) {
+            if ((rc = dev_alloc(h, reinterpret_cast<char**>(&h->h2_s32), M * C * 4 + 256))) return rc;
+            for (int i = 0; i < 2; ++i) if ((rc = dev_alloc(h, reinterpret_cast<char**>(&h->u_s32[i]), M * (C / 8) * 4 + 256))) return rc;
+        }
         h->colsum_region = (int64_t)((M + 255) / 256 + 2) * 16 * C3;
         if ((rc = dev_alloc(h, &h->d_colsum, (size_t)4 * h->colsum_region))) return rc;
     }
@@ -798,6 +806,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
             return run(h, "gemm_pw3x3", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3x3(q, st); });
         }
     }
+    if (!A) SV_FAIL(h, SVHIP_ERR_STATE, "%s: the operand exists only in the split layout and the kernel that reads it does not take this shape", label);
     if (h->x3) {              // gemm_pw takes the pre-split weights, the generic kernel (A2 / ragged shapes) the fp32 ones
         p.x3 = 1;
         if (gemm_pw_supported(p, false) && L.Wsplit) p.W = L.Wsplit;
@@ -865,7 +874,37 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     for (int i = 0; i < 3; ++i) {
         if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0, PAD_REFLECT,
                             nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
-        if (bf && res2net_chain_supported(C, T, h->res2[i][0].dil, h->res2[i][0].Kp)) {
+        const void* h2_32 = nullptr;      // F32X3: the chain output in the S32 layout (tdnn2's A operand)
+        bool r2_done = false;
+        if (h->x3 && h->h2_s32 && h->res2[i][0].Ws32) {
+            // F32X3: seven launches of gemm_pw3's Res2Net step form; step j reads U_j = c_j + y_{j-1} (S32) and writes y_j (S32, into the
+            // chain output) and U_{j+1}; no fp32 copy of the chain exists
+            char* h2s = static_cast<char*>(h->h2_s32) + r0 * C * 4;
+            char* us[2] = {static_cast<char*>(h->u_s32[0]) + r0 * C8 * 4, static_cast<char*>(h->u_s32[1]) + r0 * C8 * 4};
+            auto step_params = [&](int j) {
+                const ConvLayer& L = h->res2[i][j - 1];
+                GemmParams q;
+                q.A = us[(j - 1) & 1]; q.lda = C8; q.W = L.Ws32; q.Wrows = L.N; q.x3 = 2;
+                q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
+                q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.T = T; q.taps = 3; q.dil = L.dil; q.cin = L.cin; q.pad_mode = PAD_REFLECT;
+                q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+                q.Y = h2s + (size_t)j * C8 * 4; q.ldy = C;
+                if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
+                return q;
+            };
+            if (gemm_pw3r2_supported(step_params(1))) {
+                if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1), C, h2s, M, C8, st, C); }))) return rc;
+                if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1) + C8, C, us[0], M, C8, st, C8); }))) return rc;
+                for (int j = 1; j < 8; ++j) {
+                    const GemmParams q = step_params(j);
+                    if ((rc = run(h, "gemm_pw3r2", (double)M * h->res2[i][j - 1].flops_per_row, [&]() { return launch_gemm_pw3r2(q, st); }))) return rc;
+                }
+                h2_32 = h2s;
+                r2_done = true;
+            }
+        }
+        if (r2_done) {
+        } else if (bf && res2net_chain_supported(C, T, h->res2[i][0].dil, h->res2[i][0].Kp)) {
             Res2Params rp;
             rp.H1 = H1; rp.H2 = H2; rp.ld = C; rp.T = T; rp.dil = h->res2[i][0].dil; rp.Kp = h->res2[i][0].Kp;
             double fl = 0;
@@ -886,8 +925,8 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
             }
         }
         // tdnn2; its epilogue also leaves per-utterance column sums (the SE squeeze) when the pw2 kernel runs
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], H2, C, H3, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
-                            PAD_REFLECT, nullptr, 0, cs_base, 0, h->colsum_region))) return rc;
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn2[i], r2_done ? nullptr : H2, C, H3, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
+                            PAD_REFLECT, nullptr, 0, cs_base, 0, h->colsum_region, h2_32, C))) return rc;
         const bool from_part = h->last_colsum_done;      // the squeeze comes straight from the GEMM's column-sum partials
         if (!from_part) {
             if ((rc = run(h, "se_mean", 0, [&]() { return launch_colmean(H3, bf, C, B, T, C, d_mean, st); }))) return rc;

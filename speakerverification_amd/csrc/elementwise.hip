@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void split_words_kernel(const float* __restric
 
 // fp32 rows -> the S32 split layout of gemm_pw3's X3 form: per row, per block of 32 k: 32 hi bf16 | 32 lo bf16 (128 bytes).
 // One thread = 8 consecutive k: 32 bytes in, 16 + 16 bytes out.
-__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K) {
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K, int ldd) {
     const int per_row = K >> 3;
     const int64_t n = M * per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -539,16 +539,17 @@ __global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict_
             hi[e] = h;
             lo[e] = static_cast<bf16_t>(v - static_cast<float>(h));
         }
-        char* o = dst + row * (int64_t)K * 4 + (k0 >> 5) * 128 + (k0 & 31) * 2;
+        char* o = dst + row * (int64_t)ldd * 4 + (k0 >> 5) * 128 + (k0 & 31) * 2;
         *reinterpret_cast<bf16x8_*>(o) = hi;
         *reinterpret_cast<bf16x8_*>(o + 64) = lo;
     }
 }
 
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream) {
-    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd) {
+    if (ldd == 0) ldd = K;
+    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0 || ldd % 32 != 0 || ldd < K) return hipErrorInvalidValue;
     const int64_t g = (M * (K / 8) + 255) / 256;
-    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K);
+    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K, ldd);
     return hipGetLastError();
 }
 

@@ -65,13 +65,26 @@ constexpr int ABL = 0;
 // swizzle and the fragment reads are those of the bf16 kernel unchanged ("ks 0" reads the hi fragment, "ks 1" the lo one), and a
 // fragment pair takes three MFMAs (hi.hi + hi.lo + lo.hi) instead of two: 1.5 x the matrix work per byte staged, no conversion
 // instruction anywhere in the loop.  The epilogue is fp32: exact erf GELU, 16-byte fp32 stores straight from the accumulators.
-template <int EPI, int CS, bool X3>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
+//
+// R2 (X3 only): one step of a Res2Net chain (models/ECAPA_TDNN.py:118-129) — y_j = BN(ReLU(conv_k3_dilated(U_j))) with U_j =
+// c_j + y_{j-1} already in the S32 layout (M, cin): the X half-tiles are the im2col view of the dilated convolution (a 128-byte K
+// tile lies inside ONE tap, so the tap shift is uniform per K tile and only the per-lane source row moves: reflect(t + (tap - 1)
+// dil) inside the lane's utterance); N = cin <= 128 fills the two left wave columns of the 256 x 256 tile (the right two
+// multiply clamped weight rows and store nothing); the epilogue writes y_j in the S32 layout into the chain output (the next
+// GEMM's A operand: no fp32 copy exists) and U_{j+1} = y_j + c_{j+1} (c from the fp32 tdnn1 output) into the next step's input.
+// Measured (round 3, C = 1024, B = 256: 117 us per step, 86 TFLOP/s of reference FLOPs): not bound by the matrix pipe — the
+// same build without MFMAs takes 93 us, without the c loads 97 — but by the skeleton of a 12-K-tile problem on 401 tiles (two
+// rounds of a 256-workgroup grid, an epilogue of 128 eight-byte stores and 32 cold 16-byte loads per wave).  An L2 prefetch of the
+// c rows by LDS-DMA at the start of the tile did not help (2.75 against 2.46 ms per 21 steps).  What the form buys is that the
+// chain lives in the split layout end to end: no conversion pass in front of tdnn2.
+template <int EPI, int CS, bool X3, bool R2 = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
+    static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = (X3 ? 32 : 16) + 8 * CS;    // vector-memory stores a wave issues in one tile's epilogue
     constexpr int ESZ = X3 ? 4 : 2;                 // bytes per k of an operand row
 
-    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+    const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
     const int ntiles = ntm * ntn;
     const int G = gridDim.x;
     int perm = blockIdx.x;                          // position in a round: contiguous band per XCD (bijective for any G)
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     // per-lane byte offset (row within the tile, clamped to the matrix, and the swizzled 16-byte chunk): 8 VGPRs, no 64-bit
     // vector adds in the loop
     uint32_t xo[2][2], wo[2][2];
+    uint32_t xt[2] = {0, 0};                       // R2: frame index (inside its utterance) of the lane's X rows, [jj] = lo | hi << 16
     const char* abase = nullptr;
     const char* wbase = nullptr;
     int dsto[2];
@@ -109,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     for (int jj = 0; jj < 2; ++jj) dsto[jj] = (wave * 2 + jj) * 1024;
     auto set_src = [&](int m0, int n0) {
         const int lane = lane_now();
-        abase = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * p.lda * ESZ;
+        // (R2: the gathered rows lie up to 2 dil <= 8 rows before the lane's own; the base sits 8 rows low so that offsets stay >= 0)
+        abase = reinterpret_cast<const char*>(p.A) + ((int64_t)m0 - (R2 ? 8 : 0)) * p.lda * ESZ;
         wbase = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.Kp * ESZ;
         const int mmax = p.M - 1 - m0, nmax = p.Wrows - 1 - n0;
 #pragma unroll
@@ -119,18 +134,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
             for (int ty = 0; ty < 2; ++ty) {
                 const int m = min((rho >> 6) * 128 + ty * 64 + (rho & 63), mmax);
-                xo[ty][jj] = (uint32_t)(m * p.lda * ESZ + c * 16);
+                xo[ty][jj] = (uint32_t)((m + (R2 ? 8 : 0)) * p.lda * ESZ + c * 16);
+                if (R2) { const int t = (m0 + m) % p.T; xt[jj] = ty == 0 ? (uint32_t)t : (xt[jj] | ((uint32_t)t << 16)); }
                 const int n = min((rho >> 5) * 64 + ty * 32 + (rho & 31), nmax);
                 wo[ty][jj] = (uint32_t)(n * p.Kp * ESZ + c * 16);
             }
         }
     };
+    const int r2_shift = R2 ? __builtin_ctz((unsigned)(p.cin >> 5)) : 0;      // K tiles per tap = cin / 32 (a power of two: host check)
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
-        const char* ub = (ty < 2 ? abase : wbase) + (int64_t)kt * 128;
+        const bool gather = R2 && ty < 2;
+        const int tap = gather ? (kt >> r2_shift) : 0;
+        const char* ub = (ty < 2 ? abase : wbase) + (int64_t)(gather ? (kt - (tap << r2_shift)) : kt) * 128;
+        const int shift = gather ? (tap - 1) * p.dil : 0;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             uint32_t o = ty < 2 ? xo[ty][jj] : wo[ty - 2][jj];
+            if (gather) {       // the row of frame reflect(t + shift) of the same utterance: a few rows either way (int32 arithmetic)
+                const int t = (int)((xt[jj] >> (ty * 16)) & 0xffffu);
+                const int d = reflect_idx(t + shift, p.T) - t;
+                o = (uint32_t)((int)o + d * p.lda * ESZ);
+            }
             asm volatile("" : "+v"(o));          // the zero-extension stays in this block: SGPR base + 32-bit VGPR offset addressing
             const char* s = ub + o;
             if (!(ABL & 2)) __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(base + dsto[jj]), 16, 0, 0);
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     // every operand DMA of the tile, so the tile's first counted wait covers them)
     auto issue_consts = [&](int n0, int par) {
         if (wave < 3) {
-            const float* s = (wave == 0 ? p.bias : wave == 1 ? p.scale : p.shift) + n0 + lane_now() * 4;
+            const float* s = (wave == 0 ? p.bias : wave == 1 ? p.scale : p.shift) + min(n0 + lane_now() * 4, p.N - 4);      // (N < 256: the R2 form)
             __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + RING + par * CST + wave * 1024), 16, 0, 0);
         }
     };
@@ -324,7 +349,63 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         // ---- epilogue from the accumulators ---------------------------------------------------------------------------
         const int lane_e = lane_now();
         const int r16e = lane_e & 15, q4e = lane_e >> 4;
-        if (X3) {
+        if (R2) {
+            // Res2Net step: y = BN(ReLU(.)) in the S32 layout into the chain output; U_next = y + c_next (fp32 chunk of the tdnn1
+            // output) in the S32 layout into the next step's input.  Only the wave columns that hold channels store anything.
+            if (wn * 64 < p.N) {
+                typedef bf16_t bf16x4_ __attribute__((ext_vector_type(4)));
+                char* Yb = reinterpret_cast<char*>(p.Y);
+                char* Ub = reinterpret_cast<char*>(p.Y2);
+                const float* Cn = reinterpret_cast<const float*>(p.R);
+                auto split4 = [](const f32x4& v, bf16x4_& hi, bf16x4_& lo) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16_t hb = static_cast<bf16_t>(v[e]);
+                        hi[e] = hb;
+                        lo[e] = static_cast<bf16_t>(v[e] - static_cast<float>(hb));
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nl = wn * 64 + j * 16 + 4 * q4e;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
+                    const int boff = (nl >> 5) * 128 + (nl & 31) * 2;
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih) {           // four frames at a time: their c loads are in flight together
+                        f32x4 cn[4];
+                        if (Ub) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int m = min(m0 + wm * 128 + (ih * 4 + i) * 16 + r16e, p.M - 1);
+                                if (ABL & 512) cn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                else cn[i] = *reinterpret_cast<const f32x4*>(Cn + (int64_t)m * p.ldr + nl);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int m = m0 + wm * 128 + (ih * 4 + i) * 16 + r16e;
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(acc16[ih * 4 + i][j][e], 0.0f), sc[e], sh[e]);
+                            if (m < p.M && !(ABL & 8)) {
+                                bf16x4_ hi, lo;
+                                split4(v, hi, lo);
+                                char* q = Yb + (int64_t)m * p.ldy * 4 + boff;
+                                *reinterpret_cast<bf16x4_*>(q) = hi;
+                                *reinterpret_cast<bf16x4_*>(q + 64) = lo;
+                                if (Ub) {
+                                    split4(v + cn[i], hi, lo);
+                                    char* u = Ub + (int64_t)m * p.lda2 * 4 + boff;
+                                    *reinterpret_cast<bf16x4_*>(u) = hi;
+                                    *reinterpret_cast<bf16x4_*>(u + 64) = lo;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (X3) {
             // fp32 out: a lane's accumulator register group IS 16 contiguous bytes (4 channels of one frame)
             float* Yf = reinterpret_cast<float*>(p.Y);
 #pragma unroll
@@ -476,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         ++ntile_done;
         if (!more) break;
         // every row of the tile just stored was inside M: each wave issued exactly NST stores behind the K loop's DMAs
-        relaxed = !(ABL & 128) && !(ABL & 8) && (m0 + 256 <= p.M);
+        relaxed = !R2 && !(ABL & 128) && !(ABL & 8) && (m0 + 256 <= p.M);       // (R2: the store count differs from wave to wave)
         w = w_next; tm = tm_n; tn = tn_n;
     }
     if (DBG3 && (p.debug & 16384) && p.ts) {
@@ -558,6 +639,33 @@ bool gemm_pw3x3_supported(const GemmParams& p) {
     if (p.num_cu <= 0 || p.num_cu > 1024 || p.M <= 0 || p.Wrows < p.N) return false;
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     return ntiles > pw3_grid_cap(p.num_cu);
+}
+
+// One step of a Res2Net chain on F32X3 handles (the R2 form): A = U_j (M, cin) S32, W = the step's conv weight (cin, 3 cin) S32
+// (k = tap * cin + c), Y = chain output in S32 (row stride ldy elements, the chunk's column offset in the pointer), and with
+// R / Y2: R = the next chunk of the fp32 tdnn1 output (row stride ldr), Y2 = U_{j+1} (M, lda2) S32.
+bool gemm_pw3r2_supported(const GemmParams& p) {
+    if (p.x3 != 2 || p.taps != 3 || p.A2 || p.A3 || p.bias_utt || p.colsum || p.out_f32) return false;
+    if (!(p.cin == 64 || p.cin == 128) || p.N != p.cin || p.K != 3 * p.cin || p.Kp != p.K) return false;
+    if (p.act1 != ACT_RELU || p.act2 != ACT_NONE || p.pad_mode != PAD_REFLECT) return false;
+    if (!p.bias || !p.scale || !p.shift || !p.Y) return false;
+    if ((p.R == nullptr) != (p.Y2 == nullptr)) return false;
+    if (p.lda < p.cin || p.lda % 32 != 0 || p.ldy % 32 != 0 || (p.Y2 && (p.lda2 % 32 != 0 || p.ldr % 4 != 0))) return false;
+    if (p.T <= 2 * p.dil || p.dil < 1 || p.dil > 4 || p.T >= 65536 || p.M <= 0 || p.M % p.T != 0 || p.Wrows < p.N) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.Y2) |
+         reinterpret_cast<uintptr_t>(p.R) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
+    if (p.num_cu <= 0 || p.num_cu > 1024) return false;
+    return (p.M + 255) / 256 > pw3_grid_cap(p.num_cu);
+}
+
+hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pw3r2_supported(p)) return hipErrorInvalidValue;
+    const int ntiles = (p.M + 255) / 256;
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_RELU, 0, true, true>), PW3_LDS)) return e;
+    const int cap = pw3_grid_cap(p.num_cu);
+    hipLaunchKernelGGL((gemm_pw3_kernel<EPI_RELU, 0, true, true>), dim3(ntiles < cap ? ntiles : cap), dim3(512), PW3_LDS, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream) {

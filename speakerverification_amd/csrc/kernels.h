@@ -67,6 +67,7 @@ struct GemmParams {
     int colsum_sq = 0;
     int64_t colsum_stride = 0;
     const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
+    void* Y2 = nullptr;             // gemm_pw3's Res2Net step form only: second output (the next step's input), row stride lda2
     const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last
     int ldr = 0;
     // conv-gather GEMMs on the 256 x 256 bf16 kernel only: K3 extra K columns appended after the taps * cin conv columns, read
@@ -120,8 +121,11 @@ int pw3_grid_cap(int num_cu);
 // 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream);
-// fp32 (M, K) rows (stride ld) -> S32 layout (M, K) (4 bytes per element)
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream);
+// one Res2Net step of an F32X3 handle on the same kernel (dilated k = 3 conv gathered from an S32 input, outputs in S32)
+bool gemm_pw3r2_supported(const GemmParams& p);
+hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream);
+// fp32 (M, K) rows (stride ld) -> S32 layout, rows of ldd elements (4 bytes each; 0: dense, ldd = K)
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0);
 // row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
 int gemm_colsum_groups(const GemmParams& p, bool bf16);
 
