@@ -14,6 +14,14 @@
 //   3. the 32 x n_bins power tile goes through LDS (stride 289: conflict-free both ways) and the
 //      sparse triangular mel filters are applied from there; frames are written coalesced along T.
 // Only the non-zero window taps (200 of 512) are multiplied.
+// Pipe counters of the bf16x3 form at B = 256 (round 3, profiles/r03_pipe_counters.json; 190 - 230 us by box): matrix pipe busy
+// 0.17 of the CU cycles, LDS array 6.5 %, 47 M vector instructions per launch against 2.3 M MFMAs (4.7 k per wave: sample staging
+// with its reflect arithmetic, basis addressing, a correctly rounded software sqrt per bin, the sparse mel sums), and the waves
+// spend 49 % of their cycles in s_waitcnt / barriers: three-wave workgroups of 10 us each, 2.25 waves per SIMD, every k step
+// a round trip to L2 for 12 KB of basis per wave.  Two cuts of the vector work alone (|X|^2 as re^2 + im^2 on the split path,
+// one running basis offset per k step) measured 205 against 190 us on one box (tools/fbank_bench.py) and were not kept: the
+// kernel is latency-bound, not issue-bound.  The structural fix (9-wave workgroups of 128 frames so that a basis fragment feeds
+// 12 MFMAs instead of 3) is the open lead.
 #include "common.h"
 #include "kernels.h"
 
