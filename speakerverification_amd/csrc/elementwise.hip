@@ -373,64 +373,73 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ sr
 
 // ---- attentive statistics pooling (softmax over T, weighted mean / std, BatchNorm) --------------
 // grid (ceil(C / 64), B), block 256: lane = channel, wave w takes frames t = w, w+4, ...
+// ONE pass over the logits and X (each 4 B C T per utterance: the kernel is HBM-bound, and a second pass for the variance
+// doubled its bytes): online softmax (running max, rescaled sums) with the weighted mean and the weighted sum of squared
+// deviations kept in West's incremental form (mean += (w / W) d, M2 += w d (x - mean)): as stable as the two-pass
+// form, one exp and one division per element.  The four waves' partial states are merged with the pairwise update.
 template <typename T>
 __global__ __launch_bounds__(256) void asp_pool_kernel(const float* __restrict__ logits, const T* __restrict__ X, int ldx,
                                                        int Tn, int C, const float* __restrict__ bn_scale,
                                                        const float* __restrict__ bn_shift, float* __restrict__ pooled_raw,
                                                        float* __restrict__ pooled_bn, float eps) {
-    __shared__ float smx[4][64], sse[4][64], ssx[4][64];
+    __shared__ float smx[4][64], sse[4][64], smean[4][64], sm2[4][64];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool ok = c < C;
     const float* __restrict__ lg = logits + (int64_t)b * Tn * C + c;
     const T* __restrict__ xp = X + (int64_t)b * Tn * ldx + c;
-    // pass 1: online softmax statistics
-    float mx = -INFINITY, se = 0.0f, sx = 0.0f;
-    if (ok)
-        for (int t = wave; t < Tn; t += 4) {
-            const float a = lg[(int64_t)t * C];
-            const float xv = to_f32<T>(xp[(int64_t)t * ldx]);
-            if (a > mx) {
-                const float f = expf(mx - a);     // exp(-inf) = 0 on the first frame
-                se *= f;
-                sx *= f;
-                mx = a;
-            }
-            const float e = expf(a - mx);
-            se += e;
-            sx = fmaf(e, xv, sx);
-        }
-    smx[wave][lane] = mx; sse[wave][lane] = se; ssx[wave][lane] = sx;
-    __syncthreads();
-    float M = fmaxf(fmaxf(smx[0][lane], smx[1][lane]), fmaxf(smx[2][lane], smx[3][lane]));
-    float SE = 0.0f, SX = 0.0f;
+    float mx = -INFINITY, se = 0.0f, mean = 0.0f, m2 = 0.0f;
+    if (ok) {
+        // four frames' loads in flight per lane
+        for (int t0 = wave; t0 < Tn; t0 += 16) {
+            float a[4], xv[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float f = (smx[w][lane] == -INFINITY) ? 0.0f : expf(smx[w][lane] - M);
-        SE = fmaf(sse[w][lane], f, SE);
-        SX = fmaf(ssx[w][lane], f, SX);
-    }
-    const float mean = SX / SE;
-    __syncthreads();
-    // pass 2: weighted variance around the weighted mean
-    float sv = 0.0f;
-    if (ok)
-        for (int t = wave; t < Tn; t += 4) {
-            const float a = lg[(int64_t)t * C];
-            const float d = to_f32<T>(xp[(int64_t)t * ldx]) - mean;
-            sv = fmaf(expf(a - M), d * d, sv);
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + 4 * u, Tn - 1);
+                a[u] = lg[(int64_t)t * C];
+                xv[u] = to_f32<T>(xp[(int64_t)t * ldx]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + 4 * u >= Tn) break;
+                if (a[u] > mx) {
+                    const float f = expf(mx - a[u]);     // exp(-inf) = 0 on the first frame
+                    se *= f;
+                    m2 *= f;
+                    mx = a[u];
+                }
+                const float e = expf(a[u] - mx);
+                se += e;
+                const float d = xv[u] - mean;
+                mean = fmaf(e / se, d, mean);
+                m2 = fmaf(e * d, xv[u] - mean, m2);
+            }
         }
-    sse[wave][lane] = sv;
+    }
+    smx[wave][lane] = mx; sse[wave][lane] = se; smean[wave][lane] = mean; sm2[wave][lane] = m2;
     __syncthreads();
     if (wave == 0 && ok) {
-        const float var = (sse[0][lane] + sse[1][lane] + sse[2][lane] + sse[3][lane]) / SE;
-        const float sd = sqrtf(fmaxf(var, eps));
+        const float M = fmaxf(fmaxf(smx[0][lane], smx[1][lane]), fmaxf(smx[2][lane], smx[3][lane]));
+        float SE = 0.0f, MEAN = 0.0f, M2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = (smx[w][lane] == -INFINITY) ? 0.0f : expf(smx[w][lane] - M);
+            const float sw = sse[w][lane] * f;
+            if (sw > 0.0f) {
+                const float tot = SE + sw;
+                const float d = smean[w][lane] - MEAN;
+                M2 += sm2[w][lane] * f + d * d * (SE * sw / tot);
+                MEAN = fmaf(sw / tot, d, MEAN);
+                SE = tot;
+            }
+        }
+        const float sd = sqrtf(fmaxf(M2 / SE, eps));
         if (pooled_raw) {
-            pooled_raw[(int64_t)b * 2 * C + c] = mean;
+            pooled_raw[(int64_t)b * 2 * C + c] = MEAN;
             pooled_raw[(int64_t)b * 2 * C + C + c] = sd;
         }
-        pooled_bn[(int64_t)b * 2 * C + c] = fmaf(mean, bn_scale[c], bn_shift[c]);
+        pooled_bn[(int64_t)b * 2 * C + c] = fmaf(MEAN, bn_scale[c], bn_shift[c]);
         pooled_bn[(int64_t)b * 2 * C + C + c] = fmaf(sd, bn_scale[C + c], bn_shift[C + c]);
     }
 }

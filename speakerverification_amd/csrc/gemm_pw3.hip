@@ -72,11 +72,13 @@ constexpr int ABL = 0;
 // dil) inside the lane's utterance); N = cin <= 128 fills the two left wave columns of the 256 x 256 tile (the right two
 // multiply clamped weight rows and store nothing); the epilogue writes y_j in the S32 layout into the chain output (the next
 // GEMM's A operand: no fp32 copy exists) and U_{j+1} = y_j + c_{j+1} (c from the fp32 tdnn1 output) into the next step's input.
-// Measured (round 3, C = 1024, B = 256: 117 us per step, 86 TFLOP/s of reference FLOPs): not bound by the matrix pipe — the
-// same build without MFMAs takes 93 us, without the c loads 97 — but by the skeleton of a 12-K-tile problem on 401 tiles (two
-// rounds of a 256-workgroup grid, an epilogue of 128 eight-byte stores and 32 cold 16-byte loads per wave).  An L2 prefetch of the
-// c rows by LDS-DMA at the start of the tile did not help (2.75 against 2.46 ms per 21 steps).  What the form buys is that the
-// chain lives in the split layout end to end: no conversion pass in front of tdnn2.
+// Measured (round 3, C = 1024, B = 256; tools/r2_bench with the kernel's stage stamps): 100 us per step, 100 TFLOP/s of reference
+// FLOPs.  Per tile (85 k cycles): K loop 44.7 k (12 K tiles; the matrix pipe is 83 % busy in it, half of that on the empty wave
+// columns), epilogue 35.6 k, start 4.4 k; 401 tiles are 1.57 per workgroup, i.e. two rounds.  The epilogue is bound by the CU's
+// store path: a wave instruction here writes 64 separate 16-byte pieces (16 rows x {hi, lo} x 2 channel groups), 256 of them per
+// tile.  History: c_next loaded straight into registers between the stores 52 k cycles (every load's wait also waited for all
+// earlier stores); an L2 prefetch of the c rows by LDS-DMA no gain; the c tile through the ring + 16-byte swapped stores 35.6 k.
+// Open lead: stage y / U through the ring as whole rows and let all eight waves copy them out in 128-byte runs.
 template <int EPI, int CS, bool X3, bool R2 = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         const char* cb = smem + RING + par * CST;
         const int w_next = w + G;
         const bool more = w_next < ntiles;
+        const bool pf = more && !R2;            // the stream runs on into the next tile (R2: its epilogue needs the ring, see there)
         int tm_n = 0, tn_n = 0;
         if (more) tile_of(w_next, tm_n, tn_n);
         PW3_STAMP(0)
@@ -263,10 +266,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         constexpr int left_ = 4 * rem - (gidx);                                                     \
         constexpr int pp_ = ((gidx) + 6) & 3;                                                       \
         const int kk_ = kt + (((gidx) + 6) >> 2) - kbias;                                           \
-        if (left_ > 7 || more) {                                                                    \
+        if (left_ > 7 || pf) {                                                                      \
             if (pp_ == 0) issue(0, kk_); else if (pp_ == 1) issue(3, kk_); else if (pp_ == 2) issue(1, kk_); else issue(2, kk_ + 1); \
         }                                                                                           \
-        if (more) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                 \
+        if (pf) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                   \
         else wait_left((left_ < 8 ? left_ : 8) - 3);                                                \
         __builtin_amdgcn_s_barrier();                                                               \
     }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         // the stream runs on: after X-hi of this tile's last K tile (phase 0 of K tile nkt - 2) every issue fetches the next tile
         // (nkt is even: buffer parities continue), and the last phase leaves its W-lo(0) in wlo
         PW3_KTILE(2, kt0, wlo, wnx, 0,
-                  if (more) { set_src(tm_n * 256, tn_n * 256); issue_consts(tn_n * 256, par ^ 1); kbias = nkt; })
+                  if (pf) { set_src(tm_n * 256, tn_n * 256); issue_consts(tn_n * 256, par ^ 1); kbias = nkt; })
         PW3_ROLL
         ++kt0;
         PW3_KTILE(1, kt0, wlo, wnx, 0, )
@@ -352,58 +355,80 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         if (R2) {
             // Res2Net step: y = BN(ReLU(.)) in the S32 layout into the chain output; U_next = y + c_next (fp32 chunk of the tdnn1
             // output) in the S32 layout into the next step's input.  Only the wave columns that hold channels store anything.
+            // c_next comes through the LDS ring, which is free here because this form does not run its DMA stream on into the next
+            // tile: 256 rows x 512 bytes by LDS-DMA from all eight waves, one wait.  (Loaded straight into registers, four at a
+            // time between the stores, every wait for a load also waited for the acknowledgement of every store issued before it:
+            // the epilogue took 52 k cycles against 46 k for the K loop.)
+            __builtin_amdgcn_s_barrier();                       // (group 1 is past its last fragment read)
+            const float* Cn = reinterpret_cast<const float*>(p.R);
+            if (Cn) {
+                const int lane_c = lane_now();
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const int pidx = (q * 8 + wave) * 64 + lane_c;      // 16-byte chunk of the 256 x 32-chunk image
+                    const int row = pidx >> 5, cs = pidx & 31;
+                    const int m = min(m0 + row, p.M - 1);
+                    const float* src = Cn + (int64_t)m * p.ldr + ((cs ^ (row & 31)) << 2);
+                    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + (q * 8 + wave) * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             if (wn * 64 < p.N) {
-                typedef bf16_t bf16x4_ __attribute__((ext_vector_type(4)));
                 char* Yb = reinterpret_cast<char*>(p.Y);
                 char* Ub = reinterpret_cast<char*>(p.Y2);
-                const float* Cn = reinterpret_cast<const float*>(p.R);
-                auto split4 = [](const f32x4& v, bf16x4_& hi, bf16x4_& lo) {
+                // hi / lo halves of four values, then one v_permlane16_swap per dword with the lane 16 up: the even lane of a pair ends
+                // up with the hi halves of eight consecutive channels, the odd lane with their lo halves — 16-byte stores
+                auto store_s32 = [&](const f32x4& v, char* rowbase, bool doit) {
+                    uint32_t hd[2], ld[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bf16_t hb = static_cast<bf16_t>(v[e]);
-                        hi[e] = hb;
-                        lo[e] = static_cast<bf16_t>(v[e] - static_cast<float>(hb));
+                    for (int d = 0; d < 2; ++d) {
+                        const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
+                        typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
+                        hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
+                        ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
                     }
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(hd[0], ld[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(hd[1], ld[1], false, false);
+                    if (doit) *reinterpret_cast<u32x4*>(rowbase) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 };
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int nl = wn * 64 + j * 16 + 4 * q4e;
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
-                    const int boff = (nl >> 5) * 128 + (nl & 31) * 2;
+                    const int na = nl & ~7;                     // the pair's first channel; even q4: hi plane, odd q4: lo plane
+                    const int boff = (na >> 5) * 128 + (na & 31) * 2 + (q4e & 1) * 64;
 #pragma unroll
-                    for (int ih = 0; ih < 2; ++ih) {           // four frames at a time: their c loads are in flight together
-                        f32x4 cn[4];
+                    for (int i = 0; i < 8; ++i) {
+                        const int ml = wm * 128 + i * 16 + r16e;
+                        const int m = m0 + ml;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(acc16[i][j][e], 0.0f), sc[e], sh[e]);
+                        const bool in = m < p.M && !(ABL & 8);
+                        store_s32(v, Yb + (int64_t)m * p.ldy * 4 + boff, in);
                         if (Ub) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int m = min(m0 + wm * 128 + (ih * 4 + i) * 16 + r16e, p.M - 1);
-                                if (ABL & 512) cn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                                else cn[i] = *reinterpret_cast<const f32x4*>(Cn + (int64_t)m * p.ldr + nl);
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int m = m0 + wm * 128 + (ih * 4 + i) * 16 + r16e;
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(acc16[ih * 4 + i][j][e], 0.0f), sc[e], sh[e]);
-                            if (m < p.M && !(ABL & 8)) {
-                                bf16x4_ hi, lo;
-                                split4(v, hi, lo);
-                                char* q = Yb + (int64_t)m * p.ldy * 4 + boff;
-                                *reinterpret_cast<bf16x4_*>(q) = hi;
-                                *reinterpret_cast<bf16x4_*>(q + 64) = lo;
-                                if (Ub) {
-                                    split4(v + cn[i], hi, lo);
-                                    char* u = Ub + (int64_t)m * p.lda2 * 4 + boff;
-                                    *reinterpret_cast<bf16x4_*>(u) = hi;
-                                    *reinterpret_cast<bf16x4_*>(u + 64) = lo;
-                                }
-                            }
+                            const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + ml * 512 + (((nl >> 2) ^ (ml & 31)) << 4));
+                            store_s32(v + cn, Ub + (int64_t)m * p.lda2 * 4 + boff, in);
                         }
                     }
                 }
+            }
+            if (more) {         // the next tile starts from scratch, like the first one
+                __builtin_amdgcn_s_barrier();                   // every wave has read its c values: the ring may be refilled
+                set_src(tm_n * 256, tn_n * 256);
+                issue_consts(tn_n * 256, par ^ 1);
+                issue_prologue();
+                wait_left(5);
+                __builtin_amdgcn_s_barrier();
+                const int lane_w = lane_now();
+                const int r16w = lane_w & 15, q4w = lane_w >> 4;
+                const int woffw = (wn * 32 + r16w) * 128, wkeyw = ((wn * 32 + r16w) >> 1) & 7;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) wlo[j][ks] = *reinterpret_cast<const bf16x8*>(smem + 2 * HT + woffw + j * 2048 + (((ks * 4 + q4w) ^ wkeyw) << 4));
             }
         } else if (X3) {
             // fp32 out: a lane's accumulator register group IS 16 contiguous bytes (4 channels of one frame)

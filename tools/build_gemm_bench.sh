@@ -8,6 +8,8 @@ for f in gemm gemm_pw gemm_pw2 gemm_pw3; do /opt/rocm/bin/hipcc $FL -c $CS/$f.hi
 /opt/rocm/bin/hipcc $FL -c tools/gemm_bench.hip -o tools/gemm_bench.o
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/gemm_bench.o tools/gemm.dbg.o tools/gemm_pw.dbg.o tools/gemm_pw2.dbg.o tools/gemm_pw3.dbg.o -o tools/gemm_bench
+/opt/rocm/bin/hipcc $FL -c tools/r2_bench.hip -o tools/r2_bench.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 tools/r2_bench.o tools/gemm_pw2.dbg.o tools/gemm_pw3.dbg.o -o tools/r2_bench
 /opt/rocm/bin/hipcc $FL -c $CS/res2net.hip -o tools/res2net.dbg.o
 /opt/rocm/bin/hipcc $FL -c tools/res2_bench.hip -o tools/res2_bench.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/res2_bench.o tools/res2net.dbg.o -o tools/res2_bench
