@@ -354,6 +354,8 @@ int build_fbank_tables(svhip_handle* h) {
     if ((rc = dev_upload(h, &d_ml, mlen))) return rc;
     if ((rc = dev_upload(h, &d_mo, moff))) return rc;
     fb.n_melw = (int)mw.size();
+    fb.mel_max_bin = 0;
+    for (int i = 0; i < nm; ++i) fb.mel_max_bin = std::max(fb.mel_max_bin, mstart[i] + mlen[i] - 1);
     fb.basis = d_basis; fb.mel_w = d_mw; fb.mel_start = d_ms; fb.mel_len = d_ml; fb.mel_off = d_mo;
     return SVHIP_OK;
 }

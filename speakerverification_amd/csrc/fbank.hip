@@ -22,6 +22,8 @@
 // one running basis offset per k step) measured 205 against 190 us on one box (tools/fbank_bench.py) and were not kept: the
 // kernel is latency-bound, not issue-bound.  The structural fix (9-wave workgroups of 128 frames so that a basis fragment feeds
 // 12 MFMAs instead of 3) is the open lead.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -172,6 +174,167 @@ __global__ __launch_bounds__(FB_THREADS) void fbank_kernel(FbankTables tb, const
     }
 }
 
+// ---- the bf16x3 form, round 3: 64 frames per workgroup, one re/im pair of 32 bins per wave -----------------------------------
+// The 32-frame kernel above issues 20 vector instructions per MFMA and re-reads the whole basis per 32 frames (1.5 GB per
+// B = 256 launch, every k step a round trip to L2 for fragments that feed 3 MFMAs).  Here a wave owns ONE pair (cos / sin of 32
+// bins) for two frame tiles: a k step is 4 fragment loads (register double-buffered, one running pointer) feeding 12 MFMAs, the
+// basis is streamed once per 64 frames, and eight waves cover the 256 bins the mel bank reads (the Nyquist bin carries no mel
+// weight when fmax = sr / 2; launch_fbank checks `mel_max_bin` and keeps the kernel above otherwise).  The power tile goes to
+// LDS one 32-frame tile at a time (33 KB), so two workgroups share a CU.  |X|^2 is re^2 + im^2 here (the exact path keeps the
+// reference's sqrt-then-square rounding; on a bf16 handle the features are rounded to 2^-8 right after).
+constexpr int F2_FRAMES = 64;
+constexpr int F2_THREADS = 512;
+constexpr int F2_PT_STRIDE = 257;
+
+template <bool SPLIT>
+__global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, const float* __restrict__ wav, int L, int T,
+                                                                float* __restrict__ mel) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ns = (F2_FRAMES - 1) * tb.hop + tb.win_length;
+    const int ns_pad = ((ns + 15) & ~15) + 16;
+    bf16_t* yh = reinterpret_cast<bf16_t*>(smem);                  // SPLIT: [ns_pad] hi | [ns_pad] lo; else [ns_pad] fp32
+    bf16_t* yl = yh + ns_pad;
+    float* ys = reinterpret_cast<float*>(smem);
+    float* pt = ys + ns_pad;                                       // [32][257]
+    float* melw = pt + 32 * F2_PT_STRIDE;
+
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * F2_FRAMES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ x = wav + (int64_t)b * L;
+    const bool two = f0 + 32 < T;                                  // the last tile of an utterance may hold one frame tile only
+
+    for (int i = tid; i < tb.n_melw; i += F2_THREADS) melw[i] = tb.mel_w[i];
+    const int j0 = f0 * tb.hop + tb.lpad - tb.n_fft / 2;
+    const float coef = tb.preemph;
+    const bool interior = j0 >= 1 && j0 + ns_pad <= L;             // no reflection anywhere in the tile
+    for (int i0 = tid; i0 < ns_pad; i0 += 4 * F2_THREADS) {
+        float v[4], prev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * F2_THREADS;
+            int jj = j0 + i;
+            if (!interior) {
+                jj = jj < 0 ? -jj : jj;
+                jj = jj >= L ? 2 * (L - 1) - jj : jj;
+                jj = max(0, min(jj, L - 1));
+            }
+            const bool in = i < ns_pad;
+            v[u] = in ? x[in ? jj : 0] : 0.0f;
+            prev[u] = (in && coef >= 0.0f) ? x[jj == 0 ? 1 : jj - 1] : 0.0f;   // F.pad(reflect,(1,0)): x[-1] := x[1]
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * F2_THREADS;
+            if (i < ns_pad) {
+                float w = v[u];
+                if (coef >= 0.0f) w = __fadd_rn(__fmul_rn(-coef, prev[u]), w);
+                if (SPLIT) {
+                    const bf16_t hi = static_cast<bf16_t>(w);
+                    yh[i] = hi;
+                    yl[i] = static_cast<bf16_t>(w - static_cast<float>(hi));
+                } else {
+                    ys[i] = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
+    if (!SPLIT) {                                                  // exact fp32 MFMA, same tap order as the 32-frame kernel
+        const int qstride = tb.n_pairs * 2 * 64;
+        const f32x4* __restrict__ bs = reinterpret_cast<const f32x4*>(tb.basis) + wave * 2 * 64 + lane;
+        const float* a0 = ys + r * tb.hop + 4 * h;
+        const float* a1 = a0 + 32 * tb.hop;
+        f32x4 n0 = bs[0], n1 = bs[64];
+        for (int q = 0; q < tb.n_q; ++q) {
+            const f32x4 c0 = n0, c1 = n1;
+            const int qn = min(q + 1, tb.n_q - 1) * qstride;
+            n0 = bs[qn]; n1 = bs[qn + 64];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(a0 + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[j], c0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[j], c1[j], acc[0][1], 0, 0, 0);
+            }
+            if (two) {
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(a1 + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], c0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], c1[j], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+        const int kstride = tb.n_pairs * 2 * 64;                                        // fragments per k step
+        const bf16x8* __restrict__ bh = reinterpret_cast<const bf16x8*>(tb.basis_hi) + wave * 2 * 64 + lane;
+        const bf16x8* __restrict__ bl = reinterpret_cast<const bf16x8*>(tb.basis_lo) + wave * 2 * 64 + lane;
+        const bf16_t* a0 = yh + r * tb.hop + 8 * h;
+        const bf16_t* a1 = a0 + 32 * tb.hop;
+        bf16x8 nh0 = bh[0], nh1 = bh[64], nl0 = bl[0], nl1 = bl[64];
+        for (int kk = 0; kk < tb.n_k16; ++kk) {
+            const bf16x8 ch0 = nh0, ch1 = nh1, cl0 = nl0, cl1 = nl1;
+            const int kn = min(kk + 1, tb.n_k16 - 1) * kstride;
+            nh0 = bh[kn]; nh1 = bh[kn + 64]; nl0 = bl[kn]; nl1 = bl[kn + 64];
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0 + 16 * kk);
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0 + ns_pad + 16 * kk);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, ch0, acc[0][0], 0, 0, 0);   // small terms first
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, ch1, acc[0][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, cl0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, cl1, acc[0][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, ch0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, ch1, acc[0][1], 0, 0, 0);
+            if (two) {
+                const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1 + 16 * kk);
+                const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1 + ns_pad + 16 * kk);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, ch0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, ch1, acc[1][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, cl0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, cl1, acc[1][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, ch0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, ch1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !two) break;
+        if (mt) __syncthreads();                                   // the previous tile's mel sums have read pt
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float re = acc[mt][0][e], im = acc[mt][1][e];
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (SPLIT) {
+                pt[i * F2_PT_STRIDE + wave * 32 + r] = fmaf(re, re, im * im);
+            } else {
+                const float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));   // 'Magnitude'
+                pt[i * F2_PT_STRIDE + wave * 32 + r] = __fmul_rn(mag, mag);                      // ** 2.0
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * tb.n_mels; idx += F2_THREADS) {
+            const int i = idx & 31, m = idx >> 5;
+            const int f = f0 + 32 * mt + i;
+            const int st = tb.mel_start[m], ln = tb.mel_len[m];
+            const float* w = melw + tb.mel_off[m];
+            const float* prow = pt + i * F2_PT_STRIDE + st;
+            float sacc = 0.0f;
+            for (int k = 0; k < ln; ++k) sacc = fmaf(w[k], prow[k], sacc);
+            if (f < T) mel[((int64_t)b * tb.n_mels + m) * T + f] = sacc;
+        }
+    }
+}
+
 // per (b, mel): mean of log(x + 1e-6) over T (and biased variance of the normalised signal when
 // instance norm is on).  stats[(b*n_mels + m)*2 + {0,1}] = {shift, scale}: y = (v - shift) * scale.
 __global__ __launch_bounds__(256) void prologue_stats_kernel(const float* __restrict__ feat, float* __restrict__ stats,
@@ -244,12 +407,24 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
     const int ns_pad = ((ns + 15) & ~15) + 16;
     const size_t lds = (size_t)(ns_pad + FB_FRAMES * FB_PT_STRIDE + tb.n_melw) * sizeof(float);
     dim3 grid((T + FB_FRAMES - 1) / FB_FRAMES, B), block(FB_THREADS);
-    if (tb.split_bf16) {
-        if (!tb.basis_hi || !tb.basis_lo || tb.hop % 8 != 0) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(fbank_kernel<true>, grid, block, lds, stream, tb, wav, L, T, mel);
-    } else {
-        hipLaunchKernelGGL(fbank_kernel<false>, grid, block, lds, stream, tb, wav, L, T, mel);
+    if (tb.split_bf16 && (!tb.basis_hi || !tb.basis_lo || tb.hop % 8 != 0)) return hipErrorInvalidValue;
+    // 64-frame kernel: needs the mel bank to stop below the Nyquist bin (eight pairs = 256 bins) and its tile in 64 KiB of LDS
+    const char* small_tiles = getenv("SVHIP_FBANK32");                                   // developer switch: the 32-frame kernel
+    const int ns2 = (F2_FRAMES - 1) * tb.hop + tb.win_length;
+    const int ns2_pad = ((ns2 + 15) & ~15) + 16;
+    const size_t lds2 = (size_t)(ns2_pad + 32 * F2_PT_STRIDE + tb.n_melw) * sizeof(float);
+    if (tb.mel_max_bin < 256 && tb.n_pairs >= 8 && lds2 <= 64 * 1024 && !(small_tiles && small_tiles[0] == '1')) {
+        dim3 grid2((T + F2_FRAMES - 1) / F2_FRAMES, B);
+        if (tb.split_bf16)
+            hipLaunchKernelGGL(fbank64_kernel<true>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
+        else
+            hipLaunchKernelGGL(fbank64_kernel<false>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
+        return hipGetLastError();
     }
+    if (tb.split_bf16)
+        hipLaunchKernelGGL(fbank_kernel<true>, grid, block, lds, stream, tb, wav, L, T, mel);
+    else
+        hipLaunchKernelGGL(fbank_kernel<false>, grid, block, lds, stream, tb, wav, L, T, mel);
     return hipGetLastError();
 }
 

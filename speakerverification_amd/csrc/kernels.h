@@ -164,6 +164,7 @@ struct FbankTables {           // device pointers, built once per handle
     int n_fft = 512, win_length = 200, hop = 80, n_mels = 80, n_bins = 257, lpad = 156;
     int n_pairs = 9;                   // ceil(n_bins / 32) re/im tile pairs
     int n_q = 25;                      // win_length / 8
+    int mel_max_bin = 256;             // highest bin with a non-zero mel weight
     float preemph = 0.97f;
 };
 // wav (B, L) fp32 -> mel power (B, n_mels, T) fp32

@@ -78,3 +78,24 @@ def test_fbank_bf16x3_split_path(kind):
     peak = np.abs(ref64).max(axis=(1, 2), keepdims=True)
     print(kind, "bf16x3 log-mel max abs error", e_log, "rel-to-peak", float((np.abs(got - ref64) / peak).max()))
     assert e_log <= 5e-3
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("L", [32000, 512, 5200, 10320, 15439])
+def test_fbank_64_frame_kernel_equals_the_32_frame_kernel(monkeypatch, compute, L):
+    """the 64-frame workgroup (one bin pair per wave, basis streamed once per 64 frames) against the 32-frame kernel it replaced
+    (SVHIP_FBANK32=1), on lengths whose last tile holds one frame tile, two, or a single frame: the exact-fp32 form multiplies the
+    same taps in the same order and must agree BIT FOR BIT; the split form differs only in |X|^2 = re^2 + im^2 vs sqrt-then-square."""
+    eng = Engine(model="none", compute=compute, max_batch=5, samples=L)
+    rng = np.random.default_rng(L)
+    wav = (rng.standard_normal((5, L)) * 0.1).astype(np.float32)
+    new = eng.fbank(wav)
+    monkeypatch.setenv("SVHIP_FBANK32", "1")
+    old = eng.fbank(wav)
+    monkeypatch.delenv("SVHIP_FBANK32")
+    assert new.shape == old.shape and np.isfinite(new).all()
+    if compute == "f32":
+        np.testing.assert_array_equal(new, old)
+    else:
+        np.testing.assert_allclose(new, old, rtol=2e-6, atol=1e-12)
+    eng.close()
