@@ -966,6 +966,13 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         ap.bn_scale = h->aspbn_scale; ap.bn_shift = h->aspbn_shift;
         ap.pooled_raw = d_pool_raw; ap.pooled_bn = d_pool_bn; ap.eps = 1e-12f;
         if ((rc = run(h, "asp_fused", (double)M * h->asp_conv.flops_per_row, [&]() { return launch_asp_fused(ap, B, st); }))) return rc;
+    } else if (h->x3 && h->asp_conv.Ws32 && asp_x3_supported(T, C3, h->asp_tdnn.N, h->asp_conv.K)) {
+        AspX3Params ap;
+        ap.att = (const float*)ATT; ap.Ws32 = h->asp_conv.Ws32; ap.X = (const float*)MFA; ap.ldx = C3; ap.T = T; ap.C = C3;
+        ap.mref = d_gstats; ap.mref_ld = 2 * C3;                  // [mean | std] per utterance: the means
+        ap.bn_scale = h->aspbn_scale; ap.bn_shift = h->aspbn_shift;
+        ap.pooled_raw = d_pool_raw; ap.pooled_bn = d_pool_bn; ap.eps = 1e-12f;
+        if ((rc = run(h, "asp_x3", (double)M * h->asp_conv.flops_per_row, [&]() { return launch_asp_x3(ap, B, st); }))) return rc;
     } else {
         if ((rc = conv_gemm(h, "gemm_asp_conv", h->asp_conv, ATT, 128, LOGITS, C3, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true)))
             return rc;

@@ -229,6 +229,22 @@ struct AspFusedParams {
 bool asp_fused_supported(int T, int C, int att_channels, int Kp);
 hipError_t launch_asp_fused(const AspFusedParams& p, int B, hipStream_t stream);
 
+// the same fusion for SVHIP_F32X3 handles (asp_x3.hip): fp32 att and x, logits as split-bf16 MFMA triples, never stored
+struct AspX3Params {
+    const float* att = nullptr;     // (B*T, 128) fp32, asp.tdnn's output
+    const void* Ws32 = nullptr;     // asp.conv in the S32 split layout: [C rows][128 k]: per 32 k, 32 hi | 32 lo bf16
+    const float* X = nullptr;       // (B*T, ldx) fp32, the mfa output
+    const float* mref = nullptr;    // (B, mref_ld): the plain mean over time of every channel of X (the shift of the moments)
+    const float* bn_scale = nullptr;
+    const float* bn_shift = nullptr;
+    float* pooled_raw = nullptr;    // optional (B, 2C)
+    float* pooled_bn = nullptr;     // (B, 2C)
+    int ldx = 0, mref_ld = 0, T = 0, C = 0, B = 0;
+    float eps = 1e-12f;
+};
+bool asp_x3_supported(int T, int C, int att_channels, int K);
+hipError_t launch_asp_x3(const AspX3Params& p, int B, hipStream_t stream);
+
 // ---------------------------------------------------------------------------------------------
 // RawNet2 (rawnet2.hip)
 // ---------------------------------------------------------------------------------------------

@@ -254,3 +254,31 @@ def test_f32x3_persistent_gemm_matches_reference(golden_dir, C, cus, monkeypatch
         assert abs(got.sum() - cs[0]) <= 1e-4 * cs[1] + 1e-3, n
         assert abs(np.abs(got).sum() - cs[1]) <= 1e-4 * cs[1] + 1e-3, n
     eng.close()
+
+
+@pytest.mark.parametrize("T,B", [(401, 3), (130, 9), (64, 8), (33, 2)])
+def test_f32x3_fused_attentive_pooling_matches_the_exact_path(T, B):
+    """SVHIP_F32X3 handles pool with asp_x3_kernel (logits as split-bf16 MFMA triples, lane-local online softmax, x streamed once;
+    models/ECAPA_TDNN.py:250-259): pooled mean / std against the exact-fp32 handle's GEMM + asp_pool path, element by element, on
+    utterance lengths whose last 32-frame tile is full, nearly empty, or the only one, and batches that do / do not fill the
+    groups of 8 utterances the workgroup -> XCD mapping deals out."""
+    C = 256
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=21)
+    mel = synth.synth_mel(B, 80, T, seed=22)
+    st = {}
+    for compute in ("f32", "f32x3"):
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80 if T != 401 else 32000)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        eng.embed_features(mel)
+        labels = eng.profile_results()
+        assert ("asp_x3" in labels) == (compute == "f32x3") and ("asp_pool" in labels) == (compute == "f32"), labels.keys()
+        st[compute] = {n: eng.get_stage(n).astype(np.float64) for n in ("mfa", "asp", "asp_bn")}
+        eng.close()
+    for n in ("asp", "asp_bn"):
+        ref, got = st["f32"][n], st["f32x3"][n]
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(got - ref).max())
+        print(f"T={T} B={B} {n}: max err {err:.3e} of scale {scale:.2f}")
+        assert np.isfinite(got).all() and err <= 1e-4 * max(1.0, scale), (n, err, scale)
