@@ -72,13 +72,16 @@ constexpr int ABL = 0;
 // dil) inside the lane's utterance); N = cin <= 128 fills the two left wave columns of the 256 x 256 tile (the right two
 // multiply clamped weight rows and store nothing); the epilogue writes y_j in the S32 layout into the chain output (the next
 // GEMM's A operand: no fp32 copy exists) and U_{j+1} = y_j + c_{j+1} (c from the fp32 tdnn1 output) into the next step's input.
-// Measured (round 3, C = 1024, B = 256; tools/r2_bench with the kernel's stage stamps): 100 us per step, 100 TFLOP/s of reference
-// FLOPs.  Per tile (85 k cycles): K loop 44.7 k (12 K tiles; the matrix pipe is 83 % busy in it, half of that on the empty wave
-// columns), epilogue 35.6 k, start 4.4 k; 401 tiles are 1.57 per workgroup, i.e. two rounds.  The epilogue is bound by the CU's
-// store path: a wave instruction here writes 64 separate 16-byte pieces (16 rows x {hi, lo} x 2 channel groups), 256 of them per
-// tile.  History: c_next loaded straight into registers between the stores 52 k cycles (every load's wait also waited for all
-// earlier stores); an L2 prefetch of the c rows by LDS-DMA no gain; the c tile through the ring + 16-byte swapped stores 35.6 k.
-// Open lead: stage y / U through the ring as whole rows and let all eight waves copy them out in 128-byte runs.
+// Measured (round 3, C = 1024, B = 256; tools/r2_bench with the kernel's stage stamps): 88 us per step, 115 TFLOP/s of reference
+// FLOPs.  Per tile: K loop 44 k cycles (12 K tiles; the matrix pipe is 83 % busy in it, half of that on the empty wave columns),
+// epilogue 37 k, start 4.5 k; 401 tiles are 1.57 per workgroup, i.e. two rounds.  History of the epilogue: c_next loaded straight
+// into registers between the stores 52 k cycles (every load's wait also waited for all earlier stores); an L2 prefetch of the c
+// rows by LDS-DMA no gain; the c tile through the ring + 16-byte swapped stores from the accumulator layout 35.6 k, bound by the
+// CU's store path (64 separate 16-byte pieces per wave instruction), 100 us per step; U and y staged through the ring as whole
+// rows and copied out by all eight waves (1 KiB contiguous per instruction): the same cycle count at a higher clock, 88 us.
+// What bounds it now: every CU reaches its epilogue at the same time, and 384 KB per tile (c in, y and U out) at a CU's share of
+// the HBM bandwidth (~10 B / cycle) IS ~38 k cycles, while HBM idles through the K loops; overlapping the two needs two tiles
+// in flight per CU (a 128 x 128 / four-wave re-cut with two workgroups per CU), not built.
 template <int EPI, int CS, bool X3, bool R2 = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
@@ -360,61 +363,100 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             // time between the stores, every wait for a load also waited for the acknowledgement of every store issued before it:
             // the epilogue took 52 k cycles against 46 k for the K loop.)
             __builtin_amdgcn_s_barrier();                       // (group 1 is past its last fragment read)
+            // The ring holds one 256-row image of 512-byte rows at a time: first the c tile (fp32), which the valid waves turn IN
+            // PLACE into U = y + c in the S32 layout (a 128-byte block of a row — 32 channels as fp32, or their hi | lo planes —
+            // is read and written by the four lanes of ONE wave, and a wave's LDS operations execute in order), then y.  Each
+            // image leaves through all eight waves as whole rows: one wave instruction = two rows = 1 KiB contiguous.  (Stored
+            // straight from the accumulator layout an instruction wrote 64 separate 16-byte pieces and the epilogue was bound by
+            // the CU's store path: 35.6 k cycles per tile.)  16-byte chunk k of a block sits at k ^ (row & 7): two-way bank
+            // conflicts at most for the accumulator-layout accesses, none for the row copies.
             const float* Cn = reinterpret_cast<const float*>(p.R);
+            char* Ub = reinterpret_cast<char*>(p.Y2);
+            const int nchunk = p.N >> 2;                        // 16-byte chunks per image row (32 or 16)
+            auto copy_out = [&](char* dst, int64_t ld_bytes) {
+                const int lane_c = lane_now();
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const int pidx = (q * 8 + wave) * 64 + lane_c;
+                    const int row = pidx >> 5, ch = pidx & 31;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 512 + (ch & ~7) * 16 + (((ch & 7) ^ (row & 7)) << 4));
+                    if (m0 + row < p.M && ch < nchunk && !(ABL & 8)) *reinterpret_cast<u32x4*>(dst + (int64_t)(m0 + row) * ld_bytes + ch * 16) = v;
+                }
+            };
+            // a lane's four values -> 8 bytes of the hi plane and 8 bytes of the lo plane of its block
+            auto put_s32 = [&](const f32x4& v, int ml, int nl) {
+                typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
+                uint32_t hd[2], ld[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
+                    hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
+                    ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
+                }
+                const int kh = (nl & 31) >> 3;                  // chunk of the hi plane holding channels nl .. nl + 3 (lo: + 4)
+                char* blk = smem + ml * 512 + (nl >> 5) * 128 + (nl & 4) * 2;
+                *reinterpret_cast<uint2*>(blk + ((kh ^ (ml & 7)) << 4)) = make_uint2(hd[0], hd[1]);
+                *reinterpret_cast<uint2*>(blk + (((kh + 4) ^ (ml & 7)) << 4)) = make_uint2(ld[0], ld[1]);
+            };
             if (Cn) {
                 const int lane_c = lane_now();
 #pragma unroll 4
                 for (int q = 0; q < 16; ++q) {
-                    const int pidx = (q * 8 + wave) * 64 + lane_c;      // 16-byte chunk of the 256 x 32-chunk image
-                    const int row = pidx >> 5, cs = pidx & 31;
+                    const int pidx = (q * 8 + wave) * 64 + lane_c;      // 16-byte chunk position of the 256 x 32-chunk image
+                    const int row = pidx >> 5, pos = pidx & 31;
+                    const int cs = min((pos & ~7) | ((pos ^ row) & 7), nchunk - 1);
                     const int m = min(m0 + row, p.M - 1);
-                    const float* src = Cn + (int64_t)m * p.ldr + ((cs ^ (row & 31)) << 2);
+                    const float* src = Cn + (int64_t)m * p.ldr + (cs << 2);
                     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + (q * 8 + wave) * 1024), 16, 0, 0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (wn * 64 < p.N) {
-                char* Yb = reinterpret_cast<char*>(p.Y);
-                char* Ub = reinterpret_cast<char*>(p.Y2);
-                // hi / lo halves of four values, then one v_permlane16_swap per dword with the lane 16 up: the even lane of a pair ends
-                // up with the hi halves of eight consecutive channels, the odd lane with their lo halves — 16-byte stores
-                auto store_s32 = [&](const f32x4& v, char* rowbase, bool doit) {
-                    uint32_t hd[2], ld[2];
+            const bool valid_cols = wn * 64 < p.N;
+            if (valid_cols) {
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
-                        typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
-                        hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
-                        ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
+                for (int jp = 0; jp < 2; ++jp) {
+                    f32x4 sc[2], sh[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int nl = wn * 64 + (2 * jp + jj) * 16 + 4 * q4e;
+                        sc[jj] = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
+                        sh[jj] = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
                     }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(hd[0], ld[0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(hd[1], ld[1], false, false);
-                    if (doit) *reinterpret_cast<u32x4*>(rowbase) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                };
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int nl = wn * 64 + j * 16 + 4 * q4e;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
-                    const int na = nl & ~7;                     // the pair's first channel; even q4: hi plane, odd q4: lo plane
-                    const int boff = (na >> 5) * 128 + (na & 31) * 2 + (q4e & 1) * 64;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int ml = wm * 128 + i * 16 + r16e;
-                        const int m = m0 + ml;
-                        f32x4 v;
+                        f32x4 cn[2];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(fmaxf(acc16[i][j][e], 0.0f), sc[e], sh[e]);
-                        const bool in = m < p.M && !(ABL & 8);
-                        store_s32(v, Yb + (int64_t)m * p.ldy * 4 + boff, in);
-                        if (Ub) {
-                            const f32x4 cn = *reinterpret_cast<const f32x4*>(smem + ml * 512 + (((nl >> 2) ^ (ml & 31)) << 4));
-                            store_s32(v + cn, Ub + (int64_t)m * p.lda2 * 4 + boff, in);
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * jp + jj;
+                            const int nl = wn * 64 + j * 16 + 4 * q4e;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc16[i][j][e] = fmaf(fmaxf(acc16[i][j][e], 0.0f), sc[jj][e], sh[jj][e]);
+                            if (Cn) cn[jj] = *reinterpret_cast<const f32x4*>(smem + ml * 512 + (nl >> 5) * 128 + ((((nl & 31) >> 2) ^ (ml & 7)) << 4));
+                        }
+                        if (Cn) {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) put_s32(acc16[i][2 * jp + jj] + cn[jj], ml, wn * 64 + (2 * jp + jj) * 16 + 4 * q4e);
                         }
                     }
                 }
             }
+            if (Cn) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // the U image is complete
+                copy_out(Ub, (int64_t)p.lda2 * 4);
+                __builtin_amdgcn_s_barrier();                   // ... and has been read
+            }
+            if (valid_cols) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) put_s32(acc16[i][j], wm * 128 + i * 16 + r16e, wn * 64 + j * 16 + 4 * q4e);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
             if (more) {         // the next tile starts from scratch, like the first one
                 __builtin_amdgcn_s_barrier();                   // every wave has read its c values: the ring may be refilled
                 set_src(tm_n * 256, tn_n * 256);
