@@ -115,6 +115,7 @@ struct svhip_handle {
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
     void* s32_buf = nullptr;      // SVHIP_F32X3: the A operand of the current big GEMM in the S32 split layout (M x 3C x 4 bytes)
+    bool cat_f32_stale = false;   // SVHIP_F32X3: the last forward left the block outputs only in cat_s32 (svhip_get_stage converts on demand)
     void* cat_s32 = nullptr;      // SVHIP_F32X3: the SE-Res2Net block outputs (the CAT buffer) in the S32 layout, written by se_apply
     void* h2_s32 = nullptr;       // SVHIP_F32X3: the Res2Net chain output (H2's twin, S32 only) and the two step-input buffers (M x C/8)
     void* u_s32[2] = {};
@@ -873,9 +874,23 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     // their A operand without a conversion pass
     char* cat32 = h->cat_s32 ? static_cast<char*>(h->cat_s32) + r0 * C3 * 4 : nullptr;
     const void* xin32 = nullptr;
+    // ... and when every consumer of a block output takes the split operand at this batch size (tdnn1 of the next block, mfa: the
+    // persistent X3 kernel; the next se_apply reads its residual as hi + lo), the fp32 copy is not written at all
+    auto x3_route = [&](const ConvLayer& L, const void* a32, int lda32, bool cs) {
+        if (!h->x3 || !L.Ws32 || !h->s32_buf || !a32) return false;
+        GemmParams q;
+        q.A = a32; q.lda = lda32; q.W = L.Ws32; q.x3 = 2; q.Y = MFA; q.ldy = L.N;
+        q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
+        q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.Wrows = L.Np; q.T = T; q.taps = L.taps; q.act1 = ACT_GELU; q.num_cu = h->num_cu;
+        if (cs) { q.colsum = cs_base; q.colsum_sq = 1; q.colsum_stride = h->colsum_region; }
+        return gemm_pw3x3_supported(q);
+    };
+    const bool s32_only = cat32 && x3_route(h->tdnn1[1], cat32, C3, false) && x3_route(h->tdnn1[2], cat32, C3, false) &&
+                          x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !getenv("SVHIP_X3_KEEP_F32");
+    if (s32_only) h->cat_f32_stale = true;
     for (int i = 0; i < 3; ++i) {
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0, PAD_REFLECT,
-                            nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], (s32_only && i > 0) ? nullptr : xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0,
+                            false, 0, PAD_REFLECT, nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
         const void* h2_32 = nullptr;      // F32X3: the chain output in the S32 layout (tdnn2's A operand)
         bool r2_done = false;
         if (h->x3 && h->h2_s32 && h->res2[i][0].Ws32) {
@@ -941,13 +956,16 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
              }))) return rc;
         void* xout = off(CAT, (size_t)i * C, e);
         void* xout32 = cat32 ? cat32 + (size_t)i * C * 4 : nullptr;
-        if ((rc = run(h, "se_apply", 0, [&]() { return launch_se_apply(H3, C, d_s2, xin, ldin, xout, C3, bf, B, T, C, st, xout32, C3); })))
+        if ((rc = run(h, "se_apply", 0, [&]() {
+                 return launch_se_apply(H3, C, d_s2, xin, ldin, s32_only ? nullptr : xout, C3, bf, B, T, C, st, xout32, C3,
+                                        s32_only && i > 0 ? xin32 : nullptr, C3);
+             })))
             return rc;
         xin = xout;
         xin32 = xout32;
         ldin = C3;
     }
-    if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
+    if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, s32_only ? nullptr : CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
                         PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region, cat32, C3))) return rc;
     if (h->last_colsum_done) {
         if ((rc = run(h, "colsum_finalize", 0, [&]() { return launch_colsum_finalize(cs_base, h->colsum_region, true, B, T, C3, M, d_gstats, 1e-12f, st, h->last_colsum_groups); }))) return rc;
@@ -990,6 +1008,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
 // small latency-bound kernels of one half overlap the big GEMMs of the other
 int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     int rc = SVHIP_OK;
+    h->cat_f32_stale = false;
     if (h->lanes == 2 && B >= 64) {
         const int B0 = (B / 2 + 3) & ~3;
         SV_HIP(h, hipEventRecord(h->lane_ev[4], h->stream));
@@ -1944,7 +1963,14 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     const std::string n(name);
     if (n == "input") { src = h->X_in; cols = ld = h->cfg.n_mels; }
     else if (n == "blocks.0") { src = h->X0; cols = ld = C; }
-    else if (n == "blocks.1" || n == "blocks.2" || n == "blocks.3") { const int i = n.back() - '1'; src = off(h->CAT, (size_t)i * C, e); cols = C; ld = C3; }
+    else if (n == "blocks.1" || n == "blocks.2" || n == "blocks.3") {
+        const int i = n.back() - '1';
+        src = off(h->CAT, (size_t)i * C, e); cols = C; ld = C3;
+        if (h->cat_f32_stale && out) {        // F32X3: the block outputs exist only in the split layout; rebuild the fp32 view
+            SV_HIP(h, launch_unsplit_s32(h->cat_s32, C3, static_cast<float*>(h->CAT), C3, (int64_t)M, C3, h->stream));
+            h->cat_f32_stale = false;
+        }
+    }
     else if (n == "mfa") { src = h->MFA; cols = ld = C3; }
     else if (n == "asp") { src = h->d_pool_raw; rows = B; cols = ld = 2 * C3; f32 = true; }
     else if (n == "asp_bn") { src = h->d_pool_bn; rows = B; cols = ld = 2 * C3; f32 = true; }

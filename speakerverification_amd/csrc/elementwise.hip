@@ -322,7 +322,10 @@ constexpr int SE_ROWS = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ s,
                                                        const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo,
-                                                       int Tn, int C, char* __restrict__ s32, int ld32) {
+                                                       int Tn, int C, char* __restrict__ s32, int ld32,
+                                                       const char* __restrict__ x32, int ldx32) {
+    // (fp32 instance on F32X3 handles: s32 = the S32 twin of the output; x32 = the residual in the S32 layout instead of x;
+    //  out may then be null — every consumer reads the split form, svhip_get_stage converts it back on demand)
     constexpr int VEC = Vec16<T>::N;
     const int cpr = C / VEC;                                  // chunks per row
     const int b = blockIdx.y;
@@ -336,11 +339,20 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
         for (int t = t0 + fl; t < t1; t += 4) {
             const int64_t m = (int64_t)b * Tn + t;
             const Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
-            const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
+            Vec16<T> xv;
+            if (VEC == 4 && x32) {
+                typedef bf16_t bf16x4r_ __attribute__((ext_vector_type(4)));
+                const char* q = x32 + m * (int64_t)ldx32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
+                const bf16x4r_ xh = *reinterpret_cast<const bf16x4r_*>(q), xl = *reinterpret_cast<const bf16x4r_*>(q + 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv.set(j, static_cast<float>(xh[j]) + static_cast<float>(xl[j]));
+            } else {
+                xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
+            }
             Vec16<T> o;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), g[j], xv.get(j)));
-            *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
+            if (out) *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
             if (VEC == 4 && s32) {
                 typedef bf16_t bf16x4_ __attribute__((ext_vector_type(4)));
                 bf16x4_ hi, lo;
@@ -562,6 +574,30 @@ hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int 
     return hipGetLastError();
 }
 
+// S32 -> fp32 (svhip_get_stage on F32X3 handles whose block outputs exist only in the split layout): v = hi + lo
+__global__ __launch_bounds__(256) void unsplit_s32_kernel(const char* __restrict__ src, int lds32, float* __restrict__ dst, int ld, int64_t M, int K) {
+    const int per_row = K >> 2;
+    const int64_t n = M * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / per_row;
+        const int c = (int)(i - row * per_row) * 4;
+        typedef bf16_t bf16x4u_ __attribute__((ext_vector_type(4)));
+        const char* q = src + row * (int64_t)lds32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        const bf16x4u_ hi = *reinterpret_cast<const bf16x4u_*>(q), lo = *reinterpret_cast<const bf16x4u_*>(q + 64);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = static_cast<float>(hi[j]) + static_cast<float>(lo[j]);
+        *reinterpret_cast<f32x4*>(dst + row * ld + c) = v;
+    }
+}
+
+hipError_t launch_unsplit_s32(const void* src, int lds32, float* dst, int ld, int64_t M, int K, hipStream_t stream) {
+    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0 || lds32 % 32 != 0) return hipErrorInvalidValue;
+    const int64_t g = (M * (K / 4) + 255) / 256;
+    hipLaunchKernelGGL(unsplit_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, reinterpret_cast<const char*>(src), lds32, dst, ld, M, K);
+    return hipGetLastError();
+}
+
 hipError_t launch_split_words(const float* src, void* dst, int64_t n, hipStream_t stream) {
     if (!src || !dst || n <= 0) return hipErrorInvalidValue;
     const int64_t g = (n + 255) / 256;
@@ -600,13 +636,15 @@ hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void
 }
 
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
-                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32, int ld32) {
+                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32, int ld32, const void* x32, int ldx32) {
     const int vec = bf16 ? 8 : 4;
     if (C % vec || ldh % vec || ldx % vec || ldo % vec || B <= 0 || T <= 0) return hipErrorInvalidValue;
     if (s32 && (bf16 || C % 32 != 0 || ld32 % 32 != 0 || (reinterpret_cast<uintptr_t>(s32) & 127))) return hipErrorInvalidValue;
+    if (x32 && (bf16 || C % 32 != 0 || ldx32 % 32 != 0 || (reinterpret_cast<uintptr_t>(x32) & 127))) return hipErrorInvalidValue;
+    if ((!x && !x32) || (!out && !s32)) return hipErrorInvalidValue;
     dim3 grid((T + SE_ROWS - 1) / SE_ROWS, B), block(256);
-    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C, (char*)nullptr, 0);
-    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C, (char*)s32, ld32);
+    if (bf16) hipLaunchKernelGGL(se_apply_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)h, ldh, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, T, C, (char*)nullptr, 0, (const char*)nullptr, 0);
+    else hipLaunchKernelGGL(se_apply_kernel<float>, grid, block, 0, stream, (const float*)h, ldh, s, (const float*)x, ldx, (float*)out, ldo, T, C, (char*)s32, ld32, (const char*)x32, ldx32);
     return hipGetLastError();
 }
 

@@ -126,6 +126,7 @@ bool gemm_pw3r2_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream);
 // fp32 (M, K) rows (stride ld) -> S32 layout, rows of ldd elements (4 bytes each; 0: dense, ldd = K)
 hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0);
+hipError_t launch_unsplit_s32(const void* src, int lds32, float* dst, int ld, int64_t M, int K, hipStream_t stream);   // v = hi + lo
 // row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
 int gemm_colsum_groups(const GemmParams& p, bool bf16);
 
@@ -194,7 +195,7 @@ hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void
 // out[(b,t), c] = h[(b,t), c] * s[b, c] + x[(b,t), c]   (SE gate + residual, ECAPA_TDNN.py:177,336)
 // (fp32: s32 != null also writes out in the S32 split layout, row stride ld32 elements of 4 bytes: gemm_pw3's X3 A operand)
 hipError_t launch_se_apply(const void* h, int ldh, const float* s, const void* x, int ldx, void* out, int ldo,
-                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32 = nullptr, int ld32 = 0);
+                           bool bf16, int B, int T, int C, hipStream_t stream, void* s32 = nullptr, int ld32 = 0, const void* x32 = nullptr, int ldx32 = 0);
 // reduce the pw2 column-sum partials: out (B, C) = mean over T  [and out (B, 2C) = [mean | std] with sq]
 hipError_t launch_colsum_finalize(const float* part, int64_t sq_stride, bool with_std, int B, int T, int C, int M,
                                   float* out, float eps, hipStream_t stream, int row_groups = 8);
