@@ -115,6 +115,9 @@ struct svhip_handle {
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
     void* s32_buf = nullptr;      // SVHIP_F32X3: the A operand of the current big GEMM in the S32 split layout (M x 3C x 4 bytes)
+    void *side_a = nullptr, *side_b = nullptr;      // pending S32 side outputs of the next conv_gemm (GemmParams::side_*), consumed by it
+    int side_lda = 0, side_ldb = 0, side_c = 0;
+    bool side_done = false;       // ... and whether that GEMM wrote them
     bool cat_f32_stale = false;   // SVHIP_F32X3: the last forward left the block outputs only in cat_s32 (svhip_get_stage converts on demand)
     void* cat_s32 = nullptr;      // SVHIP_F32X3: the SE-Res2Net block outputs (the CAT buffer) in the S32 layout, written by se_apply
     void* h2_s32 = nullptr;       // SVHIP_F32X3: the Res2Net chain output (H2's twin, S32 only) and the two step-input buffers (M x C/8)
@@ -785,6 +788,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     GemmParams p;
     p.colsum = colsum; p.colsum_sq = colsum_sq; p.colsum_stride = colsum_stride;
     h->last_colsum_done = false;
+    h->side_done = false;
     p.R = R; p.ldr = ldr; p.zero_page = h->d_zero;
     p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
     p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
@@ -801,6 +805,10 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
         // pass, W was split at load time
         GemmParams q = p;
         q.A = A_s32 ? A_s32 : h->s32_buf; q.lda = A_s32 ? lda_s32 : L.K; q.W = L.Ws32; q.x3 = 2;
+        q.side_a = h->side_a; q.side_b = h->side_b; q.side_lda = h->side_lda; q.side_ldb = h->side_ldb; q.side_c = h->side_c;
+        if (!gemm_pw3x3_supported(q)) q.side_a = q.side_b = nullptr, q.side_c = 0;
+        h->side_done = q.side_c != 0;
+        h->side_c = 0;
         if (gemm_pw3x3_supported(q)) {
             int rc = A_s32 ? SVHIP_OK      // (the producer already wrote the split form: se_apply)
                            : run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(A), lda, h->s32_buf, M, L.K, st); });
@@ -889,29 +897,37 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
                           x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !getenv("SVHIP_X3_KEEP_F32");
     if (s32_only) h->cat_f32_stale = true;
     for (int i = 0; i < 3; ++i) {
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], (s32_only && i > 0) ? nullptr : xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0,
-                            false, 0, PAD_REFLECT, nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
         const void* h2_32 = nullptr;      // F32X3: the chain output in the S32 layout (tdnn2's A operand)
         bool r2_done = false;
-        if (h->x3 && h->h2_s32 && h->res2[i][0].Ws32) {
-            // F32X3: seven launches of gemm_pw3's Res2Net step form; step j reads U_j = c_j + y_{j-1} (S32) and writes y_j (S32, into the
-            // chain output) and U_{j+1}; no fp32 copy of the chain exists
-            char* h2s = static_cast<char*>(h->h2_s32) + r0 * C * 4;
-            char* us[2] = {static_cast<char*>(h->u_s32[0]) + r0 * C8 * 4, static_cast<char*>(h->u_s32[1]) + r0 * C8 * 4};
-            auto step_params = [&](int j) {
-                const ConvLayer& L = h->res2[i][j - 1];
-                GemmParams q;
-                q.A = us[(j - 1) & 1]; q.lda = C8; q.W = L.Ws32; q.Wrows = L.N; q.x3 = 2;
-                q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
-                q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.T = T; q.taps = 3; q.dil = L.dil; q.cin = L.cin; q.pad_mode = PAD_REFLECT;
-                q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
-                q.Y = h2s + (size_t)j * C8 * 4; q.ldy = C;
-                if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
-                return q;
-            };
-            if (gemm_pw3r2_supported(step_params(1))) {
-                if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1), C, h2s, M, C8, st, C); }))) return rc;
-                if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1) + C8, C, us[0], M, C8, st, C8); }))) return rc;
+        // F32X3: seven launches of gemm_pw3's Res2Net step form; step j reads U_j = c_j + y_{j-1} (S32) and writes y_j (S32, into the
+        // chain output) and U_{j+1}; no fp32 copy of the chain exists
+        char* h2s = h->h2_s32 ? static_cast<char*>(h->h2_s32) + r0 * C * 4 : nullptr;
+        char* us[2] = {h->u_s32[0] ? static_cast<char*>(h->u_s32[0]) + r0 * C8 * 4 : nullptr, h->u_s32[1] ? static_cast<char*>(h->u_s32[1]) + r0 * C8 * 4 : nullptr};
+        auto step_params = [&](int j) {
+            const ConvLayer& L = h->res2[i][j - 1];
+            GemmParams q;
+            q.A = us[(j - 1) & 1]; q.lda = C8; q.W = L.Ws32; q.Wrows = L.N; q.x3 = 2;
+            q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
+            q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.T = T; q.taps = 3; q.dil = L.dil; q.cin = L.cin; q.pad_mode = PAD_REFLECT;
+            q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+            q.Y = h2s + (size_t)j * C8 * 4; q.ldy = C;
+            if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
+            return q;
+        };
+        const bool r2_plan = h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && gemm_pw3r2_supported(step_params(1));
+        if (r2_plan) {      // tdnn1 writes the pass-through chunk and the first step's input in the split layout itself (when it takes the X3 kernel)
+            h->side_a = h2s; h->side_lda = C; h->side_b = us[0]; h->side_ldb = C8; h->side_c = C8;
+        }
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], (s32_only && i > 0) ? nullptr : xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0,
+                            false, 0, PAD_REFLECT, nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
+        const bool side_done = h->side_done;
+        h->side_c = 0;
+        if (r2_plan) {
+            {
+                if (!side_done) {
+                    if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1), C, h2s, M, C8, st, C); }))) return rc;
+                    if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(H1) + C8, C, us[0], M, C8, st, C8); }))) return rc;
+                }
                 for (int j = 1; j < 8; ++j) {
                     const GemmParams q = step_params(j);
                     if ((rc = run(h, "gemm_pw3r2", (double)M * h->res2[i][j - 1].flops_per_row, [&]() { return launch_gemm_pw3r2(q, st); }))) return rc;

@@ -475,12 +475,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         } else if (X3) {
             // fp32 out: a lane's accumulator register group IS 16 contiguous bytes (4 channels of one frame)
             float* Yf = reinterpret_cast<float*>(p.Y);
+            // side outputs (GemmParams::side_a / side_b): this wave's 64 channels, when they lie in the first two chunks of the
+            // output, leave in the S32 layout instead of fp32 — hi / lo halves of four values, then one v_permlane16_swap per dword
+            // with the lane 16 up, so that the even lane of a pair holds the hi halves of eight consecutive channels and the odd
+            // lane their lo halves: 16-byte stores
+            const int sc_w = p.side_c;
+            const int side_chunk = (sc_w > 0 && n0 == 0) ? (wn * 64) / sc_w : 2;          // wave-uniform; 0: side_a, 1: side_b, else fp32
+            char* sbase = side_chunk == 0 ? reinterpret_cast<char*>(p.side_a) : reinterpret_cast<char*>(p.side_b);
+            const int64_t sld = (int64_t)(side_chunk == 0 ? p.side_lda : p.side_ldb) * 4;
+            const int scol0 = side_chunk < 2 ? wn * 64 - side_chunk * sc_w : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int nl = wn * 64 + j * 16 + 4 * q4e;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
                 float* yl = Yf + (int64_t)(m0 + wm * 128 + r16e) * p.ldy + n0 + nl;
+                const int na = (scol0 + j * 16 + 4 * q4e) & ~7;                           // the lane pair's first channel inside the side buffer
+                const int boff = (na >> 5) * 128 + (na & 31) * 2 + (q4e & 1) * 64;       // even q4: hi plane, odd q4: lo plane
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     f32x4 v;
@@ -495,7 +506,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                     }
                     if (CS) acc16[i][j] = v;
                     const int m = m0 + wm * 128 + i * 16 + r16e;
-                    if (m < p.M && !(ABL & 8)) *reinterpret_cast<f32x4*>(yl + (int64_t)i * 16 * p.ldy) = v;
+                    const bool in = m < p.M && !(ABL & 8);
+                    if (side_chunk < 2) {
+                        uint32_t hd[2], ld[2];
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
+                            const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
+                            hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
+                            ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(hd[0], ld[0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(hd[1], ld[1], false, false);
+                        if (in) *reinterpret_cast<u32x4*>(sbase + (int64_t)m * sld + boff) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    } else if (in) {
+                        *reinterpret_cast<f32x4*>(yl + (int64_t)i * 16 * p.ldy) = v;
+                    }
                 }
             }
         } else {
@@ -701,6 +727,9 @@ bool gemm_pw3x3_supported(const GemmParams& p) {
     if (!p.bias || !p.scale || !p.shift) return false;
     if (p.N % 256 != 0 || p.K != p.Kp || p.K % 64 != 0 || p.K < 128 || p.lda < p.K || p.lda % 32 != 0 || p.ldy % 4 != 0) return false;      // whole 32-k blocks, an even number of them
     if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;
+    if (p.side_c && (!(p.side_c == 64 || p.side_c == 128) || !p.side_a || !p.side_b || p.side_lda % 32 != 0 || p.side_ldb % 32 != 0 || p.side_lda < p.side_c ||
+                     p.side_ldb < p.side_c || ((reinterpret_cast<uintptr_t>(p.side_a) | reinterpret_cast<uintptr_t>(p.side_b)) & 127)))
+        return false;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024 || p.M <= 0 || p.Wrows < p.N) return false;

@@ -74,6 +74,12 @@ struct GemmParams {
     // from row m of a second matrix (the 1 x 1 shortcut of a RawNet2 block as part of conv2's GEMM: W is [N][K + K3], Kp = K + K3)
     const void* A3 = nullptr;
     int lda3 = 0, K3 = 0;
+    // x3 == 2, pointwise form only: channels [0, side_c) of the output go to side_a and [side_c, 2 side_c) to side_b in the S32 split
+    // layout (row strides in elements) INSTEAD of the fp32 output — the Res2Net pass-through chunk and the first step's input of
+    // an F32X3 handle (side_c = C / 8 = 64 or 128)
+    void* side_a = nullptr;
+    void* side_b = nullptr;
+    int side_lda = 0, side_ldb = 0, side_c = 0;
     int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
