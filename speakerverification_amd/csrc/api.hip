@@ -31,6 +31,8 @@ struct ConvLayer {            // one conv1d as a GEMM operand set (device pointe
     int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, dil = 1, cin = 0;
     void* W = nullptr;        // packed [Np][Kp] in the compute dtype
     void* Wsplit = nullptr;   // SVHIP_F32X3 handles: the same matrix as (hi bf16 << 16 | lo bf16) words, for gemm_pw's split path
+    void* Wcv = nullptr;      // SVHIP_F32X3 handles, odd-tap convolutions with N % 256 == 0 (blocks.0): [N][cv_Kp] S32, k = tap * cv_cin + c with the
+    int cv_cin = 0, cv_Kp = 0; // input channels zero-padded to cv_cin (a multiple of 32) and cv_Kp = taps * cv_cin rounded up to 64: gemm_pw3's CV form
     void* Ws32 = nullptr;     // SVHIP_F32X3 handles, pointwise layers with N % 256 == 0 and K % 64 == 0: the S32 split layout (per row, per
                               // 32 k: 32 hi bf16 | 32 lo bf16) of gemm_pw3's X3 form
     float* bias = nullptr;    // [N] or null
@@ -507,6 +509,22 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
                 if ((rc = dev_upload(h, &d32, s32))) return rc;
                 L.Ws32 = d32;
             }
+            if (taps >= 3 && taps <= 7 && (taps & 1) && N % 256 == 0 && N != cin) {      // the conv-gather X3 form (gemm_pw3cv)
+                const int ccv = round_up(cin, 32), kcv = round_up(taps * ccv, 64);
+                std::vector<uint16_t> s32((size_t)N * kcv * 2, 0);
+                for (int n = 0; n < N; ++n)
+                    for (int t = 0; t < taps; ++t)
+                        for (int c = 0; c < cin; ++c) {
+                            const uint32_t wv = ws[(size_t)n * L.Kp + t * cin + c];
+                            const int k = t * ccv + c;
+                            const size_t o = (size_t)n * kcv * 2 + (size_t)(k >> 5) * 64 + (k & 31);
+                            s32[o] = (uint16_t)(wv >> 16);
+                            s32[o + 32] = (uint16_t)(wv & 0xffffu);
+                        }
+                uint16_t* dcv;
+                if ((rc = dev_upload(h, &dcv, s32))) return rc;
+                L.Wcv = dcv; L.cv_cin = ccv; L.cv_Kp = kcv;
+            }
         }
     }
     if (!bname.empty()) {
@@ -875,7 +893,23 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     if ((rc = run(h, "prologue", 0, [&]() {
              return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st);
          }))) return rc;
-    if ((rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
+    bool b0_done = false;
+    if (h->x3 && h->blocks0.Wcv && h->s32_buf) {
+        // F32X3: blocks.0 on the persistent kernel's conv-gather form: the features go to the S32 layout with rows zero-padded to
+        // cv_cin channels (one small pass), the im2col view is formed by the operand DMAs
+        const ConvLayer& L = h->blocks0;
+        GemmParams q;
+        q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
+        q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
+        q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
+        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+        if (gemm_pw3cv_supported(q)) {
+            if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(X_in), c.n_mels, h->s32_buf, M, L.cv_cin, st, L.cv_cin, c.n_mels); }))) return rc;
+            if ((rc = run(h, "gemm_pw3cv", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3cv(q, st); }))) return rc;
+            b0_done = true;
+        }
+    }
+    if (!b0_done && (rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
     const void* xin = X0;
     int ldin = C;
     // F32X3: se_apply also leaves each block output in the S32 split layout (CAT's twin), so tdnn1 of the next block and mfa read

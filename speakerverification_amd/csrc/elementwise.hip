@@ -543,14 +543,17 @@ __global__ __launch_bounds__(256) void split_words_kernel(const float* __restric
 
 // fp32 rows -> the S32 split layout of gemm_pw3's X3 form: per row, per block of 32 k: 32 hi bf16 | 32 lo bf16 (128 bytes).
 // One thread = 8 consecutive k: 32 bytes in, 16 + 16 bytes out.
-__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K, int ldd) {
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K, int ldd, int kvalid) {
     const int per_row = K >> 3;
     const int64_t n = M * per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / per_row;
         const int k0 = (int)(i - row * per_row) * 8;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src + row * ld + k0);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(src + row * ld + k0 + 4);
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, b = a;                   // columns >= kvalid (a multiple of 8) are zero padding
+        if (k0 < kvalid) {
+            a = *reinterpret_cast<const f32x4*>(src + row * ld + k0);
+            b = *reinterpret_cast<const f32x4*>(src + row * ld + k0 + 4);
+        }
         typedef bf16_t bf16x8_ __attribute__((ext_vector_type(8)));
         bf16x8_ hi, lo;
 #pragma unroll
@@ -566,11 +569,12 @@ __global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd) {
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd, int kvalid) {
     if (ldd == 0) ldd = K;
-    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0 || ldd % 32 != 0 || ldd < K) return hipErrorInvalidValue;
+    if (kvalid == 0) kvalid = K;
+    if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0 || ldd % 32 != 0 || ldd < K || kvalid % 8 != 0 || kvalid > K) return hipErrorInvalidValue;
     const int64_t g = (M * (K / 8) + 255) / 256;
-    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K, ldd);
+    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K, ldd, kvalid);
     return hipGetLastError();
 }
 

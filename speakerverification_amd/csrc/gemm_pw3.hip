@@ -82,9 +82,11 @@ constexpr int ABL = 0;
 // What bounds it now: every CU reaches its epilogue at the same time, and 384 KB per tile (c in, y and U out) at a CU's share of
 // the HBM bandwidth (~10 B / cycle) IS ~38 k cycles, while HBM idles through the K loops; overlapping the two needs two tiles
 // in flight per CU (a 128 x 128 / four-wave re-cut with two workgroups per CU), not built.
-template <int EPI, int CS, bool X3, bool R2 = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
+template <int EPI, int CS, bool X3, bool R2 = false, bool CV = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
+    static_assert(!CV || (X3 && !R2), "the conv-gather form (CV) is the pointwise X3 kernel with gathered X rows");
+    constexpr bool GATHER = R2 || CV;          // X half-tiles = im2col view of a dilated convolution over the rows of an utterance
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = (X3 ? 32 : 16) + 8 * CS;    // vector-memory stores a wave issues in one tile's epilogue
     constexpr int ESZ = X3 ? 4 : 2;                 // bytes per k of an operand row
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     auto set_src = [&](int m0, int n0) {
         const int lane = lane_now();
         // (R2: the gathered rows lie up to 2 dil <= 8 rows before the lane's own; the base sits 8 rows low so that offsets stay >= 0)
-        abase = reinterpret_cast<const char*>(p.A) + ((int64_t)m0 - (R2 ? 8 : 0)) * p.lda * ESZ;
+        abase = reinterpret_cast<const char*>(p.A) + ((int64_t)m0 - (GATHER ? 8 : 0)) * p.lda * ESZ;
         wbase = reinterpret_cast<const char*>(p.W) + (int64_t)n0 * p.Kp * ESZ;
         const int mmax = p.M - 1 - m0, nmax = p.Wrows - 1 - n0;
 #pragma unroll
@@ -139,20 +141,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
             for (int ty = 0; ty < 2; ++ty) {
                 const int m = min((rho >> 6) * 128 + ty * 64 + (rho & 63), mmax);
-                xo[ty][jj] = (uint32_t)((m + (R2 ? 8 : 0)) * p.lda * ESZ + c * 16);
-                if (R2) { const int t = (m0 + m) % p.T; xt[jj] = ty == 0 ? (uint32_t)t : (xt[jj] | ((uint32_t)t << 16)); }
+                xo[ty][jj] = (uint32_t)((m + (GATHER ? 8 : 0)) * p.lda * ESZ + c * 16);
+                if (GATHER) { const int t = (m0 + m) % p.T; xt[jj] = ty == 0 ? (uint32_t)t : (xt[jj] | ((uint32_t)t << 16)); }
                 const int n = min((rho >> 5) * 64 + ty * 32 + (rho & 31), nmax);
                 wo[ty][jj] = (uint32_t)(n * p.Kp * ESZ + c * 16);
             }
         }
     };
-    const int r2_shift = R2 ? __builtin_ctz((unsigned)(p.cin >> 5)) : 0;      // K tiles per tap = cin / 32 (a power of two: host check)
+    // K tiles per tap = cin / 32 (p.cin: the channel count of a row of A, a multiple of 32); tap = kt / ktpt by multiplication
+    // (kt < 64); K tiles past the last tap (padding of the K tile count to an even number) re-read the last tap: their weights are 0
+    const int ktpt = GATHER ? (p.cin >> 5) : 1;
+    const int tap_mul = GATHER ? 65536 / ktpt + 1 : 0;
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
-        const bool gather = R2 && ty < 2;
-        const int tap = gather ? (kt >> r2_shift) : 0;
-        const char* ub = (ty < 2 ? abase : wbase) + (int64_t)(gather ? (kt - (tap << r2_shift)) : kt) * 128;
-        const int shift = gather ? (tap - 1) * p.dil : 0;
+        const bool gather = GATHER && ty < 2;
+        const int tap = gather ? min((kt * tap_mul) >> 16, p.taps - 1) : 0;
+        const char* ub = (ty < 2 ? abase : wbase) + (int64_t)(gather ? min(kt - tap * ktpt, ktpt - 1) : kt) * 128;
+        const int shift = gather ? (tap - (p.taps >> 1)) * p.dil : 0;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             uint32_t o = ty < 2 ? xo[ty][jj] : wo[ty - 2][jj];
@@ -678,6 +683,15 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+hipError_t launch_cv(const GemmParams& p, hipStream_t stream) {
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_GELU, 0, true, false, true>), PW3_LDS)) return e;
+    const int cap = pw3_grid_cap(p.num_cu);
+    hipLaunchKernelGGL((gemm_pw3_kernel<EPI_GELU, 0, true, false, true>), dim3(ntiles < cap ? ntiles : cap), dim3(512), PW3_LDS, stream, p);
+    return hipGetLastError();
+}
+
 template <int EPI, bool X3>
 hipError_t launch_cs(const GemmParams& p, hipStream_t stream) {
     if (!p.colsum) return launch_inst<EPI, 0, X3>(p, stream);
@@ -767,6 +781,27 @@ hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream) {
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw3x3_supported(p)) return hipErrorInvalidValue;
     return launch_cs<EPI_GELU, true>(p, stream);
+}
+
+// The conv-gather X3 form (ECAPA blocks.0 on F32X3 handles): A = the layer input in the S32 layout with rows of p.cin channels
+// (a multiple of 32: the real channels zero-padded), W = [N][Kp] S32 with k = tap * cin + c and Kp = taps * cin rounded up to a
+// multiple of 64 (zero columns), reflect padding inside each utterance, GELU -> BN, fp32 out.
+bool gemm_pw3cv_supported(const GemmParams& p) {
+    if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.colsum || p.side_c) return false;
+    if (p.taps < 3 || p.taps > 7 || !(p.taps & 1) || p.pad_mode != PAD_REFLECT || p.dil < 1 || (p.taps >> 1) * p.dil > 8) return false;
+    if (p.act1 != ACT_GELU || p.act2 != ACT_NONE || !p.bias || !p.scale || !p.shift) return false;
+    if (p.cin % 32 != 0 || p.cin < 32 || p.lda != p.cin || p.K != p.taps * p.cin || p.Kp % 64 != 0 || p.Kp < p.K || p.Kp - p.K >= 64 || p.Kp > 63 * 32) return false;
+    if (p.N % 256 != 0 || p.ldy % 4 != 0 || p.Wrows < p.N) return false;
+    if (p.T <= (p.taps >> 1) * p.dil || p.T >= 65536 || p.M <= 0 || p.M % p.T != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
+         reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
+    if (p.num_cu <= 0 || p.num_cu > 1024) return false;
+    return ((p.M + 255) / 256) * (p.N / 256) > pw3_grid_cap(p.num_cu);
+}
+
+hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pw3cv_supported(p)) return hipErrorInvalidValue;
+    return launch_cv(p, stream);
 }
 
 }  // namespace svhip

@@ -127,11 +127,13 @@ int pw3_grid_cap(int num_cu);
 // 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream);
+bool gemm_pw3cv_supported(const GemmParams& p);          // conv-gather X3 form (odd taps, reflect): see gemm_pw3.hip
+hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream);
 // one Res2Net step of an F32X3 handle on the same kernel (dilated k = 3 conv gathered from an S32 input, outputs in S32)
 bool gemm_pw3r2_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream);
 // fp32 (M, K) rows (stride ld) -> S32 layout, rows of ldd elements (4 bytes each; 0: dense, ldd = K)
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0);
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0, int kvalid = 0);
 hipError_t launch_unsplit_s32(const void* src, int lds32, float* dst, int ld, int64_t M, int K, hipStream_t stream);   // v = hi + lo
 // row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
 int gemm_colsum_groups(const GemmParams& p, bool bf16);
