@@ -120,6 +120,7 @@ struct svhip_handle {
     void *side_a = nullptr, *side_b = nullptr;      // pending S32 side outputs of the next conv_gemm (GemmParams::side_*), consumed by it
     int side_lda = 0, side_ldb = 0, side_c = 0;
     bool side_done = false;       // ... and whether that GEMM wrote them
+    bool x0_is_s32 = false;       // SVHIP_F32X3: the last forward wrote blocks.0's output (X0) in the split layout
     bool cat_f32_stale = false;   // SVHIP_F32X3: the last forward left the block outputs only in cat_s32 (svhip_get_stage converts on demand)
     void* cat_s32 = nullptr;      // SVHIP_F32X3: the SE-Res2Net block outputs (the CAT buffer) in the S32 layout, written by se_apply
     void* h2_s32 = nullptr;       // SVHIP_F32X3: the Res2Net chain output (H2's twin, S32 only) and the two step-input buffers (M x C/8)
@@ -893,29 +894,9 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     if ((rc = run(h, "prologue", 0, [&]() {
              return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st);
          }))) return rc;
-    bool b0_done = false;
-    if (h->x3 && h->blocks0.Wcv && h->s32_buf) {
-        // F32X3: blocks.0 on the persistent kernel's conv-gather form: the features go to the S32 layout with rows zero-padded to
-        // cv_cin channels (one small pass), the im2col view is formed by the operand DMAs
-        const ConvLayer& L = h->blocks0;
-        GemmParams q;
-        q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
-        q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
-        q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
-        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
-        if (gemm_pw3cv_supported(q)) {
-            if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(X_in), c.n_mels, h->s32_buf, M, L.cv_cin, st, L.cv_cin, c.n_mels); }))) return rc;
-            if ((rc = run(h, "gemm_pw3cv", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3cv(q, st); }))) return rc;
-            b0_done = true;
-        }
-    }
-    if (!b0_done && (rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
-    const void* xin = X0;
-    int ldin = C;
     // F32X3: se_apply also leaves each block output in the S32 split layout (CAT's twin), so tdnn1 of the next block and mfa read
     // their A operand without a conversion pass
     char* cat32 = h->cat_s32 ? static_cast<char*>(h->cat_s32) + r0 * C3 * 4 : nullptr;
-    const void* xin32 = nullptr;
     // ... and when every consumer of a block output takes the split operand at this batch size (tdnn1 of the next block, mfa: the
     // persistent X3 kernel; the next se_apply reads its residual as hi + lo), the fp32 copy is not written at all
     auto x3_route = [&](const ConvLayer& L, const void* a32, int lda32, bool cs) {
@@ -930,6 +911,32 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     const bool s32_only = cat32 && x3_route(h->tdnn1[1], cat32, C3, false) && x3_route(h->tdnn1[2], cat32, C3, false) &&
                           x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !getenv("SVHIP_X3_KEEP_F32");
     if (s32_only) h->cat_f32_stale = true;
+    bool b0_done = false, x0_s32 = false;
+    if (h->x3 && h->blocks0.Wcv && h->s32_buf) {
+        // F32X3: blocks.0 on the persistent kernel's conv-gather form: the features go to the S32 layout with rows zero-padded to
+        // cv_cin channels (one small pass), the im2col view is formed by the operand DMAs
+        const ConvLayer& L = h->blocks0;
+        GemmParams q;
+        q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
+        q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
+        q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
+        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+        // (with s32_only and tdnn1 of the first block on the X3 kernel, X0 itself is written in the split layout: no conversion pass,
+        //  block 1's residual is read as hi + lo, svhip_get_stage rebuilds the fp32 view)
+        q.y_s32 = (s32_only && x3_route(h->tdnn1[0], X0, C, false)) ? 1 : 0;
+        if (gemm_pw3cv_supported(q)) {
+            if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(X_in), c.n_mels, h->s32_buf, M, L.cv_cin, st, L.cv_cin, c.n_mels); }))) return rc;
+            if ((rc = run(h, "gemm_pw3cv", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3cv(q, st); }))) return rc;
+            b0_done = true;
+            x0_s32 = q.y_s32 != 0;
+        }
+    }
+    if (!b0_done && (rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
+    h->x0_is_s32 = x0_s32;
+    const void* xin = x0_s32 ? nullptr : X0;
+    int ldin = C;
+    const void* xin32 = x0_s32 ? X0 : nullptr;
+    int ldin32 = C;
     for (int i = 0; i < 3; ++i) {
         const void* h2_32 = nullptr;      // F32X3: the chain output in the S32 layout (tdnn2's A operand)
         bool r2_done = false;
@@ -952,8 +959,8 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         if (r2_plan) {      // tdnn1 writes the pass-through chunk and the first step's input in the split layout itself (when it takes the X3 kernel)
             h->side_a = h2s; h->side_lda = C; h->side_b = us[0]; h->side_ldb = C8; h->side_c = C8;
         }
-        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], (s32_only && i > 0) ? nullptr : xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0,
-                            false, 0, PAD_REFLECT, nullptr, 0, nullptr, 0, 0, xin32, C3))) return rc;
+        if ((rc = conv_gemm(h, "gemm_tdnn", h->tdnn1[i], (s32_only && (i > 0 || x0_s32)) ? nullptr : xin, ldin, H1, C, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0,
+                            false, 0, PAD_REFLECT, nullptr, 0, nullptr, 0, 0, xin32, ldin32))) return rc;
         const bool side_done = h->side_done;
         h->side_c = 0;
         if (r2_plan) {
@@ -1008,12 +1015,13 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         void* xout32 = cat32 ? cat32 + (size_t)i * C * 4 : nullptr;
         if ((rc = run(h, "se_apply", 0, [&]() {
                  return launch_se_apply(H3, C, d_s2, xin, ldin, s32_only ? nullptr : xout, C3, bf, B, T, C, st, xout32, C3,
-                                        s32_only && i > 0 ? xin32 : nullptr, C3);
+                                        s32_only && (i > 0 || x0_s32) ? xin32 : nullptr, ldin32);
              })))
             return rc;
         xin = xout;
         xin32 = xout32;
         ldin = C3;
+        ldin32 = C3;
     }
     if ((rc = conv_gemm(h, "gemm_mfa", h->mfa, s32_only ? nullptr : CAT, C3, MFA, C3, M, ACT_GELU, ACT_NONE, nullptr, 0, nullptr, 0, false, 0,
                         PAD_REFLECT, nullptr, 0, cs_base, 1, h->colsum_region, cat32, C3))) return rc;
@@ -2012,7 +2020,13 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     bool f32 = !h->bf16;
     const std::string n(name);
     if (n == "input") { src = h->X_in; cols = ld = h->cfg.n_mels; }
-    else if (n == "blocks.0") { src = h->X0; cols = ld = C; }
+    else if (n == "blocks.0") {
+        src = h->X0; cols = ld = C;
+        if (h->x0_is_s32 && out) {            // F32X3: X0 holds hi | lo planes; the fp32 view goes to the (idle) operand staging buffer
+            SV_HIP(h, launch_unsplit_s32(h->X0, C, static_cast<float*>(h->s32_buf), C, (int64_t)M, C, h->stream));
+            src = h->s32_buf;
+        }
+    }
     else if (n == "blocks.1" || n == "blocks.2" || n == "blocks.3") {
         const int i = n.back() - '1';
         src = off(h->CAT, (size_t)i * C, e); cols = C; ld = C3;

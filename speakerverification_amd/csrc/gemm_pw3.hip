@@ -485,10 +485,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             // with the lane 16 up, so that the even lane of a pair holds the hi halves of eight consecutive channels and the odd
             // lane their lo halves: 16-byte stores
             const int sc_w = p.side_c;
-            const int side_chunk = (sc_w > 0 && n0 == 0) ? (wn * 64) / sc_w : 2;          // wave-uniform; 0: side_a, 1: side_b, else fp32
-            char* sbase = side_chunk == 0 ? reinterpret_cast<char*>(p.side_a) : reinterpret_cast<char*>(p.side_b);
-            const int64_t sld = (int64_t)(side_chunk == 0 ? p.side_lda : p.side_ldb) * 4;
-            const int scol0 = side_chunk < 2 ? wn * 64 - side_chunk * sc_w : 0;
+            // wave-uniform; 0: side_a (or, with y_s32, the whole output: Y itself is an S32 buffer), 1: side_b, else fp32
+            const int side_chunk = p.y_s32 ? 0 : (sc_w > 0 && n0 == 0) ? (wn * 64) / sc_w : 2;
+            char* sbase = p.y_s32 ? reinterpret_cast<char*>(p.Y) : side_chunk == 0 ? reinterpret_cast<char*>(p.side_a) : reinterpret_cast<char*>(p.side_b);
+            const int64_t sld = (int64_t)(p.y_s32 ? p.ldy : side_chunk == 0 ? p.side_lda : p.side_ldb) * 4;
+            const int scol0 = p.y_s32 ? n0 + wn * 64 : side_chunk < 2 ? wn * 64 - side_chunk * sc_w : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int nl = wn * 64 + j * 16 + 4 * q4e;
@@ -736,7 +737,7 @@ hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream) {
 
 // The X3 form (p.x3 == 2: A and W in the S32 split layout, fp32 out): the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p) {
-    if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.taps > 1) return false;
+    if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.taps > 1 || p.y_s32) return false;
     if (p.act1 != ACT_GELU || p.act2 != ACT_NONE) return false;
     if (!p.bias || !p.scale || !p.shift) return false;
     if (p.N % 256 != 0 || p.K != p.Kp || p.K % 64 != 0 || p.K < 128 || p.lda < p.K || p.lda % 32 != 0 || p.ldy % 4 != 0) return false;      // whole 32-k blocks, an even number of them
@@ -791,7 +792,7 @@ bool gemm_pw3cv_supported(const GemmParams& p) {
     if (p.taps < 3 || p.taps > 7 || !(p.taps & 1) || p.pad_mode != PAD_REFLECT || p.dil < 1 || (p.taps >> 1) * p.dil > 8) return false;
     if (p.act1 != ACT_GELU || p.act2 != ACT_NONE || !p.bias || !p.scale || !p.shift) return false;
     if (p.cin % 32 != 0 || p.cin < 32 || p.lda != p.cin || p.K != p.taps * p.cin || p.Kp % 64 != 0 || p.Kp < p.K || p.Kp - p.K >= 64 || p.Kp > 63 * 32) return false;
-    if (p.N % 256 != 0 || p.ldy % 4 != 0 || p.Wrows < p.N) return false;
+    if (p.N % 256 != 0 || p.ldy % 4 != 0 || p.Wrows < p.N || (p.y_s32 && (p.ldy % 32 != 0 || (reinterpret_cast<uintptr_t>(p.Y) & 127)))) return false;
     if (p.T <= (p.taps >> 1) * p.dil || p.T >= 65536 || p.M <= 0 || p.M % p.T != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;

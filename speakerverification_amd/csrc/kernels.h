@@ -77,6 +77,7 @@ struct GemmParams {
     // x3 == 2, pointwise form only: channels [0, side_c) of the output go to side_a and [side_c, 2 side_c) to side_b in the S32 split
     // layout (row strides in elements) INSTEAD of the fp32 output — the Res2Net pass-through chunk and the first step's input of
     // an F32X3 handle (side_c = C / 8 = 64 or 128)
+    int y_s32 = 0;                  // x3 == 2, pointwise / conv-gather forms: Y is written in the S32 split layout (ldy in elements) instead of fp32
     void* side_a = nullptr;
     void* side_b = nullptr;
     int side_lda = 0, side_ldb = 0, side_c = 0;
