@@ -1849,11 +1849,16 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         // chunks of 131 072 embeddings: the candidate statistics of chunk c run on a second stream under the MFMA kernel of
         // chunk c + 1 (two candidate buffers; the kernels meet through events)
         const int64_t chunk = std::min<int64_t>(N, 131072);
-        const int nbuf = N > chunk ? 2 : 1;
         void *mb, *cand, *cnt, *flag;
         const size_t mb_bytes = (size_t)(D + 32) * D * 4;          // [MB | slice partials of its computation]
         const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 2;
-        if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + cohort_moments_scratch_bytes(D), &mb))) return rc;
+        // (the exact default is the six-bf16-MFMA form where it is built: scores to fp32 rounding at 2.7 x the fp32 matrix rate)
+        const bool x6 = asnorm_fused6_supported(D) && !getenv("SVHIP_ASNORM_F32MFMA");
+        // (x6: the candidate kernel takes 1.7 ms of 17 on its own and 7 when it shares the CUs with the matrix kernel: one stream.
+        //  The fp32-MFMA form keeps the second stream: 26.1 - 26.9 against 27.5 ms)
+        const int nbuf = (N > chunk && !x6) ? 2 : 1;
+        const size_t mom_bytes = (cohort_moments_scratch_bytes(D) + 255) & ~(size_t)255;
+        if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + mom_bytes + (x6 ? asnorm_planes_bytes(D, K) : 0), &mb))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CAND, cand_elems * 4 * nbuf, &cand))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CNT, cnt_elems * 4 * nbuf, &cnt))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_FLAG, (size_t)(N + 1) * 4, &flag))) return rc;
@@ -1866,6 +1871,11 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         if ((rc = run(h, "asnorm_cohort_moments", 0, [&]() { return launch_cohort_moments((const float*)dC, K, D, (float*)mb, (float*)((char*)mb + mb_bytes), h->stream); }))) return rc;
         AsnormFusedParams fp;
         fp.cohort = (const float*)dC; fp.K = K; fp.MB = (const float*)mb; fp.z = asnorm_tail_z(K, top);
+        if (x6) {
+            void* planes = (char*)mb + mb_bytes + mom_bytes;
+            if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream); }))) return rc;
+            fp.planes = planes;
+        }
         int c = 0;
         for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
             const int64_t rows = std::min(chunk, N - r0);

@@ -169,6 +169,160 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused_kernel(AsnormFusedParams 
     if (valid) p.cnt[row * 2 + h] = cnt;
 }
 
+// ---- the same kernel on SIX bf16 MFMAs per product block ("x6"): fp32-grade scores at 2.7 x the fp32 matrix rate ----------------
+// An fp32 value splits EXACTLY into three bf16 parts, v = h + m + l (8 + 8 + 8 mantissa bits), so a product is the nine partial
+// products of the parts; the three smallest (m l, l m, l l: <= 2^-26 of |a b|) are dropped and the other six are bf16 MFMAs with
+// exact fp32 products and fp32 accumulation: h h, h m, m h, h l, l h, m m.  A score (|e| = |c| = 1) is then within 1.5e-8 of the
+// exact-fp32-MFMA kernel's plus the usual accumulation rounding — three orders below anything AS-norm can see (the 2^-17 of the
+// three-product form is NOT: 2e-4 on the normalised scores) — while v_mfma_f32_32x32x16_bf16 does 16 k values in the 32
+// cycles v_mfma_f32_32x32x2_f32 needs for one: six of them per 16 k against eight fp32 MFMAs of 64 cycles, 192 against 512 cycles.
+// Same structure as above (embeddings = B operand in registers, cohort blocks through LDS, lane-local selection, exact moments as
+// leading pseudo-cohort blocks); the cohort image (pseudo rows first, then the K cohort rows) is split into three bf16 planes once
+// per call (split3_planes_kernel).  D = 192 only: the B operand is 144 VGPRs.
+template <int D>
+__global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = D / 8;                       // 16-byte chunks (8 bf16) per row of a plane
+    constexpr int PL = 32 * D * 2;                  // one plane of a block of 32 rows
+    constexpr int BLK = 3 * PL;
+    constexpr int NDMA = 3 * 32 * CH / 256;         // DMA instructions per thread per block
+    constexpr int NP = D / 32 + 1;                  // pseudo-cohort blocks: rows of M, then cbar
+    constexpr int NS = D / 16;                      // MFMA k steps per block
+    static_assert(D % 64 == 0 && (3 * 32 * CH) % 256 == 0 && CH % 8 == 0, "block image: whole DMA rounds, chunk groups of 8");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + j;
+    const bool valid = row < p.N;
+    const float* __restrict__ erow = p.E + (valid ? row : p.N - 1) * D;
+
+    // B operand: embedding j, k = 16 s + 8 h .. + 7 for k step s, in three bf16 parts
+    bf16x8 bh[NS], bm[NS], bl[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(erow + 16 * s_ + 8 * h);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(erow + 16 * s_ + 8 * h + 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v = u < 4 ? v0[u] : v1[u - 4];
+            const bf16_t a = static_cast<bf16_t>(v);
+            const float r1 = v - static_cast<float>(a);
+            const bf16_t b = static_cast<bf16_t>(r1);
+            bh[s_][u] = a;
+            bm[s_][u] = b;
+            bl[s_][u] = static_cast<bf16_t>(r1 - static_cast<float>(b));
+        }
+    }
+
+    const int rows_total = NP * 32 + p.K;
+    const int nb = (rows_total + 31) / 32;
+    const char* planes = reinterpret_cast<const char*>(p.planes);
+    const int64_t plane_bytes = (int64_t)rows_total * D * 2;
+    // the image is lane-linear (16 bytes per lane): position -> (plane, row, chunk slot); the swizzle goes on the source chunk
+    auto issue = [&](int b, int buf) {
+        const int r0 = b * 32;
+        const int limit = rows_total - 1 - r0;          // the last block clamps its rows
+#pragma unroll
+        for (int q = 0; q < NDMA; ++q) {
+            const int pidx = q * 256 + tid;
+            const int pl = pidx / (32 * CH), rem = pidx - pl * (32 * CH);
+            const int i = rem / CH, cs = rem - i * CH;
+            const int c = (cs & ~7) | ((cs ^ (i >> 1)) & 7);
+            const char* src = planes + pl * plane_bytes + ((int64_t)(r0 + min(i, limit)) * D + c * 8) * 2;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + buf * BLK + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto rd = [&](int buf, int pl, int s_) {          // A fragment: cohort row j of the block, k = 16 s + 8 h .. + 7
+        const int cs = 2 * s_ + h;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BLK + pl * PL + j * (D * 2) + (((cs & ~7) | ((cs ^ (j >> 1)) & 7)) << 4));
+    };
+    auto mfma_block = [&](int buf) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // (no read-ahead of the A fragments: the fp32 kernel measured none / one group / half a block ahead as 26.1 / 26.7 / 27.5 ms —
+        //  the partner wave covers the LDS latency — and here every register counts)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const bf16x8 ah = rd(buf, 0, s_), am = rd(buf, 1, s_), al = rd(buf, 2, s_);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return acc;
+    };
+
+    float second = 0.0f, tau = 0.0f;
+    int cnt = 0;
+    float* candl = p.cand + ((valid ? row : 0) * 2 + h) * AF_CAPL;
+    // acc[r] = score of image row 32 b + (r & 3) + 8 (r >> 2) + 4 h against embedding j
+    auto process = [&](const f32x16& a, int b) {
+        if (b < NP - 1) {               // rows of M: (M e)_i . e_i
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + 32 * b + 8 * g + 4 * h);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) second = fmaf(a[4 * g + u], ev[u], second);
+            }
+        } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of the h = 0 lanes
+            const float m = __shfl(a[0], j, 64);
+            const float sec = second + __shfl_xor(second, 32, 64);
+            tau = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+        } else {
+            const int kb = (b - NP) * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = kb + (r & 3) + 8 * (r >> 2);
+                const float v = a[r];
+                if (i < p.K && v > tau) {
+                    if (cnt < AF_CAPL && valid) candl[cnt] = v;
+                    ++cnt;
+                }
+            }
+        }
+    };
+
+    issue(0, 0);
+    f32x16 accp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+    for (int b = 0; b < nb; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block b has landed (and the candidate stores of one block ago, long since)
+        __syncthreads();                                       // ... for every wave; nobody still reads the other buffer
+        if (b + 1 < nb) issue(b + 1, (b + 1) & 1);
+        // the selection of the PREVIOUS block goes first: its candidate stores are then a whole MFMA phase old at the next wait
+        // (issued after the MFMAs they sat right in front of that wait: 18.8 ms for 1.2 M embeddings)
+        if (b > 0) process(accp, b - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        accp = mfma_block(b & 1);
+    }
+    process(accp, nb - 1);
+    if (valid) p.cnt[row * 2 + h] = cnt;
+}
+
+// fp32 rows -> three bf16 planes [3][rows_total][D]: rows [0, n0) from A (the pseudo-cohort rows MB), the rest from B (the cohort)
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
+                                                            bf16_t* __restrict__ planes) {
+    const int64_t n = (int64_t)(n0 + n1) * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D;
+        const float v = r < n0 ? A[i] : B[i - (int64_t)n0 * D];
+        const bf16_t a = static_cast<bf16_t>(v);
+        const float r1 = v - static_cast<float>(a);
+        const bf16_t b = static_cast<bf16_t>(r1);
+        planes[i] = a;
+        planes[n + i] = b;
+        planes[2 * n + i] = static_cast<bf16_t>(r1 - static_cast<float>(b));
+    }
+}
+
 // one wave per embedding: exact statistics of the top-`top` of its candidates; rows that cannot be decided are flagged
 __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cnt, int64_t rows,
                                                                 int top, float* __restrict__ mu, float* __restrict__ sigma,
@@ -280,10 +434,29 @@ hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, f
     return hipGetLastError();
 }
 
+bool asnorm_fused6_supported(int D) { return D == 192; }
+size_t asnorm_planes_bytes(int D, int K) { return (size_t)3 * (D + 32 + K) * D * 2; }
+
+hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream) {
+    if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)(D + 32 + K) * D;
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
+    return hipGetLastError();
+}
+
 hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t stream) {
     if (p.N <= 0) return hipSuccess;
     if (!asnorm_fused_supported(D, p.K, 1) || !p.E || !p.cohort || !p.MB || !p.cand || !p.cnt) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(p.E) | reinterpret_cast<uintptr_t>(p.cohort) | reinterpret_cast<uintptr_t>(p.MB)) & 15) return hipErrorInvalidValue;
+    if (p.planes) {                                       // the six-bf16-MFMA form
+        if (!asnorm_fused6_supported(D) || (reinterpret_cast<uintptr_t>(p.planes) & 15)) return hipErrorInvalidValue;
+        static DeviceOnce attr6;
+        const int lds6 = 2 * 3 * 32 * 192 * 2;
+        if (hipError_t e = set_max_dynamic_lds(attr6, reinterpret_cast<const void*>(asnorm_fused6_kernel<192>), lds6)) return e;
+        hipLaunchKernelGGL((asnorm_fused6_kernel<192>), dim3((unsigned)((p.N + 127) / 128)), dim3(256), lds6, stream, p);
+        return hipGetLastError();
+    }
     switch (D) {
         case 192: return launch_fused_d<192>(p, stream);
         case 256: return launch_fused_d<256>(p, stream);

@@ -23,13 +23,16 @@ __device__ __forceinline__ int wave_isum(int v) {
 // threshold counted exactly.
 template <int PER>
 __device__ __forceinline__ void select_stats(const uint32_t (&k)[PER], int top, float& mean_out, float& sd_out) {
+    // (the count of a step is the sum of the population counts of PER lane masks: scalar work, no cross-lane shuffle — as
+    //  per-lane counts + a six-step butterfly the search was 192 dependent ds_bpermute round trips per embedding and the candidate
+    //  kernel took as long as the matrix kernel it runs beside)
     uint32_t prefix = 0;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) cnt += (k[j] >= cand);
-        if (wave_isum(cnt) >= top) prefix = cand;
+        for (int j = 0; j < PER; ++j) cnt += __popcll(__ballot(k[j] >= cand));
+        if (cnt >= top) prefix = cand;
     }
     const float vth = fkey_inv(prefix);
     float sum = 0.0f;

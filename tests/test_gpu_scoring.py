@@ -280,3 +280,31 @@ def test_whole_trial_scoring_modes(eng, n_files, n_crops, D, P):
     assert np.array_equal(eng.mean_crops(Fd).cpu().numpy(), m)
     with pytest.raises(Exception):
         eng.score_trials(F, np.array([n_files], np.int32), np.array([0], np.int32), "cosine")      # index out of range
+
+
+def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
+    """D = 192 runs the fused AS-norm kernel on SIX bf16 MFMAs per product block (every fp32 value split exactly into three bf16
+    parts; the three smallest of the nine partial products, <= 2^-26 relative, dropped): scores to fp32 rounding.  Against the
+    exact-fp32-MFMA form of the same kernel (SVHIP_ASNORM_F32MFMA=1) and against the float64 oracle, on a cohort with ties and a
+    ragged last block; same bars as the fp32 form."""
+    eng = Engine(model="none", max_batch=1)
+    rng = np.random.Generator(np.random.PCG64(606))
+    N, D, K, top = 1333, 192, 5994, 200
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    cohort = rng.standard_normal((K, D)).astype(np.float32)
+    cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
+    cohort[7] = cohort[9]
+    mu6, sd6 = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback == 0
+    monkeypatch.setenv("SVHIP_ASNORM_F32MFMA", "1")
+    mu1, sd1 = eng.asnorm_stats(E, cohort, top)
+    monkeypatch.delenv("SVHIP_ASNORM_F32MFMA")
+    assert eng.asnorm_last_fallback == 0
+    rmu, rsd = o_scoring.asnorm_stats(E, cohort, top)
+    print("x6 vs f64 oracle: mu", float(np.abs(mu6 - rmu).max()), "sd rel", float((np.abs(sd6 - rsd) / rsd).max()),
+          "| fp32 MFMA vs oracle: mu", float(np.abs(mu1 - rmu).max()), "| x6 vs fp32 MFMA: mu", float(np.abs(mu6 - mu1).max()))
+    assert float(np.abs(mu6 - rmu).max()) <= 1e-6 and float(np.abs(mu1 - rmu).max()) <= 1e-6
+    assert float((np.abs(sd6 - rsd) / rsd).max()) <= 1e-4
+    assert float(np.abs(mu6 - mu1).max()) <= 5e-7 and float(np.abs(sd6 - sd1).max()) <= 5e-7
+    eng.close()
