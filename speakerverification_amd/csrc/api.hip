@@ -1067,7 +1067,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
 int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
     int rc = SVHIP_OK;
     h->cat_f32_stale = false;
-    if (h->lanes == 2 && B >= 64) {
+    if (h->lanes == 2 && B >= 64 && !h->x3) {      // (F32X3: the lanes would share the split-operand staging buffer)
         const int B0 = (B / 2 + 3) & ~3;
         SV_HIP(h, hipEventRecord(h->lane_ev[4], h->stream));
         for (int l = 0; l < 2 && !rc; ++l) {
