@@ -18,7 +18,9 @@
 // MFMAs 30 (28 at peak), epilogue 20, weight staging 12, barriers / loop skeleton 24.  All 256 workgroups reach their row
 // passes together, so HBM sees 7 bursts of 60 MB per launch; measured and of no effect on the total: software-pipelined
 // fragment reads, the c_{j+1} prefetch above, y_j stores delayed behind the next stage's weight loads (C = 512: 64 us either
-// way).  What would help is two workgroups per CU out of phase, which the 136 KiB of LDS (C = 1024) rule out.
+// way).  What would help is two workgroups per CU out of phase, which the 136 KiB of LDS (C = 1024) rule out.  Round 3: the odd
+// workgroups started 8 / 16 / 24 k cycles late (s_sleep) so that half of the CUs hit their row passes out of phase with the other
+// half: 0.424 / 0.444 / 0.449 ms per three launches against 0.427 — the bursts are not what the time goes to.
 #include "common.h"
 #include "kernels.h"
 
