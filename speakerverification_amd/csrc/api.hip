@@ -826,6 +826,8 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
         q.A = A_s32 ? A_s32 : h->s32_buf; q.lda = A_s32 ? lda_s32 : L.K; q.W = L.Ws32; q.x3 = 2;
         q.side_a = h->side_a; q.side_b = h->side_b; q.side_lda = h->side_lda; q.side_ldb = h->side_ldb; q.side_c = h->side_c;
         if (!gemm_pw3x3_supported(q)) q.side_a = q.side_b = nullptr, q.side_c = 0;
+        // (utterances shorter than a tile: no column sums from this kernel — the caller then takes the squeeze / statistics kernels)
+        if (!gemm_pw3x3_supported(q) && q.colsum) q.colsum = nullptr;
         h->side_done = q.side_c != 0;
         h->side_c = 0;
         if (gemm_pw3x3_supported(q)) {

@@ -284,3 +284,33 @@ def test_f32x3_fused_attentive_pooling_matches_the_exact_path(T, B):
         err = float(np.abs(got - ref).max())
         print(f"T={T} B={B} {n}: max err {err:.3e} of scale {scale:.2f}")
         assert np.isfinite(got).all() and err <= 1e-4 * max(1.0, scale), (n, err, scale)
+
+
+@pytest.mark.parametrize("C,T,B", [(512, 130, 5), (1024, 257, 3), (1024, 130, 4), (512, 401, 3)])
+def test_f32x3_persistent_forms_on_ragged_geometries(monkeypatch, C, T, B):
+    """every persistent-kernel form of an F32X3 handle (pointwise X3 with side outputs, Res2Net steps, conv-gather blocks.0, outputs
+    kept only in the split layout) on shapes whose row count is not a multiple of the 256-row tile and whose utterances are
+    shorter / longer than a tile (T < 256: no column sums from the GEMM epilogue, the squeeze and the global statistics take
+    their own kernels), against the exact-fp32 handle: embeddings within 1e-4 of the scale, every stage within 1e-4 of its scale."""
+    monkeypatch.setenv("SVHIP_PW3_CUS", "2")
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=31)
+    mel = synth.synth_mel(B, 80, T, seed=32)
+    res = {}
+    for compute in ("f32", "f32x3"):
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80 if T != 401 else 32000)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        out = eng.embed_features(mel)
+        labels = eng.profile_results()
+        stages = {n: stage_cf(eng, n, B, T).astype(np.float64) for n in STAGES}
+        eng.close()
+        res[compute] = (out, stages, labels)
+    lab = res["f32x3"][2]
+    assert "gemm_pw3x3" in lab and "gemm_pw3r2" in lab and "gemm_pw3cv" in lab, lab.keys()
+    out32, outx3 = res["f32"][0], res["f32x3"][0]
+    scale = float(np.abs(out32).max())
+    assert np.isfinite(outx3).all() and float(np.abs(outx3 - out32).max()) <= 1e-4 * max(1.0, scale)
+    for n in STAGES:
+        a, b = res["f32"][1][n], res["f32x3"][1][n]
+        assert float(np.abs(a - b).max()) <= 1e-4 * max(1.0, float(np.abs(a).max())), n

@@ -199,3 +199,25 @@ def test_profile_filter_brackets_only_the_named_kernel():
     eng.embed_wave(wav)
     assert eng.profile_results() == every            # nothing recorded while profiling is off
     eng.close()
+
+
+def test_f32x3_full_batch_of_short_utterances():
+    """B = 256 utterances of 130 frames on an F32X3 handle: every big GEMM takes the persistent kernel WITHOUT a grid cap, but the
+    utterances are shorter than its 256-row tile, so the column sums (SE squeeze, ASP statistics) must come from their own kernels
+    while the operands stay in the split layout.  Finite, deterministic, and rows 0..3 equal the same utterances embedded alone."""
+    C, T, B = 1024, 130, 256
+    eng = Engine(model="ecapa", compute="f32x3", channels=C, max_batch=B, samples=(T - 1) * 80)
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=41))
+    eng.finalize()
+    mel = synth.synth_mel(B, 80, T, seed=42)
+    eng.profile(True)
+    a = eng.embed_features(mel)
+    labels = eng.profile_results()
+    b = eng.embed_features(mel)
+    # (130 M-tiles: fewer than CUs, so the Res2Net steps stay on the conv kernels; the pointwise layers have 520 / 1560 tiles)
+    assert "gemm_pw3x3" in labels and "gemm_pw3cv" in labels and "se_mean" in labels and "asp_gstats" in labels, labels.keys()
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    small = eng.embed_features(mel[:4])
+    scale = float(np.abs(a).max())
+    assert float(np.abs(small - a[:4]).max()) <= 1e-4 * scale
+    eng.close()
