@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
     const int j = lane & 31, h = lane >> 5;
     const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + j;
     const bool valid = row < p.N;
-    const float* __restrict__ erow = p.E + (valid ? row : p.N - 1) * D;
+    // (per-lane addresses are kept as 32-bit offsets from the scalar bases: every VGPR counts here)
+    const uint32_t eoff = (uint32_t)((valid ? row : p.N - 1) * D);                  // < 2^31 elements per launch (host check)
+    const float* __restrict__ erow = p.E + eoff;
 
     // B operand: embedding j, k = 16 s + 8 h .. + 7 for k step s, in three bf16 parts
     bf16x8 bh[NS], bm[NS], bl[NS];
@@ -242,18 +244,24 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        // (no read-ahead of the A fragments: the fp32 kernel measured none / one group / half a block ahead as 26.1 / 26.7 / 27.5 ms —
-        //  the partner wave covers the LDS latency — and here every register counts)
+        // A fragments are read ONE k step ahead of their six MFMAs, fenced (left alone hipcc issues each ds_read right in front of
+        // the wait of the MFMAs that use it, and a wave then sits out the LDS latency every k step whenever its SIMD partner is
+        // not in its own MFMA phase: matrix pipe busy 0.58)
+        bf16x8 ah = rd(buf, 0, 0), am = rd(buf, 1, 0), al = rd(buf, 2, 0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
-            const bf16x8 ah = rd(buf, 0, s_), am = rd(buf, 1, s_), al = rd(buf, 2, s_);
+            bf16x8 nh = ah, nm = am, nl = al;
+            if (s_ + 1 < NS) { nh = rd(buf, 0, s_ + 1); nm = rd(buf, 1, s_ + 1); nl = rd(buf, 2, s_ + 1); }
+            __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);      // small terms first
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[s_], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[s_], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[s_], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nh; am = nm; al = nl;
         }
         __builtin_amdgcn_s_setprio(0);
         return acc;
@@ -261,13 +269,13 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
 
     float second = 0.0f, tau = 0.0f;
     int cnt = 0;
-    float* candl = p.cand + ((valid ? row : 0) * 2 + h) * AF_CAPL;
+    const uint32_t coff = (uint32_t)(((valid ? row : 0) * 2 + h) * AF_CAPL);
     // acc[r] = score of image row 32 b + (r & 3) + 8 (r >> 2) + 4 h against embedding j
     auto process = [&](const f32x16& a, int b) {
         if (b < NP - 1) {               // rows of M: (M e)_i . e_i
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + 32 * b + 8 * g + 4 * h);
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(p.E + eoff + 32 * b + 8 * g + 4 * h);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) second = fmaf(a[4 * g + u], ev[u], second);
             }
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
                 const int i = kb + (r & 3) + 8 * (r >> 2);
                 const float v = a[r];
                 if (i < p.K && v > tau) {
-                    if (cnt < AF_CAPL && valid) candl[cnt] = v;
+                    if (cnt < AF_CAPL && valid) p.cand[coff + cnt] = v;
                     ++cnt;
                 }
             }
@@ -450,7 +458,7 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
     if (!asnorm_fused_supported(D, p.K, 1) || !p.E || !p.cohort || !p.MB || !p.cand || !p.cnt) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(p.E) | reinterpret_cast<uintptr_t>(p.cohort) | reinterpret_cast<uintptr_t>(p.MB)) & 15) return hipErrorInvalidValue;
     if (p.planes) {                                       // the six-bf16-MFMA form
-        if (!asnorm_fused6_supported(D) || (reinterpret_cast<uintptr_t>(p.planes) & 15)) return hipErrorInvalidValue;
+        if (!asnorm_fused6_supported(D) || (reinterpret_cast<uintptr_t>(p.planes) & 15) || p.N > (int64_t)1 << 21) return hipErrorInvalidValue;      // (32-bit lane offsets)
         static DeviceOnce attr6;
         const int lds6 = 2 * 3 * 32 * 192 * 2;
         if (hipError_t e = set_max_dynamic_lds(attr6, reinterpret_cast<const void*>(asnorm_fused6_kernel<192>), lds6)) return e;
