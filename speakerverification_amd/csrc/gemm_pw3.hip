@@ -81,7 +81,9 @@ constexpr int ABL = 0;
 // rows and copied out by all eight waves (1 KiB contiguous per instruction): the same cycle count at a higher clock, 88 us.
 // What bounds it now: every CU reaches its epilogue at the same time, and 384 KB per tile (c in, y and U out) at a CU's share of
 // the HBM bandwidth (~10 B / cycle) IS ~38 k cycles, while HBM idles through the K loops; overlapping the two needs two tiles
-// in flight per CU (a 128 x 128 / four-wave re-cut with two workgroups per CU), not built.
+// in flight per CU (a 128 x 128 / four-wave re-cut with two workgroups per CU), not built.  Letting the two empty wave columns skip
+// their fragment reads and MFMAs (they keep the DMA stream, waits and barriers) changed the step by nothing (88.7 us): the clock rose
+// and the K loop's cycle count with it (44 k -> 52 k) — that loop runs at the pace of its gathered operand stream, not of the matrix pipe.
 template <int EPI, int CS, bool X3, bool R2 = false, bool CV = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
