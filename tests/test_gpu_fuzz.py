@@ -56,3 +56,36 @@ def test_random_geometry(model, C, L, B, sw, sx, monkeypatch):
         assert cosine(outs["sep"], outs["bf16"]).min() >= 0.999 and c32.min() >= 0.9, c32
     else:
         assert c32.min() >= 0.998, c32
+
+
+def _x3_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.choice([256, 512, 1024])), int(rng.integers(40, 520)), int(rng.choice([1, 2, 3, 5, 9])),
+                    int(rng.choice([0, 1, 2, 3, 7])), int(rng.integers(1, 1000)), int(rng.integers(1, 1000))))
+    return out
+
+
+@pytest.mark.parametrize("C,T,B,cus,sw,sx", _x3_cases(12, 303))
+def test_random_geometry_f32x3(C, T, B, cus, sw, sx, monkeypatch):
+    """SVHIP_F32X3 against the exact-fp32 handle on seeded random (channels, frames, batch, persistent-grid cap): the cap decides which
+    layers take the persistent split-operand kernel (pointwise, Res2Net-step, conv-gather forms), whether their outputs exist only
+    in the split layout, and whether the column sums come from the GEMM epilogue — every combination must stay within the 1e-4 bar."""
+    if cus:
+        monkeypatch.setenv("SVHIP_PW3_CUS", str(cus))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=sw)
+    mel = synth.synth_mel(B, 80, T, seed=sx)
+    outs = {}
+    for compute in ("f32", "f32x3"):
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        outs[compute] = eng.embed_features(mel)
+        if compute == "f32x3":
+            again = eng.embed_features(mel)
+            assert np.array_equal(outs[compute], again)
+        eng.close()
+    scale = float(np.abs(outs["f32"]).max())
+    err = float(np.abs(outs["f32x3"] - outs["f32"]).max())
+    assert np.isfinite(outs["f32x3"]).all() and err <= 1e-4 * max(1.0, scale), (err, scale)
