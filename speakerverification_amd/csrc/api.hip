@@ -1037,12 +1037,19 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
          }))) return rc;
     if ((rc = conv_gemm(h, "gemm_asp_tdnn", h->asp_tdnn, MFA, C3, ATT, 128, M, ACT_RELU, ACT_TANH, nullptr, 0, d_ctx, 128)))
         return rc;
-    if (bf && asp_fused_supported(T, C3, h->asp_tdnn.N, h->asp_conv.Kp)) {
+    // bf16: 16 waves per CU, lane-local online softmax (asp_x3.hip's bf16 form: 0.195 against 0.264 ms at B = 256, any T); the
+    // one-wave-per-SIMD kernel keeps the channel counts that are not multiples of 256 (and SVHIP_ASP_V1=1: the tests compare the two)
+    const char* asp_v1 = getenv("SVHIP_ASP_V1");
+    const bool asp_v2 = bf && C3 % 256 == 0 && h->asp_tdnn.N == 128 && h->asp_conv.Kp == 128 && !(asp_v1 && asp_v1[0] == '1');
+    if (asp_v2 || (bf && asp_fused_supported(T, C3, h->asp_tdnn.N, h->asp_conv.Kp))) {
         AspFusedParams ap;
         ap.att = ATT; ap.W = h->asp_conv.W; ap.Kp = h->asp_conv.Kp; ap.bias = h->asp_conv.bias;
         ap.X = MFA; ap.ldx = C3; ap.T = T; ap.C = C3;
         ap.bn_scale = h->aspbn_scale; ap.bn_shift = h->aspbn_shift;
         ap.pooled_raw = d_pool_raw; ap.pooled_bn = d_pool_bn; ap.eps = 1e-12f;
+        if (asp_v2) {
+            if ((rc = run(h, "asp_bf16", (double)M * h->asp_conv.flops_per_row, [&]() { return launch_asp_bf16(ap, d_gstats, 2 * C3, B, st); }))) return rc;
+        } else
         if ((rc = run(h, "asp_fused", (double)M * h->asp_conv.flops_per_row, [&]() { return launch_asp_fused(ap, B, st); }))) return rc;
     } else if (h->x3 && h->asp_conv.Ws32 && asp_x3_supported(T, C3, h->asp_tdnn.N, h->asp_conv.K)) {
         AspX3Params ap;

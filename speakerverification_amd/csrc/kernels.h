@@ -252,6 +252,7 @@ struct AspX3Params {
     int ldx = 0, mref_ld = 0, T = 0, C = 0, B = 0;
     float eps = 1e-12f;
 };
+hipError_t launch_asp_bf16(const AspFusedParams& p, const float* mref, int mref_ld, int B, hipStream_t stream);      // asp_x3.hip: the bf16 form of asp_x3
 bool asp_x3_supported(int T, int C, int att_channels, int K);
 hipError_t launch_asp_x3(const AspX3Params& p, int B, hipStream_t stream);
 

@@ -314,3 +314,39 @@ def test_f32x3_persistent_forms_on_ragged_geometries(monkeypatch, C, T, B):
     for n in STAGES:
         a, b = res["f32"][1][n], res["f32x3"][1][n]
         assert float(np.abs(a - b).max()) <= 1e-4 * max(1.0, float(np.abs(a).max())), n
+
+
+@pytest.mark.parametrize("T,B", [(401, 3), (130, 9), (64, 8), (33, 2), (500, 2)])
+def test_bf16_attentive_pooling_kernels_agree(monkeypatch, T, B):
+    """bf16 handles pool with asp_bf16_kernel (16 waves per CU, lane-local online softmax, moments shifted by the plain channel
+    mean) unless SVHIP_ASP_V1=1 selects asp_fused_kernel (one wave per SIMD, the whole logit column in registers): same inputs,
+    stages `asp` / `asp_bn` within 2e-3 of their scale (both see bf16 logits; the moments are fp32 in both), and both against the
+    exact-fp32 handle within the bf16 path's bar.  T = 500 is past asp_fused's 416-frame limit: the new kernel has none."""
+    C = 256
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=51)
+    mel = synth.synth_mel(B, 80, T, seed=52)
+    st = {}
+    for name, compute, v1 in (("f32", "f32", False), ("v2", "bf16", False), ("v1", "bf16", True)):
+        if v1:
+            monkeypatch.setenv("SVHIP_ASP_V1", "1")
+        else:
+            monkeypatch.delenv("SVHIP_ASP_V1", raising=False)
+        eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80 if T != 401 else 32000)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        eng.embed_features(mel)
+        labels = eng.profile_results()
+        if name == "v2":
+            assert "asp_bf16" in labels, labels.keys()
+        if name == "v1" and T <= 416:
+            assert "asp_fused" in labels, labels.keys()
+        st[name] = {n: eng.get_stage(n).astype(np.float64) for n in ("asp", "asp_bn")}
+        eng.close()
+    for n in ("asp", "asp_bn"):
+        scale = float(np.abs(st["f32"][n]).max())
+        e21 = float(np.abs(st["v2"][n] - st["v1"][n]).max()) / scale
+        e2 = float(np.abs(st["v2"][n] - st["f32"][n]).max()) / scale
+        e1 = float(np.abs(st["v1"][n] - st["f32"][n]).max()) / scale
+        print(f"T={T} B={B} {n}: v2 vs v1 {e21:.2e}, v2 vs f32 {e2:.2e}, v1 vs f32 {e1:.2e}")
+        assert np.isfinite(st["v2"][n]).all() and e21 <= 2e-3 and e2 <= max(3e-2, 1.5 * e1)
