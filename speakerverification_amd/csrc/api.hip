@@ -300,8 +300,9 @@ int build_fbank_tables(svhip_handle* h) {
     // bf16x3 tables: the same windowed taps split into bf16 hi + lo, k-steps of 16 (zero padded)
     fb.n_k16 = (c.win_length + 15) / 16;
     fb.split_bf16 = (h->bf16 && c.hop_length % 8 == 0) ? 1 : 0;
-    if (fb.split_bf16) {
-        std::vector<uint16_t> bhi((size_t)fb.n_k16 * fb.n_pairs * 2 * 64 * 8, 0), blo(bhi.size(), 0);
+    fb.split6 = (h->x3 && c.hop_length % 8 == 0) ? 1 : 0;          // F32X3 handles: the exact three-way split, six products
+    if (fb.split_bf16 || fb.split6) {
+        std::vector<uint16_t> bhi((size_t)fb.n_k16 * fb.n_pairs * 2 * 64 * 8, 0), blo(bhi.size(), 0), bl3(bhi.size(), 0);
         for (int kk = 0; kk < fb.n_k16; ++kk)
             for (int pr = 0; pr < fb.n_pairs; ++pr)
                 for (int part = 0; part < 2; ++part)
@@ -320,12 +321,20 @@ int build_fbank_tables(svhip_handle* h) {
                             const size_t idx = ((((size_t)kk * fb.n_pairs + pr) * 2 + part) * 64 + lane) * 8 + j;
                             bhi[idx] = hi;
                             blo[idx] = f32_to_bf16_rne(v - hf);
+                            uint32_t mu = (uint32_t)blo[idx] << 16;
+                            float mf; memcpy(&mf, &mu, 4);
+                            bl3[idx] = f32_to_bf16_rne((v - hf) - mf);
                         }
         uint16_t *dh, *dl;
         int rc2;
         if ((rc2 = dev_upload(h, &dh, bhi))) return rc2;
         if ((rc2 = dev_upload(h, &dl, blo))) return rc2;
         fb.basis_hi = dh; fb.basis_lo = dl;
+        if (fb.split6) {
+            uint16_t* d3;
+            if ((rc2 = dev_upload(h, &d3, bl3))) return rc2;
+            fb.basis_l3 = d3;
+        }
     }
     // Slaney mel bank (librosa 0.7 filters.mel(htk=False, norm=1)) in double, stored float32, sparse rows
     const double sr = c.fb_sr;

@@ -186,16 +186,21 @@ constexpr int F2_FRAMES = 64;
 constexpr int F2_THREADS = 512;
 constexpr int F2_PT_STRIDE = 257;
 
-template <bool SPLIT>
+// MODE 0: exact fp32 MFMA; 1: bf16x3 (two-way split, three products); 2: bf16x6 — the EXACT three-way split v = h + m + l of samples
+// and basis and the six partial products above 2^-26 (h h, h m, m h, h l, l h, m m): fp32-grade spectra at 6 x 32 = 192 matrix
+// cycles per 16 taps against 8 x 64 = 512 for the fp32 MFMA (F32X3 handles; see asnorm_fused.hip for the same arithmetic)
+template <int MODE>
 __global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, const float* __restrict__ wav, int L, int T,
                                                                 float* __restrict__ mel) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ns = (F2_FRAMES - 1) * tb.hop + tb.win_length;
     const int ns_pad = ((ns + 15) & ~15) + 16;
-    bf16_t* yh = reinterpret_cast<bf16_t*>(smem);                  // SPLIT: [ns_pad] hi | [ns_pad] lo; else [ns_pad] fp32
+    constexpr bool SPLIT = MODE == 1, X6 = MODE == 2;
+    bf16_t* yh = reinterpret_cast<bf16_t*>(smem);                  // SPLIT: [ns_pad] hi | [ns_pad] lo; X6: h | m | l; else [ns_pad] fp32
     bf16_t* yl = yh + ns_pad;
+    bf16_t* y3 = yl + ns_pad;
     float* ys = reinterpret_cast<float*>(smem);
-    float* pt = ys + ns_pad;                                       // [32][257]
+    float* pt = X6 ? reinterpret_cast<float*>(y3 + ns_pad) : ys + ns_pad;      // [32][257]
     float* melw = pt + 32 * F2_PT_STRIDE;
 
     const int b = blockIdx.y;
@@ -229,10 +234,13 @@ __global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, 
             if (i < ns_pad) {
                 float w = v[u];
                 if (coef >= 0.0f) w = __fadd_rn(__fmul_rn(-coef, prev[u]), w);
-                if (SPLIT) {
+                if (SPLIT || X6) {
                     const bf16_t hi = static_cast<bf16_t>(w);
+                    const float r1 = w - static_cast<float>(hi);
+                    const bf16_t mi = static_cast<bf16_t>(r1);
                     yh[i] = hi;
-                    yl[i] = static_cast<bf16_t>(w - static_cast<float>(hi));
+                    yl[i] = mi;
+                    if (X6) y3[i] = static_cast<bf16_t>(r1 - static_cast<float>(mi));
                 } else {
                     ys[i] = w;
                 }
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, 
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
-    if (!SPLIT) {                                                  // exact fp32 MFMA, same tap order as the 32-frame kernel
+    if (MODE == 0) {                                               // exact fp32 MFMA, same tap order as the 32-frame kernel
         const int qstride = tb.n_pairs * 2 * 64;
         const f32x4* __restrict__ bs = reinterpret_cast<const f32x4*>(tb.basis) + wave * 2 * 64 + lane;
         const float* a0 = ys + r * tb.hop + 4 * h;
@@ -272,6 +280,36 @@ __global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, 
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], c0[j], acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], c1[j], acc[1][1], 0, 0, 0);
                 }
+            }
+        }
+    } else if (X6) {
+        const int kstride = tb.n_pairs * 2 * 64;
+        const bf16x8* __restrict__ bh = reinterpret_cast<const bf16x8*>(tb.basis_hi) + wave * 2 * 64 + lane;
+        const bf16x8* __restrict__ bm = reinterpret_cast<const bf16x8*>(tb.basis_lo) + wave * 2 * 64 + lane;      // (the two-way "lo" IS m)
+        const bf16x8* __restrict__ bl = reinterpret_cast<const bf16x8*>(tb.basis_l3) + wave * 2 * 64 + lane;
+        const bf16_t* a0 = yh + r * tb.hop + 8 * h;
+        for (int kk = 0; kk < tb.n_k16; ++kk) {
+            const int kn = kk * kstride;
+            const bf16x8 ch0 = bh[kn], ch1 = bh[kn + 64], cm0 = bm[kn], cm1 = bm[kn + 64], cl0 = bl[kn], cl1 = bl[kn + 64];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                if (mt == 1 && !two) break;
+                const bf16_t* ap = a0 + mt * 32 * tb.hop + 16 * kk;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + ns_pad);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * ns_pad);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch0, acc[mt][0], 0, 0, 0);      // small terms first
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cm0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, cm1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ch0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, ch1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cm0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cm1, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch1, acc[mt][1], 0, 0, 0);
             }
         }
     } else {
@@ -412,13 +450,18 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
     const char* small_tiles = getenv("SVHIP_FBANK32");                                   // developer switch: the 32-frame kernel
     const int ns2 = (F2_FRAMES - 1) * tb.hop + tb.win_length;
     const int ns2_pad = ((ns2 + 15) & ~15) + 16;
-    const size_t lds2 = (size_t)(ns2_pad + 32 * F2_PT_STRIDE + tb.n_melw) * sizeof(float);
-    if (tb.mel_max_bin < 256 && tb.n_pairs >= 8 && lds2 <= 64 * 1024 && !(small_tiles && small_tiles[0] == '1')) {
+    const bool x6 = tb.split6 && tb.basis_hi && tb.basis_lo && tb.basis_l3 && tb.hop % 8 == 0;
+    const size_t lds2 = (size_t)(32 * F2_PT_STRIDE + tb.n_melw) * sizeof(float) + (size_t)ns2_pad * (x6 ? 6 : 4);
+    if (tb.mel_max_bin < 256 && tb.n_pairs >= 8 && lds2 <= 80 * 1024 && !(small_tiles && small_tiles[0] == '1')) {
         dim3 grid2((T + F2_FRAMES - 1) / F2_FRAMES, B);
-        if (tb.split_bf16)
-            hipLaunchKernelGGL(fbank64_kernel<true>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
+        if (x6) {
+            static DeviceOnce attr6;
+            if (hipError_t e = set_max_dynamic_lds(attr6, reinterpret_cast<const void*>(fbank64_kernel<2>), 80 * 1024)) return e;
+            hipLaunchKernelGGL(fbank64_kernel<2>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
+        } else if (tb.split_bf16)
+            hipLaunchKernelGGL(fbank64_kernel<1>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
         else
-            hipLaunchKernelGGL(fbank64_kernel<false>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
+            hipLaunchKernelGGL(fbank64_kernel<0>, grid2, dim3(F2_THREADS), lds2, stream, tb, wav, L, T, mel);
         return hipGetLastError();
     }
     if (tb.split_bf16)

@@ -164,6 +164,8 @@ struct FbankTables {           // device pointers, built once per handle
     const float* basis = nullptr;      // [q][tile][lane] float4: windowed cos/sin taps laid out for MFMA B operands
     const void* basis_hi = nullptr;    // bf16x3 path: [k16][pair][part][lane] 8 x bf16 (hi / lo parts of the same taps)
     const void* basis_lo = nullptr;
+    const void* basis_l3 = nullptr;    // bf16x6 path (F32X3 handles): the third part of the exact split basis = hi + lo + l3
+    int split6 = 0;
     int n_k16 = 13;                    // ceil(win_length / 16)
     int split_bf16 = 0;                // 1: bf16x3 DFT (bf16-compute handles)
     const float* mel_w = nullptr;      // packed non-zero mel weights

@@ -99,3 +99,26 @@ def test_fbank_64_frame_kernel_equals_the_32_frame_kernel(monkeypatch, compute, 
     else:
         np.testing.assert_allclose(new, old, rtol=2e-6, atol=1e-12)
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["white", "speechlike"])
+def test_fbank_six_product_form_on_f32x3_handles(kind):
+    """F32X3 handles run the DFT on six bf16 MFMAs per product block (samples and basis split EXACTLY into three bf16 parts, the
+    three partial products below 2^-26 dropped): fp32-grade — held to the SAME bars as the exact-fp32 MFMA form (mel power within
+    2e-6 of the utterance peak, log-mel within 1e-4 of the float64 oracle), and within 2e-6 of the peak of that form's own output."""
+    wav = synth.synth_waveforms(4) if kind == "white" else synth.synth_speechlike(4)
+    outs = {}
+    for compute in ("f32", "f32x3"):
+        eng = Engine(model="none", compute=compute, max_batch=4)
+        outs[compute] = eng.fbank(wav)
+        eng.close()
+    ref64 = o_fbank.melspectrogram(torch.from_numpy(wav).double()).numpy()
+    peak = np.abs(ref64).max(axis=(1, 2), keepdims=True)
+    e6 = float((np.abs(outs["f32x3"] - ref64) / peak).max())
+    e1 = float((np.abs(outs["f32"] - ref64) / peak).max())
+    lg = o_fbank.log_mean_norm(torch.from_numpy(outs["f32x3"]).double()).numpy()
+    lr = o_fbank.log_mean_norm(torch.from_numpy(ref64)).numpy()
+    e_log = float(np.abs(lg - lr).max())
+    print(kind, "x6 rel-to-peak", e6, "fp32 MFMA rel-to-peak", e1, "x6 log-mel err", e_log, "x6 vs fp32 form", float((np.abs(outs["f32x3"] - outs["f32"]) / peak).max()))
+    assert e6 <= 2e-6 and e_log <= 1e-4
+    assert float((np.abs(outs["f32x3"] - outs["f32"]) / peak).max()) <= 2e-6
