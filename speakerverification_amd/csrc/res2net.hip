@@ -20,7 +20,8 @@
 // fragment reads, the c_{j+1} prefetch above, y_j stores delayed behind the next stage's weight loads (C = 512: 64 us either
 // way).  What would help is two workgroups per CU out of phase, which the 136 KiB of LDS (C = 1024) rule out.  Round 3: the odd
 // workgroups started 8 / 16 / 24 k cycles late (s_sleep) so that half of the CUs hit their row passes out of phase with the other
-// half: 0.424 / 0.444 / 0.449 ms per three launches against 0.427 — the bursts are not what the time goes to.
+// half: 0.424 / 0.444 / 0.449 ms per three launches against 0.427 — the bursts are not what the time goes to; the same chain on 16 waves
+// per workgroup (4 m-tiles per wave, 128 VGPRs): 0.46 ms — each weight fragment then feeds 4 MFMAs instead of 7 and the kernel spills.
 #include "common.h"
 #include "kernels.h"
 
