@@ -966,7 +966,12 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
             if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
             return q;
         };
-        const bool r2_plan = h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && gemm_pw3r2_supported(step_params(1));
+        // (C / 8 = 128: the dedicated 128 x 128 kernel, two workgroups per CU, any batch size; C / 8 = 64, or SVHIP_R2_BIG=1: the R2 form
+        //  of the persistent 256 x 256 kernel)
+        const char* r2big = getenv("SVHIP_R2_BIG");
+        const bool r2_small = h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && !(r2big && r2big[0] == '1') && r2_step_supported(step_params(1)) &&
+                              x3_route(h->tdnn2[i], h2s, C, false);      // (tdnn2 must be able to read the chain output in the split layout)
+        const bool r2_plan = r2_small || (h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && gemm_pw3r2_supported(step_params(1)));
         if (r2_plan) {      // tdnn1 writes the pass-through chunk and the first step's input in the split layout itself (when it takes the X3 kernel)
             h->side_a = h2s; h->side_lda = C; h->side_b = us[0]; h->side_ldb = C8; h->side_c = C8;
         }
@@ -982,7 +987,9 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
                 }
                 for (int j = 1; j < 8; ++j) {
                     const GemmParams q = step_params(j);
-                    if ((rc = run(h, "gemm_pw3r2", (double)M * h->res2[i][j - 1].flops_per_row, [&]() { return launch_gemm_pw3r2(q, st); }))) return rc;
+                    if (r2_small) {
+                        if ((rc = run(h, "r2_step", (double)M * h->res2[i][j - 1].flops_per_row, [&]() { return launch_r2_step(q, st); }))) return rc;
+                    } else if ((rc = run(h, "gemm_pw3r2", (double)M * h->res2[i][j - 1].flops_per_row, [&]() { return launch_gemm_pw3r2(q, st); }))) return rc;
                 }
                 h2_32 = h2s;
                 r2_done = true;

@@ -128,6 +128,8 @@ int pw3_grid_cap(int num_cu);
 // 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream);
+bool r2_step_supported(const GemmParams& p);               // r2_step.hip: the Res2Net step on 128 x 128 tiles, two workgroups per CU (cin = 128)
+hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3cv_supported(const GemmParams& p);          // conv-gather X3 form (odd taps, reflect): see gemm_pw3.hip
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream);
 // one Res2Net step of an F32X3 handle on the same kernel (dilated k = 3 conv gathered from an S32 input, outputs in S32)

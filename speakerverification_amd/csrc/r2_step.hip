@@ -1,0 +1,217 @@
+// r2_step.hip — one step of a Res2Net chain on SVHIP_F32X3 handles, 128 x 128 tiles, two workgroups per CU (gfx950).
+//
+// Same contract as gemm_pw3's R2 form (models/ECAPA_TDNN.py:118-129): y_j = BN(ReLU(conv_k3_dilated(U_j))) with U_j = c_j + y_{j-1}
+// in the S32 split layout (per row, per 32 channels: 32 hi bf16 | 32 lo bf16), products as bf16 MFMA triples (hi.hi + hi.lo + lo.hi);
+// y_j goes to the chain output in S32, U_{j+1} = y_j + c_{j+1} (c from the fp32 tdnn1 output) to the next step's input.
+//
+// Why a second kernel.  The R2 form borrows gemm_pw3's 256 x 256 tile with N = 128 channels: two of its four wave columns hold no
+// channels, so only two of a CU's four SIMDs do useful matrix work, and its epilogue needs the whole 128 KiB operand ring for the
+// c tile, so K loop (matrix-bound) and epilogue (HBM-bound: c in, y and U out, 384 KB per tile) alternate on every CU at once
+// (88 us per step; gemm_pw3.hip's header).  Here a workgroup is four waves on a 128-frame x 128-channel tile — every SIMD holds a
+// useful wave — with 64 KiB of LDS (two K-tile buffers of X and W, 16 KiB each; the same 64 KiB then stage the c / U / y images),
+// so TWO workgroups share a CU and one's epilogue runs under the other's K loop.
+#include "common.h"
+#include "kernels.h"
+#include "gemm_epi.h"
+
+namespace svhip {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+constexpr int RS_TILE = 128;                       // frames per tile = channels per tile
+constexpr int RS_HT = RS_TILE * 128;               // one operand half-buffer: 128 rows x one 32-k block (128 bytes)
+constexpr int RS_LDS = 4 * RS_HT;                  // {X, W} x two K tiles = 64 KiB = one 128-row image of 512-byte rows
+
+__global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;        // rows wm * 64 .. + 63, channels wn * 64 .. + 63
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int m0 = blockIdx.x * RS_TILE;
+
+    // ---- operand DMA addressing: thread -> four (row, 16-byte slot) items of a 128 x 128-byte half-buffer; the swizzle
+    //      (slot ^ (row >> 1 & 7)) goes on the source chunk ----
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    int xm[4], xt[4];
+    uint32_t xc[4], wo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pidx = q * 256 + tid;
+        const int row = pidx >> 3, slot = pidx & 7;
+        const int c = slot ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, p.M - 1);
+        xm[q] = m;
+        xt[q] = m % p.T;
+        xc[q] = (uint32_t)c * 16u;
+        wo[q] = (uint32_t)row * (uint32_t)p.Kp * 4u + (uint32_t)c * 16u;          // weight row = output channel `row` (N = 128 rows)
+    }
+    auto issue = [&](int kt, int buf) {
+        const int tap = kt >> 2, kin = kt & 3;                                      // four 32-k blocks per tap (cin = 128)
+        const int shift = (tap - 1) * p.dil;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tt = reflect_idx(xt[q] + shift, p.T);
+            const char* s = Ab + ((int64_t)(xm[q] + tt - xt[q]) * p.lda * 4 + kin * 128 + xc[q]);
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + (buf * 2) * RS_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* s = Wb + wo[q] + kt * 128;
+            __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + (buf * 2 + 1) * RS_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // acc[i][j][e]: frame m0 + wm*64 + i*16 + r16, channel wn*64 + j*16 + 4*q4 + e; starts at the bias
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + j * 16 + 4 * q4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = b4;
+    }
+    issue(0, 0);
+    const int nkt = p.Kp >> 5;                      // 12
+    const int xrow = (wm * 64 + r16) * 128, wrow = (wn * 64 + r16) * 128;
+    const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 64 + r16) >> 1) & 7;      // (+ 16 i keeps (row >> 1) & 7)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                              // K tile kt has landed for every wave; nobody still reads the other buffer
+        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+        const char* xb = smem + (buf * 2) * RS_HT + xrow;
+        const char* wb = smem + (buf * 2 + 1) * RS_HT + wrow;
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wh[j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + ((q4 ^ wkey) << 4));
+            wl[j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + (((4 + q4) ^ wkey) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + i * 2048 + ((q4 ^ xkey) << 4));
+            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + i * 2048 + (((4 + q4) ^ xkey) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl, acc[i][j], 0, 0, 0);      // small terms first
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh, acc[i][j], 0, 0, 0);
+        }
+    }
+    lds_barrier();                                  // every wave is past its last fragment read: the 64 KiB become the row image
+
+    // ---- epilogue: y = BN(ReLU(acc)); the image (128 rows x 512 bytes, 16-byte chunk k of a 128-byte block at k ^ (row & 7)) holds
+    //      first c (fp32), turned in place into U = y + c in S32 (a block is read and written by the four q4 lanes of ONE wave, whose
+    //      LDS operations execute in order), then y; each leaves through all four waves as whole rows ----
+    const float* Cn = reinterpret_cast<const float*>(p.R);
+    char* Ub = reinterpret_cast<char*>(p.Y2);
+    auto copy_out = [&](char* dst, int64_t ld_bytes) {
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int pidx = q * 256 + tid;
+            const int row = pidx >> 5, ch = pidx & 31;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * 512 + (ch & ~7) * 16 + (((ch & 7) ^ (row & 7)) << 4));
+            if (m0 + row < p.M) *reinterpret_cast<u32x4*>(dst + (int64_t)(m0 + row) * ld_bytes + ch * 16) = v;
+        }
+    };
+    auto put_s32 = [&](const f32x4& v, int ml, int nl) {
+        typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
+        uint32_t hd[2], ld[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
+            hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
+            ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
+        }
+        const int kh = (nl & 31) >> 3;
+        char* blk = smem + ml * 512 + (nl >> 5) * 128 + (nl & 4) * 2;
+        *reinterpret_cast<uint2*>(blk + ((kh ^ (ml & 7)) << 4)) = make_uint2(hd[0], hd[1]);
+        *reinterpret_cast<uint2*>(blk + (((kh + 4) ^ (ml & 7)) << 4)) = make_uint2(ld[0], ld[1]);
+    };
+    if (Cn) {
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int pidx = q * 256 + tid;          // 16-byte chunk position of the 128 x 32-chunk image
+            const int row = pidx >> 5, pos = pidx & 31;
+            const int cs = (pos & ~7) | ((pos ^ row) & 7);
+            const int m = min(m0 + row, p.M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        f32x4 sc[2], sh[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int nl = wn * 64 + (2 * jp + jj) * 16 + 4 * q4;
+            sc[jj] = *reinterpret_cast<const f32x4*>(p.scale + nl);
+            sh[jj] = *reinterpret_cast<const f32x4*>(p.shift + nl);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + r16;
+            f32x4 cn[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                const int nl = wn * 64 + j * 16 + 4 * q4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaf(fmaxf(acc[i][j][e], 0.0f), sc[jj][e], sh[jj][e]);
+                if (Cn) cn[jj] = *reinterpret_cast<const f32x4*>(smem + ml * 512 + (nl >> 5) * 128 + ((((nl & 31) >> 2) ^ (ml & 7)) << 4));
+            }
+            if (Cn) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) put_s32(acc[i][2 * jp + jj] + cn[jj], ml, wn * 64 + (2 * jp + jj) * 16 + 4 * q4);
+            }
+        }
+    }
+    if (Cn) {
+        lds_barrier();                              // the U image is complete
+        copy_out(Ub, (int64_t)p.lda2 * 4);
+        lds_barrier();                              // ... and has been read
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) put_s32(acc[i][j], wm * 64 + i * 16 + r16, wn * 64 + j * 16 + 4 * q4);
+    lds_barrier();
+    copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
+}
+
+}  // namespace
+
+// cin = N = 128, K = Kp = 384, reflect padding, ReLU -> BN; the same GemmParams as gemm_pw3's R2 form
+bool r2_step_supported(const GemmParams& p) {
+    if (p.x3 != 2 || p.taps != 3 || p.A2 || p.A3 || p.bias_utt || p.colsum || p.out_f32) return false;
+    if (p.cin != 128 || p.N != 128 || p.K != 384 || p.Kp != 384 || p.Wrows < 128) return false;
+    if (p.act1 != ACT_RELU || p.act2 != ACT_NONE || p.pad_mode != PAD_REFLECT) return false;
+    if (!p.bias || !p.scale || !p.shift || !p.Y || !p.A || !p.W) return false;
+    if ((p.R == nullptr) != (p.Y2 == nullptr)) return false;
+    if (p.lda < 128 || p.lda % 32 != 0 || p.ldy % 32 != 0 || (p.Y2 && (p.lda2 % 32 != 0 || p.ldr % 4 != 0))) return false;
+    if (p.T <= 2 * p.dil || p.dil < 1 || p.dil > 8 || p.M <= 0 || p.M % p.T != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.Y2) |
+         reinterpret_cast<uintptr_t>(p.R) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
+    return true;
+}
+
+hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream) {
+    if (!r2_step_supported(p)) return hipErrorInvalidValue;
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(r2_step_kernel), RS_LDS)) return e;
+    hipLaunchKernelGGL(r2_step_kernel, dim3((p.M + RS_TILE - 1) / RS_TILE), dim3(256), RS_LDS, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace svhip

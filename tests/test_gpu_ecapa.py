@@ -225,7 +225,7 @@ def test_f32x3_persistent_gemm_matches_reference(golden_dir, C, cus, monkeypatch
             labels = eng.profile_results()
             eng.close()
             assert ("gemm_pw3x3" in labels) == (compute == "f32x3"), labels
-            assert "gemm_pw3r2" not in labels            # C / 8 = 32: the Res2Net step form is built for 64 and 128 channels
+            assert "gemm_pw3r2" not in labels and "r2_step" not in labels      # C / 8 = 32: the Res2Net step kernels are built for 64 and 128 channels
         scale = float(np.abs(outs["f32"]).max())
         assert float(np.abs(outs["f32"] - outs["f32x3"]).max()) <= 1e-4 * scale
         return
@@ -239,7 +239,8 @@ def test_f32x3_persistent_gemm_matches_reference(golden_dir, C, cus, monkeypatch
     eng.profile(False)
     # (one conversion pass: the zero-padded features; blocks.0 — the conv-gather form of the same kernel —, tdnn1 for its first
     #  two chunks, se_apply and the Res2Net steps write their outputs pre-split)
-    assert prof["gemm_pw3x3"]["launches"] == 7 and prof["gemm_pw3r2"]["launches"] == 21 and prof["split_s32"]["launches"] == 1, prof.keys()
+    r2 = "r2_step" if C == 1024 else "gemm_pw3r2"      # C / 8 = 128: the dedicated 128 x 128 kernel; 64: the R2 form of the persistent one
+    assert prof["gemm_pw3x3"]["launches"] == 7 and prof[r2]["launches"] == 21 and prof["split_s32"]["launches"] == 1, prof.keys()
     assert prof["gemm_pw3cv"]["launches"] == 1 and "gemm_conv" not in prof, prof.keys()
     assert "gemm_conv_add" not in prof
     assert "se_mean" not in prof and "asp_gstats" not in prof          # the squeeze / global statistics come from the GEMM epilogue
@@ -307,7 +308,7 @@ def test_f32x3_persistent_forms_on_ragged_geometries(monkeypatch, C, T, B):
         eng.close()
         res[compute] = (out, stages, labels)
     lab = res["f32x3"][2]
-    assert "gemm_pw3x3" in lab and "gemm_pw3r2" in lab and "gemm_pw3cv" in lab, lab.keys()
+    assert "gemm_pw3x3" in lab and ("r2_step" if C == 1024 else "gemm_pw3r2") in lab and "gemm_pw3cv" in lab, lab.keys()
     out32, outx3 = res["f32"][0], res["f32x3"][0]
     scale = float(np.abs(out32).max())
     assert np.isfinite(outx3).all() and float(np.abs(outx3 - out32).max()) <= 1e-4 * max(1.0, scale)
@@ -350,3 +351,39 @@ def test_bf16_attentive_pooling_kernels_agree(monkeypatch, T, B):
         e1 = float(np.abs(st["v1"][n] - st["f32"][n]).max()) / scale
         print(f"T={T} B={B} {n}: v2 vs v1 {e21:.2e}, v2 vs f32 {e2:.2e}, v1 vs f32 {e1:.2e}")
         assert np.isfinite(st["v2"][n]).all() and e21 <= 2e-3 and e2 <= max(3e-2, 1.5 * e1)
+
+
+@pytest.mark.parametrize("T,B,cus", [(401, 3, 2), (130, 5, 1), (257, 2, 2)])
+def test_f32x3_res2net_step_kernels_agree(monkeypatch, T, B, cus):
+    """C / 8 = 128: the Res2Net steps of an F32X3 handle run on r2_step_kernel (128 x 128 tiles, two workgroups per CU) unless
+    SVHIP_R2_BIG=1 selects the R2 form of the persistent 256 x 256 kernel: same operands, same arithmetic (hi.hi + hi.lo + lo.hi in
+    the same order per 32-k block) — the two kernels add the three partial products of a 32-k block in different orders, and a last-bit difference of a chain
+    value can move its `lo` half by one step of the split layout (2^-17 relative): the block outputs agree to the
+    quantisation of the layout itself (measured 0.7 - 4.2e-5 of the scale, growing block by block; bar 1e-4; embeddings 3e-5),
+    not to fp32 rounding.  A wrong row or tap shows up three orders above that."""
+    C = 1024
+    monkeypatch.setenv("SVHIP_PW3_CUS", str(cus))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=61)
+    mel = synth.synth_mel(B, 80, T, seed=62)
+    st = {}
+    for name, big in (("small", False), ("big", True)):
+        if big:
+            monkeypatch.setenv("SVHIP_R2_BIG", "1")
+        else:
+            monkeypatch.delenv("SVHIP_R2_BIG", raising=False)
+        eng = Engine(model="ecapa", compute="f32x3", channels=C, max_batch=B, samples=(T - 1) * 80 if T != 401 else 32000)
+        eng.load_state_dict(sd)
+        eng.finalize()
+        eng.profile(True)
+        out = eng.embed_features(mel)
+        labels = eng.profile_results()
+        assert ("r2_step" in labels) == (not big) and ("gemm_pw3r2" in labels) == big, labels.keys()
+        st[name] = (out, {n: eng.get_stage(n).astype(np.float64) for n in ("blocks.1", "blocks.2", "blocks.3")})
+        eng.close()
+    errs = {}
+    for n in ("blocks.1", "blocks.2", "blocks.3"):
+        a, b = st["small"][1][n], st["big"][1][n]
+        errs[n] = float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+    errs["emb"] = float(np.abs(st["small"][0] - st["big"][0]).max()) / max(1.0, float(np.abs(st["big"][0]).max()))
+    print(f"T={T} B={B} r2_step vs gemm_pw3r2:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["emb"] <= 3e-5 and max(errs.values()) <= 1e-4, errs
