@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SVHIP_ABI_VERSION 2
+#define SVHIP_ABI_VERSION 3
 
 typedef struct svhip_handle svhip_handle;
 
@@ -43,7 +43,7 @@ typedef enum svhip_status {
 } svhip_status;
 
 enum { SVHIP_MODEL_ECAPA = 0, SVHIP_MODEL_RAWNET2 = 1, SVHIP_MODEL_NONE = 2 /* fbank + scoring only */ };
-enum { SVHIP_F32 = 0, SVHIP_BF16 = 1, SVHIP_I64 = 2, SVHIP_F32X3 = 3 /* compute only */ };
+enum { SVHIP_F32 = 0, SVHIP_BF16 = 1, SVHIP_I64 = 2, SVHIP_F32X3 = 3 /* compute only */, SVHIP_F16 = 4 /* compute only */ };
 enum { SVHIP_IN_DEVICE = 1, SVHIP_OUT_DEVICE = 2, SVHIP_ASYNC = 4 };
 
 typedef struct svhip_config {
@@ -51,7 +51,10 @@ typedef struct svhip_config {
     int32_t model;          /* SVHIP_MODEL_* */
     int32_t compute;        /* SVHIP_F32: fp32 MFMA, 1e-4 parity path; SVHIP_BF16: bf16 MFMA, fp32 accumulate;
                                SVHIP_F32X3: fp32 storage and arithmetic everywhere except the k = 1 / k = 5 convolution GEMMs, whose
-                               products are three bf16 MFMAs on hi / lo-split fp32 operands (~2^-17 per product): 1e-4 parity, ~2x faster */
+                               products are three bf16 MFMAs on hi / lo-split fp32 operands (~2^-17 per product): 1e-4 parity, ~2x faster;
+                               SVHIP_F16 (RawNet2 handles only): fp16 storage + fp16 MFMA, fp32 accumulate — the same speed as bf16 with
+                               three more mantissa bits (RawNet2's un-normalised residual stack loses two digits to bf16 WEIGHT rounding);
+                               an fp16 value overflows at 65504: the input is LayerNorm'ed, so only the weights decide the activation scale */
     int32_t device;         /* HIP device ordinal */
     int32_t channels;       /* ECAPA C (channels = [C,C,C,C,3C], ECAPA_TDNN.py:378) */
     int32_t n_mels;         /* 80 */
@@ -238,6 +241,13 @@ int svhip_profile_filter(svhip_handle* h, const char* label);   /* NULL / "": ev
 int svhip_profile_reset(svhip_handle* h);
 int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap, double* ms, int64_t* launches, double* flops);
 double svhip_workload_flops(const svhip_handle* h);
+/* Developer / test options (not part of the reference's surface).  The SVHIP_<NAME> environment variables are read ONCE, by
+ * svhip_create, as a new handle's defaults; afterwards only this call changes them — no getenv on the hot path.  Names:
+ * "pw3_cus" (cap of the persistent GEMM grids; 0: off), "rn_unfused", "rn_stop", "rn_snap", "asp_v1", "r2_big", "x3_keep_f32",
+ * "asnorm_slab", "asnorm_f32mfma", "fbank32", "cv_off", "layer_labels".  Unknown names: SVHIP_ERR_INVALID. */
+int svhip_set_option(svhip_handle* h, const char* name, int32_t value);
+/* Free the scoring / metrics scratch slots of the handle (grown on demand, otherwise kept until svhip_destroy). */
+int svhip_trim_scratch(svhip_handle* h);
 int svhip_selftest(void);   /* host-only self checks (per-device launch-attribute bookkeeping); 0 = ok, no GPU needed */
 
 #ifdef __cplusplus

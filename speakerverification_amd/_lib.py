@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SVHIP_LIB_PATH") or os.path.join(HERE, "libsvhip.so")
 
 OK = 0
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
-F32, BF16, I64, F32X3 = 0, 1, 2, 3
+F32, BF16, I64, F32X3, F16 = 0, 1, 2, 3, 4
 IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
 TRIAL_COSINE, TRIAL_PNORM, TRIAL_PDIST = 0, 1, 2
 COMM_ID_BYTES = 128
@@ -92,6 +92,8 @@ _SIGNATURES = {
     "svhip_profile_get": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "svhip_workload_flops": (C.c_double, [_P]),
+    "svhip_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "svhip_trim_scratch": (C.c_int, [_P]),
     "svhip_selftest": (C.c_int, []),
 }
 

@@ -60,7 +60,25 @@ struct svhip_handle {
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};       // [lane] done events, [4] = fork point
     int lanes = 1;                            // > 1: the forward runs as that many batch slices on as many streams
-    bool bf16 = false;
+    // developer / test switches.  The SVHIP_* environment variables of the same names are read ONCE, in svhip_create (they are the
+    // defaults of a new handle); afterwards only svhip_set_option changes them: no getenv on any forward or scoring call
+    struct DevOpts {
+        int layer_labels = 0;     // one profile row per GEMM shape
+        int x3_keep_f32 = 0;      // F32X3: keep the fp32 copies of the block outputs beside the split layout
+        int r2_big = 0;           // F32X3: Res2Net steps on the R2 form of the 256 x 256 kernel instead of r2_step
+        int asp_v1 = 0;           // bf16: asp_fused_kernel instead of asp_bf16_kernel
+        int rn_stop = -1;         // RawNet2: return after this many residual blocks (0: after the sinc front-end), unfused kernel sequence
+        int rn_snap = -1;         // RawNet2: keep block n's pre-activation as stage "rn_snap"
+        int rn_unfused = 0;       // RawNet2: the separate kernel sequence instead of rn_block128 / rn_tail / the folded shortcut
+        int asnorm_slab = 0;      // AS-norm statistics on the slab path
+        int asnorm_f32mfma = 0;   // AS-norm fused kernel on the exact fp32 MFMA instead of six bf16 MFMAs
+        int fbank32 = 0;          // the 32-frame front-end kernel
+        int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
+        int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
+    } opt;
+    bool bf16 = false;                        // 16-bit storage handle: bf16, or fp16 when `f16` is set (the flag keeps its round-1 name)
+    bool f16 = false;                         // SVHIP_F16: the 16-bit type is IEEE half (RawNet2)
+    int dt = DT_F32;                          // DT_F32 / DT_BF16 / DT_F16: what the element-wise launchers are told
     bool x3 = false;                          // SVHIP_F32X3: fp32 handle whose conv GEMMs run as split-bf16 MFMA triples
     bool finalized = false;
     std::string err;
@@ -94,7 +112,6 @@ struct svhip_handle {
         float* afms_fcT = nullptr;              // fc weight transposed [cin][cout] (the gate kernel reads consecutive outputs per wave)
     };
     RnBlock rn_blocks[8];
-    bool layer_labels = getenv("SVHIP_LAYER_LABELS") != nullptr;
     float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
     void* rn_filt = nullptr;
     float *rn_agg_scale = nullptr, *rn_agg_shift = nullptr;
@@ -202,6 +219,13 @@ int dev_upload(svhip_handle* h, T** p, const std::vector<T>& v) {
     return SVHIP_OK;
 }
 
+inline uint16_t f32_to_f16_rne(float f) {      // IEEE half, round to nearest even (the host compiler's _Float16 conversion)
+    const _Float16 hv = static_cast<_Float16>(f);
+    uint16_t u;
+    memcpy(&u, &hv, 2);
+    return u;
+}
+
 inline uint16_t f32_to_bf16_rne(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -209,6 +233,9 @@ inline uint16_t f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+
+// a weight in the handle's 16-bit storage type
+inline uint16_t to_h16(const svhip_handle* h, float f) { return h->f16 ? f32_to_f16_rne(f) : f32_to_bf16_rne(f); }
 
 // ---- profiling-aware launch wrapper --------------------------------------------------------------
 hipEvent_t prof_event(svhip_handle* h) {
@@ -485,7 +512,7 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
     int rc;
     if (h->bf16) {
         std::vector<uint16_t> pb(packed.size());
-        for (size_t i = 0; i < packed.size(); ++i) pb[i] = f32_to_bf16_rne(packed[i]);
+        for (size_t i = 0; i < packed.size(); ++i) pb[i] = to_h16(h, packed[i]);
         uint16_t* d;
         if ((rc = dev_upload(h, &d, pb))) return rc;
         L.W = d;
@@ -666,7 +693,7 @@ int bake_sinc(svhip_handle* h) {
     if (h->bf16) {
         std::vector<uint16_t> pk((size_t)NF * 256, 0);
         for (int f = 0; f < NF; ++f)
-            for (int k = 0; k < KS; ++k) pk[(size_t)f * 256 + k] = f32_to_bf16_rne(filt[(size_t)f * KS + k]);
+            for (int k = 0; k < KS; ++k) pk[(size_t)f * 256 + k] = to_h16(h, filt[(size_t)f * KS + k]);
         uint16_t* d;
         if ((rc = dev_upload(h, &d, pk))) return rc;
         h->rn_filt = d;
@@ -708,8 +735,8 @@ int finalize_rawnet2(svhip_handle* h) {
                 std::vector<uint16_t> pk((size_t)Np * Kt, 0);
                 for (int n = 0; n < planes; ++n) {
                     for (int t = 0; t < 3; ++t)
-                        for (int c = 0; c < planes; ++c) pk[(size_t)n * Kt + t * planes + c] = f32_to_bf16_rne(w2->data[((size_t)n * planes + c) * 3 + t]);
-                    for (int c = 0; c < inpl; ++c) pk[(size_t)n * Kt + K2 + c] = f32_to_bf16_rne(ws->data[(size_t)n * inpl + c]);
+                        for (int c = 0; c < planes; ++c) pk[(size_t)n * Kt + t * planes + c] = to_h16(h, w2->data[((size_t)n * planes + c) * 3 + t]);
+                    for (int c = 0; c < inpl; ++c) pk[(size_t)n * Kt + K2 + c] = to_h16(h, ws->data[(size_t)n * inpl + c]);
                 }
                 uint16_t* d;
                 if ((rc = dev_upload(h, &d, pk))) return rc;
@@ -824,6 +851,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.lda = lda; p.lda2 = lda2; p.ldy = ldy; p.ld_bu = ld_bu;
     p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
+    p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus;
     const bool bf = h->bf16;
     hipStream_t st = h->cur;
     (void)label;
@@ -861,7 +889,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
                          : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
-    if (h->layer_labels) {                // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
+    if (h->opt.layer_labels) {            // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
         snprintf(shaped, sizeof(shaped), "%s M%d N%d K%d", klabel, M, L.N, L.K);
         klabel = shaped;
     }
@@ -916,11 +944,12 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         q.A = a32; q.lda = lda32; q.W = L.Ws32; q.x3 = 2; q.Y = MFA; q.ldy = L.N;
         q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
         q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.Wrows = L.Np; q.T = T; q.taps = L.taps; q.act1 = ACT_GELU; q.num_cu = h->num_cu;
+        q.pw3_cus = h->opt.pw3_cus;
         if (cs) { q.colsum = cs_base; q.colsum_sq = 1; q.colsum_stride = h->colsum_region; }
         return gemm_pw3x3_supported(q);
     };
     const bool s32_only = cat32 && x3_route(h->tdnn1[1], cat32, C3, false) && x3_route(h->tdnn1[2], cat32, C3, false) &&
-                          x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !getenv("SVHIP_X3_KEEP_F32");
+                          x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !h->opt.x3_keep_f32;
     if (s32_only) h->cat_f32_stale = true;
     bool b0_done = false, x0_s32 = false;
     if (h->x3 && h->blocks0.Wcv && h->s32_buf) {
@@ -931,7 +960,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
         q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
         q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
-        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus;
         // (with s32_only and tdnn1 of the first block on the X3 kernel, X0 itself is written in the split layout: no conversion pass,
         //  block 1's residual is read as hi + lo, svhip_get_stage rebuilds the fp32 view)
         q.y_s32 = (s32_only && x3_route(h->tdnn1[0], X0, C, false)) ? 1 : 0;
@@ -961,15 +990,14 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
             q.A = us[(j - 1) & 1]; q.lda = C8; q.W = L.Ws32; q.Wrows = L.N; q.x3 = 2;
             q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
             q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.T = T; q.taps = 3; q.dil = L.dil; q.cin = L.cin; q.pad_mode = PAD_REFLECT;
-            q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu;
+            q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus;
             q.Y = h2s + (size_t)j * C8 * 4; q.ldy = C;
             if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
             return q;
         };
         // (C / 8 = 128: the dedicated 128 x 128 kernel, two workgroups per CU, any batch size; C / 8 = 64, or SVHIP_R2_BIG=1: the R2 form
         //  of the persistent 256 x 256 kernel)
-        const char* r2big = getenv("SVHIP_R2_BIG");
-        const bool r2_small = h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && !(r2big && r2big[0] == '1') && r2_step_supported(step_params(1)) &&
+        const bool r2_small = h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && !h->opt.r2_big && r2_step_supported(step_params(1)) &&
                               x3_route(h->tdnn2[i], h2s, C, false);      // (tdnn2 must be able to read the chain output in the split layout)
         const bool r2_plan = r2_small || (h->x3 && h2s && us[0] && us[1] && h->res2[i][0].Ws32 && gemm_pw3r2_supported(step_params(1)));
         if (r2_plan) {      // tdnn1 writes the pass-through chunk and the first step's input in the split layout itself (when it takes the X3 kernel)
@@ -1055,8 +1083,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         return rc;
     // bf16: 16 waves per CU, lane-local online softmax (asp_x3.hip's bf16 form: 0.195 against 0.264 ms at B = 256, any T); the
     // one-wave-per-SIMD kernel keeps the channel counts that are not multiples of 256 (and SVHIP_ASP_V1=1: the tests compare the two)
-    const char* asp_v1 = getenv("SVHIP_ASP_V1");
-    const bool asp_v2 = bf && C3 % 256 == 0 && h->asp_tdnn.N == 128 && h->asp_conv.Kp == 128 && !(asp_v1 && asp_v1[0] == '1');
+    const bool asp_v2 = bf && C3 % 256 == 0 && h->asp_tdnn.N == 128 && h->asp_conv.Kp == 128 && !h->opt.asp_v1;
     if (asp_v2 || (bf && asp_fused_supported(T, C3, h->asp_tdnn.N, h->asp_conv.Kp))) {
         AspFusedParams ap;
         ap.att = ATT; ap.W = h->asp_conv.W; ap.Kp = h->asp_conv.Kp; ap.bias = h->asp_conv.bias;
@@ -1119,7 +1146,7 @@ static GemmParams conv2sc_params(svhip_handle* h, const svhip_handle::RnBlock& K
     p.M = M; p.N = K.cout; p.K = K.conv2.K; p.Kp = K.conv2.K + K.cin; p.Wrows = K.conv2.Np;
     p.lda = K.cout; p.ldy = K.cout; p.T = T; p.taps = 3; p.dil = 1; p.cin = K.cout; p.pad_mode = PAD_ZERO;
     p.A3 = pre; p.lda3 = K.cin; p.K3 = K.cin;
-    p.num_cu = h->num_cu;
+    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus;
     return p;
 }
 static bool conv2sc_fits(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
@@ -1145,16 +1172,17 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     int rc;
     void* rn_xn = bf ? static_cast<char*>(h->rn_xn) + (size_t)b0 * 2 * h->rn_Lp * 2 : nullptr;
-    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st, rn_xn, h->rn_Lp, h->rn_gamma, h->rn_beta); }))) return rc;
+    const int dt = h->dt;
+    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st, rn_xn, h->rn_Lp, h->rn_gamma, h->rn_beta, dt); }))) return rc;
     int T = h->rn_T1;
     void *x = off(h->rn_buf[0], b0 * per_utt, e), *pre = off(h->rn_buf[1], b0 * per_utt, e), *hb = off(h->rn_buf[2], b0 * per_utt, e),
          *o = off(h->rn_buf[3], b0 * per_utt, e), *sc = off(h->rn_buf[4], b0 * per_utt, e), *xn = off(h->rn_buf[5], b0 * per_utt, e);
-    const char* stop_env = getenv("SVHIP_RN_STOP");          // developer hook: stop after N blocks, expose x as stage "rn_x"
-    const int stop_after = stop_env ? atoi(stop_env) : -1;
+    // developer hook (option rn_stop): return after N residual blocks (0: after the front-end) with x exposed as stage "rn_x"; the
+    // unfused kernel sequence runs, whose storage points are those of the fused kernels
+    const int stop_after = h->opt.rn_stop;
     // developer hook (tests): SVHIP_RN_SNAP=2 keeps a copy of lrelu(bn1(x)) as block 2 will read it — the first tensor that both the
     // fused 128-channel blocks and the separate kernel sequence materialise — as stage "rn_snap"
-    const char* snap_env = getenv("SVHIP_RN_SNAP");
-    const int snap_at = snap_env ? atoi(snap_env) : -1;
+    const int snap_at = h->opt.rn_snap;
     auto snapshot = [&](const void* src, int Tn, int Cn) -> int {
         const size_t bytes = (size_t)B * Tn * Cn * e;
         if (h->rn_snap_cap < bytes) {
@@ -1170,15 +1198,16 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
-             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, bf, B, L, T, st,
+             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, dt, B, L, T, st,
                                    nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu);
          }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
+    if (stop_after == 0) return SVHIP_OK;
     // bf16: the 128 -> 128 pooled blocks (layer1, layer2) each run as ONE fused kernel + the AFMS gate kernel; the gate of
     // block i is applied by block i + 1 on the way in (or by the rn_afms_apply pass in front of the first GEMM block)
     int first = 0;
-    const bool fuse_ok = bf && stop_after < 0 && !getenv("SVHIP_RN_UNFUSED");
-    const bool no_tail = getenv("SVHIP_RN_UNFUSED") != nullptr;        // (tests: the separate passes against the fused tail)
+    const bool fuse_ok = bf && stop_after < 0 && !h->opt.rn_unfused;
+    const bool no_tail = h->opt.rn_unfused != 0;                        // (tests: the separate passes against the fused tail)
     const float *g_alpha = nullptr, *g_gate = nullptr;          // pending gate of the previous fused block
     const void* xin = x;
     for (; fuse_ok && first < 8; ++first) {
@@ -1193,7 +1222,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         void* dst = (first & 1) ? hb : o;                        // ping-pong: never the buffer being read
         bp.opool = reinterpret_cast<bf16_t*>(dst);
         bp.colsum = rn_part;
-        bp.B = B; bp.T = T; bp.Tout = T / 3; bp.ntiles = rn_block128_ntiles(T);
+        bp.B = B; bp.T = T; bp.Tout = T / 3; bp.ntiles = rn_block128_ntiles(T); bp.f16 = h->f16 ? 1 : 0;
         const double fl = (double)B * T * (K.conv1.flops_per_row + K.conv2.flops_per_row);
         if ((rc = run(h, "rn_block128", fl, [&]() { return launch_rn_block128(bp, h->num_cu, st); }))) return rc;
         float* gate = rn_gate[first & 1];                        // two gate buffers: block i + 1 reads i's while writing its own
@@ -1211,7 +1240,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         const float* nsh = first < 8 ? h->rn_blocks[first].bn1_shift : h->rn_agg_shift;
         // x itself is read only as an identity shortcut (or as a debug stage): not written when the next block projects its input
         void* xdst = (first < 8 && h->rn_blocks[first].has_shortcut && stop_after < 0) ? nullptr : x;
-        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, xdst, bf, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
+        if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(xin, xdst, dt, Kp.alpha, g_gate, B, T, Kp.cout, st, nsc, nsh, pre, 0.3f); }))) return rc;
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = Kp.cout;
         if (snap_at == first && b0 == 0 && (rc = snapshot(pre, T, Kp.cout))) return rc;
     }
@@ -1221,7 +1250,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // out = lrelu(bn1(x))                                                         RawNet_baseline.py:222
         // (blocks 1..7 get it from the previous block's AFMS pass, which writes x and lrelu(bn1(x)) together)
         if ((bi == 0 && first == 0) || stop_after >= 0) {
-            if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, bf, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
+            if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, dt, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
         }
         // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
         // A 1 x 1 shortcut rides in conv2's GEMM as extra K columns when the 256 x 256 kernel takes it (no shortcut tensor in HBM)
@@ -1243,30 +1272,31 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // the block output itself is read only by an identity shortcut of the next block (or as a debug stage)
         const bool x_dead = stop_after < 0 && npre && (bi == 7 || h->rn_blocks[bi + 1].has_shortcut);
         const int Tn = K.downsample ? T / 3 : T;
-        if (!no_tail && rn_tail_supported(bf, Tn, K.cout)) {
+        if (!no_tail && rn_tail_supported(dt, Tn, K.cout)) {
             // max-pool + AFMS + next pre-activation in one launch, the pooled activation held in registers      :228-229, :62-68
             char tl[48] = "rn_tail";
-            if (h->layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
+            if (h->opt.layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
             if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
-                     return launch_rn_tail(o, x_dead ? nullptr : xn, npre, bf, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
+                     return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
                  }))) return rc;
             T = Tn;
         } else {
             void* y = o;
             if (K.downsample) {                                                          // :228-229
-                if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, bf, B, T, K.cout, st); }))) return rc;
+                if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, dt, B, T, K.cout, st); }))) return rc;
                 T /= 3;
                 y = hb;
             }
             // AFMS: (y + alpha) * sigmoid(fc(mean_t y))                                     :62-68
-            if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, bf, K.cout, B, T, K.cout, rn_mean, st, rn_scratch, 16); }))) return rc;
+            if ((rc = run(h, "rn_afms_mean", 0, [&]() { return launch_colmean(y, dt, K.cout, B, T, K.cout, rn_mean, st, rn_scratch, 16); }))) return rc;
             if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
                      return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
                  }))) return rc;
-            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, x_dead ? nullptr : xn, bf, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, x_dead ? nullptr : xn, dt, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
         }
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
+        if (stop_after == bi + 1) return SVHIP_OK;
         if (snap_at == bi + 1 && b0 == 0 && npre && (rc = snapshot(npre, T, K.cout))) return rc;
     }
     // aggregation: attentive statistics pooling                                          RawNet2_custom.py:215-224
@@ -1275,7 +1305,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att0, pre, 512, hb, 128, M, ACT_LRELU001))) return rc;
     float* rn_logits = h->rn_logits + (size_t)b0 * T * 512;
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
-    if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(rn_logits, pre, bf, B, T, 512, rn_pooled, st); }))) return rc;
+    if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(rn_logits, pre, dt, B, T, 512, rn_pooled, st); }))) return rc;
     if ((rc = run(h, "rn_fc", 2.0 * B * h->rn_fc.N * h->rn_fc.K, [&]() {
              return launch_rowvec_linear(rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st);
          }))) return rc;
@@ -1286,7 +1316,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
 // blocks are grids of 86 - 400 workgroups, the AFMS passes are latency-bound) run beside the big ones of another
 int rawnet2_forward(svhip_handle* h, const float* d_wav, int B) {
     int rc = SVHIP_OK;
-    const int lanes = (h->lanes > 1 && B >= 16 * h->lanes && !getenv("SVHIP_RN_STOP")) ? h->lanes : 1;
+    const int lanes = (h->lanes > 1 && B >= 16 * h->lanes && h->opt.rn_stop < 0) ? h->lanes : 1;
     if (lanes > 1) {
         const int per = ((B + lanes - 1) / lanes + 3) & ~3;
         SV_HIP(h, hipEventRecord(h->lane_ev[4], h->stream));
@@ -1372,13 +1402,27 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return SVHIP_ERR_INVALID; }
     if (cfg->model != SVHIP_MODEL_ECAPA && cfg->model != SVHIP_MODEL_RAWNET2 && cfg->model != SVHIP_MODEL_NONE) { g_create_error = "unknown model"; return SVHIP_ERR_INVALID; }
     if (cfg->model == SVHIP_MODEL_ECAPA && (cfg->channels <= 0 || cfg->channels % 64 != 0)) { g_create_error = "ECAPA channels must be a positive multiple of 64"; return SVHIP_ERR_INVALID; }
+    if (cfg->compute != SVHIP_F32 && cfg->compute != SVHIP_BF16 && cfg->compute != SVHIP_F32X3 && cfg->compute != SVHIP_F16) { g_create_error = "unknown compute mode"; return SVHIP_ERR_INVALID; }
+    if (cfg->compute == SVHIP_F16 && cfg->model != SVHIP_MODEL_RAWNET2) { g_create_error = "SVHIP_F16 is RawNet2's 16-bit mode (ECAPA's is SVHIP_BF16)"; return SVHIP_ERR_UNSUPPORTED; }
     if (cfg->model == SVHIP_MODEL_RAWNET2 && cfg->samples < 251 + 3 * 3 * 3 * 3 * 3 * 3 * 3) { g_create_error = "RawNet2 needs at least 2438 samples"; return SVHIP_ERR_INVALID; }
     if (cfg->n_mels <= 0 || cfg->n_mels % 8 != 0 || cfg->max_batch <= 0 || cfg->samples < cfg->n_fft || cfg->hop_length <= 0) { g_create_error = "bad n_mels / max_batch / samples"; return SVHIP_ERR_INVALID; }
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SVHIP_ERR_HIP; }
     svhip_handle* h = new svhip_handle();
     h->cfg = *cfg;
-    h->bf16 = cfg->compute == SVHIP_BF16;
+    h->f16 = cfg->compute == SVHIP_F16;
+    h->bf16 = cfg->compute == SVHIP_BF16 || h->f16;
+    h->dt = h->f16 ? DT_F16 : h->bf16 ? DT_BF16 : DT_F32;
     h->x3 = cfg->compute == SVHIP_F32X3;
+    {   // the developer switches' defaults come from the environment, once
+        auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
+        auto is1 = [](const char* n) { const char* e = getenv(n); return (e && e[0] == '1') ? 1 : 0; };
+        auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        svhip_handle::DevOpts& o = h->opt;
+        o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
+        o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
+        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF");
+    }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
     if (cfg->stream) { h->stream = reinterpret_cast<hipStream_t>(cfg->stream); h->own_stream = false; }
@@ -1406,6 +1450,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         }
     }
     int rc = build_fbank_tables(h);
+    h->fb.force32 = h->opt.fbank32;
     if (rc == SVHIP_OK) rc = alloc_workspace(h);
     if (rc != SVHIP_OK) { g_create_error = h->err; svhip_destroy(h); return rc; }
     if (cfg->model == SVHIP_MODEL_NONE) h->finalized = true;
@@ -1661,7 +1706,7 @@ namespace {
 // a scratch slot of at least `bytes` (grown by half again; the old block is freed only after the stream has drained)
 int scratch(svhip_handle* h, int slot, size_t bytes, void** out) {
     if (h->scr_cap[slot] < bytes || !h->scr[slot]) {
-        if (h->scr[slot]) { SV_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->scr[slot]); h->scr[slot] = nullptr; h->scr_cap[slot] = 0; }
+        if (h->scr[slot]) { SV_HIP(h, hipStreamSynchronize(h->stream)); if (h->aux_stream) SV_HIP(h, hipStreamSynchronize(h->aux_stream)); (void)hipFree(h->scr[slot]); h->scr[slot] = nullptr; h->scr_cap[slot] = 0; }
         const size_t cap = std::max<size_t>(bytes + bytes / 2, 256);
         if (hipMalloc(&h->scr[slot], cap) != hipSuccess) {
             if (hipMalloc(&h->scr[slot], std::max<size_t>(bytes, 256)) != hipSuccess) { h->scr[slot] = nullptr; SV_FAIL(h, SVHIP_ERR_NOMEM, "scratch slot %d: %zu bytes", slot, bytes); }
@@ -1869,7 +1914,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     if ((rc = tM.out(mu, (size_t)N * 4, dout, &dM))) return rc;
     if ((rc = tS.out(sigma, (size_t)N * 4, dout, &dS))) return rc;
     const bool aligned = ((reinterpret_cast<uintptr_t>(dE) | reinterpret_cast<uintptr_t>(dC)) & 15) == 0;
-    if (!h->x3 && aligned && asnorm_fused_supported(D, K, top) && !getenv("SVHIP_ASNORM_SLAB")) {
+    if (!h->x3 && aligned && asnorm_fused_supported(D, K, top) && !h->opt.asnorm_slab) {
         // fused path: the scores never leave the MFMA accumulators (csrc/asnorm_fused.hip)
         // chunks of 131 072 embeddings: the candidate statistics of chunk c run on a second stream under the MFMA kernel of
         // chunk c + 1 (two candidate buffers; the kernels meet through events)
@@ -1878,7 +1923,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         const size_t mb_bytes = (size_t)(D + 32) * D * 4;          // [MB | slice partials of its computation]
         const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 2;
         // (the exact default is the six-bf16-MFMA form where it is built: scores to fp32 rounding at 2.7 x the fp32 matrix rate)
-        const bool x6 = asnorm_fused6_supported(D) && !getenv("SVHIP_ASNORM_F32MFMA");
+        const bool x6 = asnorm_fused6_supported(D) && !h->opt.asnorm_f32mfma;
         // (x6: the candidate kernel takes 1.7 ms of 17 on its own and 7 when it shares the CUs with the matrix kernel: one stream.
         //  The fp32-MFMA form keeps the second stream: 26.1 - 26.9 against 27.5 ms)
         const int nbuf = (N > chunk && !x6) ? 2 : 1;
@@ -2075,6 +2120,7 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     else if (n == "asp_bn") { src = h->d_pool_bn; rows = B; cols = ld = 2 * C3; f32 = true; }
     else if (n == "rn_x") { src = h->rn_dbg_x; rows = (size_t)B * h->rn_dbg_T; cols = ld = h->rn_dbg_C; }
     else if (n == "rn_snap") { src = h->rn_snap; rows = (size_t)B * h->rn_snap_T; cols = ld = h->rn_snap_C; }
+    else if (n == "rn_pooled") { src = h->rn_pooled; rows = B; cols = ld = 1024; f32 = true; }
     else if (n == "mel") { src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true; }
     else SV_FAIL(h, SVHIP_ERR_INVALID, "unknown stage %s", name);
     *count = (int64_t)(rows * cols);
@@ -2086,7 +2132,8 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     if (f32) memcpy(out, tmp.data(), tmp.size());
     else {
         const uint16_t* s = reinterpret_cast<const uint16_t*>(tmp.data());
-        for (size_t i = 0; i < rows * cols; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&out[i], &u, 4); }
+        if (h->f16) for (size_t i = 0; i < rows * cols; ++i) { _Float16 hv; memcpy(&hv, &s[i], 2); out[i] = static_cast<float>(hv); }
+        else for (size_t i = 0; i < rows * cols; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&out[i], &u, 4); }
     }
     return SVHIP_OK;
 }
@@ -2106,6 +2153,35 @@ int svhip_profile_get(svhip_handle* h, int32_t idx, char* name, int32_t name_cap
     return SVHIP_OK;
 }
 double svhip_workload_flops(const svhip_handle* h) { return h ? h->flops_per_utt : 0.0; }
+
+int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
+    if (!h || !name) return SVHIP_ERR_INVALID;
+    const std::string n(name);
+    svhip_handle::DevOpts& o = h->opt;
+    struct { const char* key; int* slot; } table[] = {
+        {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
+        {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off}};
+    for (auto& t : table)
+        if (n == t.key) {
+            *t.slot = value;
+            h->fb.force32 = o.fbank32;
+            return SVHIP_OK;
+        }
+    SV_FAIL(h, SVHIP_ERR_INVALID, "unknown option %s", name);
+}
+
+// Release the scoring / metrics scratch slots (they are grown on demand and otherwise kept for the life of the handle: one slab-path
+// AS-norm call or one large host-pointer call would hold gigabytes of HBM beside the model engines' workspaces).
+int svhip_trim_scratch(svhip_handle* h) {
+    if (!h) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->aux_stream) SV_HIP(h, hipStreamSynchronize(h->aux_stream));
+    for (int i = 0; i < svhip_handle::SCR_COUNT; ++i)
+        if (h->scr[i]) { (void)hipFree(h->scr[i]); h->scr[i] = nullptr; h->scr_cap[i] = 0; }
+    return SVHIP_OK;
+}
 
 // host-only self checks (no GPU needed): the per-device one-time flag every LDS-hungry launcher keeps
 int svhip_selftest(void) {

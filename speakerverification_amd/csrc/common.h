@@ -7,12 +7,20 @@ namespace svhip {
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// fp16 (IEEE half): the second 16-bit storage type.  RawNet2's 16-bit path runs on it (SVHIP_F16): same MFMA rate as bf16, three more
+// mantissa bits — on RawNet2 the bf16 rounding of the conv WEIGHTS alone moves an embedding by up to 9 % of its scale (cosine 0.994
+// to the fp32 reference; tests/analysis/rn_bf16_sites.py), fp16 storage keeps it within 1 % (cosine >= 0.9999)
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WAVE = 64;
+
+// storage / MFMA operand type of a launch: the launchers' `dt` argument (a plain `bool bf16` converts to DT_F32 / DT_BF16)
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4, ACT_LRELU03 = 5, ACT_LRELU001 = 6 };
 enum Pad : int { PAD_REFLECT = 0, PAD_ZERO = 1 };
@@ -23,7 +31,9 @@ __device__ __forceinline__ bf16_t f2bf(float v) { return static_cast<bf16_t>(v);
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return static_cast<float>(v); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return static_cast<f16_t>(v); }
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }
 
@@ -69,6 +79,46 @@ template <> struct Vec16<bf16_t> {
     bf16x8 v;
     __device__ __forceinline__ float get(int i) const { return static_cast<float>(v[i]); }
     __device__ __forceinline__ void set(int i, float x) { v[i] = static_cast<bf16_t>(x); }
+};
+
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    f16x8 v;
+    __device__ __forceinline__ float get(int i) const { return static_cast<float>(v[i]); }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = static_cast<f16_t>(x); }
+};
+
+// Per-type pieces of the 16-bit kernels: H = bf16_t or f16_t.  Fragments travel as raw 16-byte vectors (bf16x8 in the kernels'
+// declarations whatever H is); only the MFMA opcode and the fp32 <-> 16-bit conversions differ.
+template <typename H> struct Half16;
+template <> struct Half16<bf16_t> {
+    static constexpr bool F16 = false;
+    static __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    // two 16-bit values in one dword <-> fp32 (unpack exact, pack round-to-nearest-even: v_cvt_pk_bf16_f32)
+    static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{a, b}, bf16x2_));
+    }
+};
+template <> struct Half16<f16_t> {
+    static constexpr bool F16 = true;
+    static __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    typedef f16_t f16x2_ __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2_, w)[0]); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2_, w)[1]); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {      // v_cvt_pk_f16_f32 (round to nearest even; overflow -> inf)
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{a, b}, f16x2_));
+    }
 };
 
 }  // namespace svhip

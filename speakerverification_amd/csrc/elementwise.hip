@@ -490,22 +490,25 @@ inline int grid_for(int64_t work_items) {
 
 }  // namespace
 
-hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
+hipError_t launch_colmean(const void* X, int dt, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
                           float* scratch, int scratch_slices) {
-    const int vec = bf16 ? 8 : 4;
+    const bool bf16 = dt == DT_BF16;
+    const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec != 0 || ldx % vec != 0) return hipErrorInvalidValue;
     const int gx = (C + 64 * vec - 1) / (64 * vec);
     if (scratch && scratch_slices > 1 && T >= 1024 && gx * B < 2048) {       // too few workgroups for a long T: slice it
         const int TS = scratch_slices;
         dim3 grid(gx, B, TS), block(256);
-        if (bf16) hipLaunchKernelGGL(colsum_slice_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, TS, scratch);
+        if (dt == DT_F16) hipLaunchKernelGGL(colsum_slice_kernel<f16_t>, grid, block, 0, stream, (const f16_t*)X, ldx, T, C, TS, scratch);
+        else if (bf16) hipLaunchKernelGGL(colsum_slice_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, TS, scratch);
         else hipLaunchKernelGGL(colsum_slice_kernel<float>, grid, block, 0, stream, (const float*)X, ldx, T, C, TS, scratch);
         const int n = B * C;
         hipLaunchKernelGGL(colsum_slice_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scratch, TS, C, T, mean, n);
         return hipGetLastError();
     }
     dim3 grid((C + 64 * vec - 1) / (64 * vec), B), block(256);
-    if (bf16) hipLaunchKernelGGL((colstats_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, mean, C, 0.f);
+    if (dt == DT_F16) hipLaunchKernelGGL((colstats_kernel<f16_t, false>), grid, block, 0, stream, (const f16_t*)X, ldx, T, C, mean, C, 0.f);
+    else if (bf16) hipLaunchKernelGGL((colstats_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)X, ldx, T, C, mean, C, 0.f);
     else hipLaunchKernelGGL((colstats_kernel<float, false>), grid, block, 0, stream, (const float*)X, ldx, T, C, mean, C, 0.f);
     return hipGetLastError();
 }

@@ -447,12 +447,11 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
     dim3 grid((T + FB_FRAMES - 1) / FB_FRAMES, B), block(FB_THREADS);
     if (tb.split_bf16 && (!tb.basis_hi || !tb.basis_lo || tb.hop % 8 != 0)) return hipErrorInvalidValue;
     // 64-frame kernel: needs the mel bank to stop below the Nyquist bin (eight pairs = 256 bins) and its tile in 64 KiB of LDS
-    const char* small_tiles = getenv("SVHIP_FBANK32");                                   // developer switch: the 32-frame kernel
     const int ns2 = (F2_FRAMES - 1) * tb.hop + tb.win_length;
     const int ns2_pad = ((ns2 + 15) & ~15) + 16;
     const bool x6 = tb.split6 && tb.basis_hi && tb.basis_lo && tb.basis_l3 && tb.hop % 8 == 0;
     const size_t lds2 = (size_t)(32 * F2_PT_STRIDE + tb.n_melw) * sizeof(float) + (size_t)ns2_pad * (x6 ? 6 : 4);
-    if (tb.mel_max_bin < 256 && tb.n_pairs >= 8 && lds2 <= 80 * 1024 && !(small_tiles && small_tiles[0] == '1')) {
+    if (tb.mel_max_bin < 256 && tb.n_pairs >= 8 && lds2 <= 80 * 1024 && !tb.force32) {
         dim3 grid2((T + F2_FRAMES - 1) / F2_FRAMES, B);
         if (x6) {
             static DeviceOnce attr6;

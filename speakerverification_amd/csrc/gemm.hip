@@ -12,6 +12,8 @@
 //   grid: XCD-aware — each XCD owns a contiguous band of M tiles and walks it in groups of 8 M-tiles
 //        x all N-tiles (m fastest), so concurrently resident workgroups share A and W panels in that
 //        XCD's L2.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -57,6 +59,27 @@ template <> struct MmaTraits<bf16_t> {
         chunk_t r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = static_cast<bf16_t>(static_cast<float>(a[j]) + static_cast<float>(b[j]));
+        return r;
+    }
+};
+
+template <> struct MmaTraits<f16_t> {         // SVHIP_F16 handles (RawNet2)
+    static constexpr int EPC = 8;
+    static constexpr int BK = 64;
+    typedef f16x8 chunk_t;
+    static __device__ __forceinline__ void mma(const chunk_t& a, const chunk_t& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ chunk_t zero() {
+        chunk_t z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = static_cast<f16_t>(0.0f);
+        return z;
+    }
+    static __device__ __forceinline__ chunk_t add(const chunk_t& a, const chunk_t& b) {
+        chunk_t r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = static_cast<f16_t>(static_cast<float>(a[j]) + static_cast<float>(b[j]));
         return r;
     }
 };
@@ -278,7 +301,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                     if (EPI == EPI_BN_LRELU03) v = v > 0.0f ? v : 0.3f * v;
                     if (p.R) v += to_f32<T>(reinterpret_cast<const T*>(p.R)[(int64_t)m * p.ldr + n]);
                     if (out_f32) reinterpret_cast<float*>(p.Y)[(int64_t)m * p.ldy + n] = v;
-                    else reinterpret_cast<bf16_t*>(p.Y)[(int64_t)m * p.ldy + n] = static_cast<bf16_t>(v);
+                    else {
+                        typedef typename std::conditional<sizeof(T) == 2, T, bf16_t>::type OT;
+                        reinterpret_cast<OT*>(p.Y)[(int64_t)m * p.ldy + n] = static_cast<OT>(v);
+                    }
                 }
             }
         }
@@ -315,9 +341,11 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
     if (p.act1 == ACT_NONE && p.act2 == ACT_NONE) return launch_epi<T, EPI_NONE>(p, stream);
+    if constexpr (!std::is_same<T, f16_t>::value) {      // (fp16: RawNet2's epilogues only)
     if (p.act1 == ACT_RELU && p.act2 == ACT_NONE) return launch_epi<T, EPI_RELU>(p, stream);
     if (p.act1 == ACT_GELU && p.act2 == ACT_NONE) return launch_epi<T, EPI_GELU>(p, stream);
     if (p.act1 == ACT_RELU && p.act2 == ACT_TANH) return launch_epi<T, EPI_RELU_TANH>(p, stream);
+    }
     if (p.act1 == ACT_LRELU03 && p.act2 == ACT_NONE) return launch_epi<T, EPI_LRELU03>(p, stream);
     if (p.act1 == ACT_NONE && p.act2 == ACT_LRELU03) return launch_epi<T, EPI_BN_LRELU03>(p, stream);
     if (p.act1 == ACT_LRELU001 && p.act2 == ACT_NONE) return launch_epi<T, EPI_LRELU001>(p, stream);
@@ -339,7 +367,7 @@ GemmRoute gemm_route(const GemmParams& p, bool bf16) {
         const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         const bool pw3 = !no_pw3 && gemm_pw3_supported(p, bf16);
         // (a capped persistent grid — the test switch SVHIP_PW3_CUS — also takes the small grids that would go to the narrow tile)
-        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu && !(pw3 && pw3_grid_cap(p.num_cu) < p.num_cu)) return ROUTE_PW_NARROW;
+        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu && !(pw3 && pw3_grid_cap(p) < p.num_cu)) return ROUTE_PW_NARROW;
         if (pw3) return ROUTE_PW3;
         return ROUTE_PW2;
     }
@@ -369,6 +397,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         case ROUTE_PW_NARROW: return launch_gemm_pw(p, bf16, stream, true);
         default: break;
     }
+    if (bf16 && p.f16) return p.x3 ? hipErrorInvalidValue : launch_t<f16_t>(p, stream);
     return bf16 ? launch_t<bf16_t>(p, stream) : launch_t<float>(p, stream);
 }
 

@@ -94,6 +94,14 @@ template <> struct Frag<bf16_t> {
     }
 };
 
+template <> struct Frag<f16_t> {           // SVHIP_F16 handles (RawNet2): the bf16 kernel with the fp16 MFMA opcode
+    typedef f16x8 chunk_t;
+    static constexpr int EPC = 8, BK = 64;
+    static __device__ __forceinline__ void mma(const chunk_t& w, const chunk_t& x, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+    }
+};
+
 // CONV: the A operand is the im2col view of a dilated 1-D convolution (per-lane DMA source = frame
 // t + (tap - taps/2)*dil of the same utterance, reflect / zero padded; padded chunks read a zero page).
 // fp32 value pair -> bf16 hi / lo parts (x = hi + lo up to 2^-17 relative): eight k-values of one fragment row
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
         return; }
 
     // ---- epilogue: acc[i][j][4g+e] is (m = wm*64 + i*32 + fr, n = wn*64 + j*32 + 8g + 4fh + e) ----
-    typedef typename std::conditional<OUT_F32, float, bf16_t>::type OT;
+    typedef typename std::conditional<OUT_F32, float, typename std::conditional<sizeof(T) == 2, T, bf16_t>::type>::type OT;
     constexpr int ORB = PBN * (int)sizeof(OT);                    // output tile row bytes: 256 or 512
     constexpr int OCH = OUT_F32 ? 16 : 8;                         // bytes written per lane per group
 #pragma unroll
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
                     *reinterpret_cast<f32x4*>(smem + ml * ORB + ((c16 ^ (ml & 7)) << 4)) = o;
                 } else {
                     const int c8 = nl >> 2;                                   // 8-byte chunk index
-                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                    bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+                    typedef OT bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o = {static_cast<OT>(v[0]), static_cast<OT>(v[1]), static_cast<OT>(v[2]), static_cast<OT>(v[3])};
                     *reinterpret_cast<bf16x4*>(smem + ml * ORB + ((c8 ^ (ml & 15)) << 3)) = o;
                 }
             }
@@ -397,9 +405,11 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
 template <typename T, bool OUT_F32, int BN>
 hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     if (p.act1 == ACT_NONE && p.act2 == ACT_NONE) return launch_inst<T, EPI_NONE, OUT_F32, BN>(p, stream);
+    if constexpr (!std::is_same<T, f16_t>::value) {      // (fp16: RawNet2's epilogues only)
     if (p.act1 == ACT_RELU && p.act2 == ACT_NONE) return launch_inst<T, EPI_RELU, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_GELU && p.act2 == ACT_NONE) return launch_inst<T, EPI_GELU, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_RELU && p.act2 == ACT_TANH) return launch_inst<T, EPI_RELU_TANH, OUT_F32, BN>(p, stream);
+    }
     if (p.act1 == ACT_LRELU03 && p.act2 == ACT_NONE) return launch_inst<T, EPI_LRELU03, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_NONE && p.act2 == ACT_LRELU03) return launch_inst<T, EPI_BN_LRELU03, OUT_F32, BN>(p, stream);
     if (p.act1 == ACT_LRELU001 && p.act2 == ACT_NONE) return launch_inst<T, EPI_LRELU001, OUT_F32, BN>(p, stream);
@@ -439,6 +449,11 @@ bool gemm_pw_supported(const GemmParams& p, bool bf16) {
 
 hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow) {
     if (!gemm_pw_supported(p, bf16) || p.M <= 0 || p.N <= 0 || p.Wrows < p.N) return hipErrorInvalidValue;
+    if (bf16 && p.f16) {
+        if (p.out_f32) return launch_epi<f16_t, true, 128>(p, stream);
+        if (p.N >= 256 && !narrow) return launch_epi<f16_t, false, 256>(p, stream);
+        return launch_epi<f16_t, false, 128>(p, stream);
+    }
     if (bf16) {
         if (p.out_f32) return launch_epi<bf16_t, true, 128>(p, stream);
         // 256-wide N tiles halve the LDS-DMA bytes per FLOP; the output tile (256 x 256 bf16) still fits the LDS

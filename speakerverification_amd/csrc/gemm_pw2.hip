@@ -53,7 +53,8 @@ constexpr int ABL = PW2_ABL;
 constexpr int ABL = 0;
 #endif
 
-template <int EPI, int CONV>        // CONV: 0 plain, 1 conv-gather, 2 conv-gather + appended pointwise K segment (A3)
+// H: the 16-bit operand / output type (bf16_t, or f16_t for SVHIP_F16 handles: the same loop, the f16 MFMA opcode and conversions)
+template <int EPI, int CONV, typename H = bf16_t>        // CONV: 0 plain, 1 conv-gather, 2 conv-gather + appended pointwise K segment (A3)
 __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
+                acc16[(I0) + i][(J0) + j] = Half16<H>::mfma16(WARR[j][ks], xf[i][ks], acc16[(I0) + i][(J0) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_s_barrier();
 #define PW2_KTILE(steady_, REM_, KT_, WCUR, WNXT)                                                   \
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
             float v[4];
             if (ABL & 4) { v[0] = acc16[i][cg][0]; v[1] = acc16[i][cg][1]; v[2] = acc16[i][cg][2]; v[3] = acc16[i][cg][3]; }
             else act4<EPI>(v, acc16[i][cg], sc4a[cg], sh4a[cg]);
-            typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 o = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+            typedef H bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o = {static_cast<H>(v[0]), static_cast<H>(v[1]), static_cast<H>(v[2]), static_cast<H>(v[3])};
             *reinterpret_cast<bf16x4*>(smem + ml * ORB + (((nl >> 2) ^ (ml & 15)) << 3)) = o;
         }
     }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
         const int rb = (m0 / p.T + 1) * p.T - m0;            // first tile row that belongs to the next utterance
         const int rend = min(256, p.M - m0);
         float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f}, q1[4] = {0.f, 0.f, 0.f, 0.f};
-        typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+        typedef H bf16x4 __attribute__((ext_vector_type(4)));
         // rows [lo, mid) belong to segment 0, [mid, hi) to segment 1; all three are wave-uniform (rg is the wave index).
         // Almost always a wave's 32 rows sit in one segment: that case runs fully unrolled (32 LDS reads in flight, no selects);
         // a runtime-bounded loop exposes one LDS round trip per row (2.7 us per tile when every wave took it)
@@ -375,11 +376,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
                 u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float lo = __uint_as_float(d[e] << 16) + __uint_as_float(rv[it][e] << 16);
-                    const float hi = __uint_as_float(d[e] & 0xffff0000u) + __uint_as_float(rv[it][e] & 0xffff0000u);
-                    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
-                    const bf16x2 pk = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
-                    d[e] = __builtin_bit_cast(uint32_t, pk);
+                    const float lo = Half16<H>::lo(d[e]) + Half16<H>::lo(rv[it][e]);
+                    const float hi = Half16<H>::hi(d[e]) + Half16<H>::hi(rv[it][e]);
+                    d[e] = Half16<H>::pack2(lo, hi);
                 }
                 const int m = m0 + row, n = n0 + q * 8;
                 if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(Yb + ((int64_t)m * p.ldy + n) * 2) = d;
@@ -411,13 +410,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pw2_kernel(GemmParams p) {
 #undef PW2_STAMP
 }
 
-template <int EPI, int CONV>
-hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+template <int EPI, int CONV, typename H>
+hipError_t launch_inst_h(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + QBM - 1) / QBM, ntn = (p.N + QBN - 1) / QBN;
     static DeviceOnce attr;
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, CONV>), PW2_LDS)) return e;
-    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, CONV>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw2_kernel<EPI, CONV, H>), PW2_LDS)) return e;
+    hipLaunchKernelGGL((gemm_pw2_kernel<EPI, CONV, H>), dim3(ntm * ntn), dim3(512), PW2_LDS, stream, p);
     return hipGetLastError();
+}
+// fp16 instances exist for the epilogues RawNet2 uses (ECAPA's 16-bit path is bf16): none / LeakyReLU forms
+template <int EPI, int CONV>
+hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
+    if (p.f16) {
+        if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) return hipErrorInvalidValue;
+        else return launch_inst_h<EPI, CONV, f16_t>(p, stream);
+    }
+    return launch_inst_h<EPI, CONV, bf16_t>(p, stream);
 }
 
 }  // namespace
@@ -428,6 +436,7 @@ bool gemm_pw2_supported(const GemmParams& p, bool bf16) {
     if (p.act2 != ACT_NONE && !(p.act2 == ACT_LRELU03 && p.act1 == ACT_NONE)) return false;
     if (p.colsum && (p.T < 256 || p.M % p.T != 0)) return false;      // at most one utterance boundary per 256-row tile
     if (!(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU || p.act1 == ACT_LRELU03)) return false;
+    if (p.f16 && (p.act1 == ACT_RELU || p.act1 == ACT_GELU)) return false;          // (no fp16 instances of ECAPA's epilogues)
     if (p.N < 256 || p.Kp % 64 != 0 || p.N % 8 != 0 || p.lda % 8 != 0 || p.ldy % 8 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y)) & 15) return false;
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;

@@ -680,7 +680,7 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS, X3>), PW3_LDS)) return e;
-    const int cap = pw3_grid_cap(p.num_cu);
+    const int cap = pw3_grid_cap(p);
     const int grid = ntiles < cap ? ntiles : cap;
     hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS, X3>), dim3(grid), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
@@ -690,7 +690,7 @@ hipError_t launch_cv(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_GELU, 0, true, false, true>), PW3_LDS)) return e;
-    const int cap = pw3_grid_cap(p.num_cu);
+    const int cap = pw3_grid_cap(p);
     hipLaunchKernelGGL((gemm_pw3_kernel<EPI_GELU, 0, true, false, true>), dim3(ntiles < cap ? ntiles : cap), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
 }
@@ -708,23 +708,21 @@ hipError_t launch_cs(const GemmParams& p, hipStream_t stream) {
 // workgroup has no second tile to overlap anything with).
 bool gemm_pw3_supported(const GemmParams& p, bool bf16) {
     if (!gemm_pw2_supported(p, bf16)) return false;
-    if (p.taps > 1 || p.R || p.A3) return false;
+    if (p.taps > 1 || p.R || p.A3 || p.f16) return false;
     if (p.N % 256 != 0 || p.Kp < 256) return false;
     if (!p.bias || !p.scale || !p.shift) return false;
     if (p.act2 != ACT_NONE || !(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU)) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
-    return ntiles > pw3_grid_cap(p.num_cu);
+    return ntiles > pw3_grid_cap(p);
 }
 
-// developer switch SVHIP_PW3_CUS=n (read at every call, like the library's other test switches): launch at most n workgroups, so that
-// a small test problem walks several tiles per workgroup (relaxed / strict waits, constant strips of both parities, masked last
-// tile); 0 disables the persistent kernel
-int pw3_grid_cap(int num_cu) {
-    const char* e = getenv("SVHIP_PW3_CUS");
-    const int env = e ? atoi(e) : -1;
-    if (env == 0) return 1 << 30;
-    return env > 0 ? (env < num_cu ? env : num_cu) : num_cu;
+// developer option pw3_cus = n (GemmParams::pw3_cus, from the handle: SVHIP_PW3_CUS at svhip_create or svhip_set_option): launch at
+// most n workgroups, so that a small test problem walks several tiles per workgroup (relaxed / strict waits, constant strips of both
+// parities, masked last tile); 0 disables the persistent kernels
+int pw3_grid_cap(const GemmParams& p) {
+    if (p.pw3_cus == 0) return 1 << 30;
+    return p.pw3_cus > 0 ? (p.pw3_cus < p.num_cu ? p.pw3_cus : p.num_cu) : p.num_cu;
 }
 
 hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream) {
@@ -751,7 +749,7 @@ bool gemm_pw3x3_supported(const GemmParams& p) {
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024 || p.M <= 0 || p.Wrows < p.N) return false;
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
-    return ntiles > pw3_grid_cap(p.num_cu);
+    return ntiles > pw3_grid_cap(p);
 }
 
 // One step of a Res2Net chain on F32X3 handles (the R2 form): A = U_j (M, cin) S32, W = the step's conv weight (cin, 3 cin) S32
@@ -768,7 +766,7 @@ bool gemm_pw3r2_supported(const GemmParams& p) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.Y2) |
          reinterpret_cast<uintptr_t>(p.R) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
-    return (p.M + 255) / 256 > pw3_grid_cap(p.num_cu);
+    return (p.M + 255) / 256 > pw3_grid_cap(p);
 }
 
 hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream) {
@@ -776,7 +774,7 @@ hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream) {
     const int ntiles = (p.M + 255) / 256;
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_RELU, 0, true, true>), PW3_LDS)) return e;
-    const int cap = pw3_grid_cap(p.num_cu);
+    const int cap = pw3_grid_cap(p);
     hipLaunchKernelGGL((gemm_pw3_kernel<EPI_RELU, 0, true, true>), dim3(ntiles < cap ? ntiles : cap), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
 }
@@ -799,7 +797,7 @@ bool gemm_pw3cv_supported(const GemmParams& p) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
-    return ((p.M + 255) / 256) * (p.N / 256) > pw3_grid_cap(p.num_cu);
+    return ((p.M + 255) / 256) * (p.N / 256) > pw3_grid_cap(p);
 }
 
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream) {

@@ -82,6 +82,8 @@ struct GemmParams {
     void* side_b = nullptr;
     int side_lda = 0, side_ldb = 0, side_c = 0;
     int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
+    int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
+                                    // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
     int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
@@ -89,6 +91,7 @@ struct GemmParams {
     int taps = 1, dil = 1, cin = 0, pad_mode = 0;
     int act1 = 0, act2 = 0;
     int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
+    int f16 = 0;              // 16-bit compute only: operands and outputs are fp16 (SVHIP_F16 handles), not bf16
     int x3 = 0;               // fp32 operands only: products as three bf16 MFMAs on hi / lo-split fragments.  1: gemm_pw expects W as
                               // (hi bf16 << 16 | lo bf16) words (ConvLayer::Wsplit), the generic kernel splits true fp32 W itself;
                               // 2: A and W are both in the S32 split layout (gemm_pw3's X3 form, launch_gemm_pw3x3)
@@ -123,7 +126,7 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
 // SVHIP_PW3_CUS, which lets small test problems run more than one tile per workgroup)
 bool gemm_pw3_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream);
-int pw3_grid_cap(int num_cu);
+int pw3_grid_cap(const GemmParams& p);
 // the X3 form of the persistent kernel (x3 == 2): A (M, K) and W (N, K) in the S32 split layout (per row, per 32 k: 32 hi bf16 |
 // 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p);
@@ -179,6 +182,7 @@ struct FbankTables {           // device pointers, built once per handle
     int n_pairs = 9;                   // ceil(n_bins / 32) re/im tile pairs
     int n_q = 25;                      // win_length / 8
     int mel_max_bin = 256;             // highest bin with a non-zero mel weight
+    int force32 = 0;                   // developer option fbank32: the 32-frame kernel whatever the bank
     float preemph = 0.97f;
 };
 // wav (B, L) fp32 -> mel power (B, n_mels, T) fp32
@@ -195,7 +199,7 @@ hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, i
 // ---------------------------------------------------------------------------------------------
 // mean over the T rows of each utterance: X (B*T, ldx) cols [0,C) -> mean (B, C) fp32
 // (optional scratch of B * scratch_slices * C floats: long T with few channels is reduced in two stages)
-hipError_t launch_colmean(const void* X, bool bf16, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
+hipError_t launch_colmean(const void* X, int dt, int ldx, int B, int T, int C, float* mean, hipStream_t stream,
                           float* scratch = nullptr, int scratch_slices = 0);
 // mean and population std over T (two pass, clamp 1e-12 as ECAPA_TDNN.py:222-227): -> stats (B, 2C) = [mean | std]
 hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int C, float* stats, float eps, hipStream_t stream);
@@ -268,22 +272,23 @@ hipError_t launch_asp_x3(const AspX3Params& p, int B, hipStream_t stream);
 //  past its last tile's first sample)
 constexpr int RN_XN_TAIL = 512;
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn = nullptr, int Lp = 0,
-                              const float* gamma = nullptr, const float* beta = nullptr);
+                              const float* gamma = nullptr, const float* beta = nullptr, int xn_dt = DT_BF16);
 // LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
-                          const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
+                          const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,
                           hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr,
                           const void* xn = nullptr, int Lp = 0, int num_cu = 256);
-hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
+// (dt: DT_F32 / DT_BF16 / DT_F16 — the storage type of the activations)
+hipError_t launch_rn_bn_act(const void* x, void* y, int dt, const float* scale, const float* shift, int64_t rows, int C,
                             float slope, hipStream_t stream);
-hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream);
-hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
+hipError_t launch_rn_maxpool3(const void* x, void* y, int dt, int B, int Tin, int C, hipStream_t stream);
+hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alpha, const float* s, int B, int T, int C,
                                 hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
                                 void* pre = nullptr, float slope = 0.3f);
 // fused block tail (rawnet2.hip): [max_pool1d(3)] + AFMS + the next consumer's lrelu(bn(.)), one workgroup per utterance with the
 // pooled activation held in registers; rn_tail_supported says whether (Tn, C) fits (else the four separate passes run)
-bool rn_tail_supported(bool bf16, int Tn, int C);
-hipError_t launch_rn_tail(const void* x, void* y, void* pre, bool bf16, bool pool, const float* alpha, const float* WT, const float* bias,
+bool rn_tail_supported(int dt, int Tn, int C);
+hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
                           const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream);
 // Fused 128 -> 128 pooled RawNetBasicBlock (rn_block128.hip, bf16): previous block's AFMS gate on the way in, BN + LeakyReLU,
 // conv1 + BN + LeakyReLU, conv2 + identity shortcut, max_pool1d(3), per-tile column sums of the pooled output.
@@ -303,6 +308,7 @@ struct RnBlock128Params {
     int per_wg = 0, nseg = 0;            // filled by the launcher: items per workgroup, workgroups that can share an utterance
     unsigned long long* dbg = nullptr;   // tools/rb_bench: per-workgroup phase cycle totals (only read in -DSVHIP_GEMM_DEBUG builds)
     int debug = 0;                       // tools/rb_bench ablations (debug builds): 1 no fragment reads, 2 no MFMA, 4 no conversion, 8 no pool
+    int f16 = 0;                         // the 16-bit tensors (xin, W1, W2, opool) hold fp16, not bf16
 };
 int rn_block128_ntiles(int T);
 int rn_block128_nparts(int B, int T, int num_cu);
@@ -311,7 +317,7 @@ hipError_t launch_rn_block128(const RnBlock128Params& p, int num_cu, hipStream_t
 // AFMS gate from partial column sums: s (B, C) = sigmoid(fc(sum(part) / Tn)); part (B, nparts, C), WT = fc weight TRANSPOSED [C][C] fp32
 hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* WT, const float* bias, float* s,
                                hipStream_t stream);
-hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream);
+hipError_t launch_rn_attn_pool(const float* logits, const void* x, int dt, int B, int T, int C, float* out, hipStream_t stream);
 
 // synthetic waveforms from a counter-based RNG (synth.hip): out (B, L) fp32 = utterances [first_utt, first_utt + B) of the stream `seed`
 hipError_t launch_synth_wave(float* out, uint64_t seed, int64_t first_utt, int B, int L, hipStream_t stream);

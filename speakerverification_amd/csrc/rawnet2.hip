@@ -15,6 +15,8 @@
 //   rn_maxpool3   : max_pool1d(3) along frames
 //   rn_afms_apply : (x + alpha) * s[b, c]                                (AFMS, RawNet_baseline.py:66-67)
 //   rn_attn_pool  : softmax over frames, m = sum x w, s = sqrt(clamp(sum x^2 w - m^2, 1e-5))
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -24,8 +26,9 @@ namespace {
 
 // With `xn` the kernel also writes the LayerNorm output gamma * (x - mean) * inv + beta (RawNet_baseline.py:24) as bf16 into a
 // zero-tailed row of Lp samples: the bf16 sinc kernel stages its operand from it with LDS-DMA (no arithmetic in its tile loop).
+template <typename H>
 __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restrict__ x, int L, float* __restrict__ stats,
-                                                          bf16_t* __restrict__ xn, int Lp, const float* __restrict__ gamma,
+                                                          H* __restrict__ xn, int Lp, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta) {
     __shared__ float red[4];
     const int b = blockIdx.x;
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
     if (xn) {
         // copy 0: sample j at index j; copy 1: sample j + 1 at index j — so that every 2-sample LDS-DMA of the sinc kernel, for an
         // even or an odd shift, starts on a 4-byte boundary
-        bf16_t* __restrict__ o0 = xn + (int64_t)b * 2 * Lp;
-        bf16_t* __restrict__ o1 = o0 + Lp;
+        H* __restrict__ o0 = xn + (int64_t)b * 2 * Lp;
+        H* __restrict__ o1 = o0 + Lp;
         const bool vec = (L % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
         for (int j0 = threadIdx.x * 8; j0 < Lp; j0 += 256 * 8) {
             float v[9];
@@ -85,11 +88,11 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
                     v[e] = j < L ? gamma[j] * (p[j] - mean) * inv + beta[j] : 0.0f;
                 }
             }
-            bf16x8 a, c;
+            Vec16<H> a, c;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] = static_cast<bf16_t>(v[e]); c[e] = static_cast<bf16_t>(v[e + 1]); }
-            *reinterpret_cast<bf16x8*>(o0 + j0) = a;
-            *reinterpret_cast<bf16x8*>(o1 + j0) = c;
+            for (int e = 0; e < 8; ++e) { a.set(e, v[e]); c.set(e, v[e + 1]); }
+            *reinterpret_cast<Vec16<H>*>(o0 + j0) = a;
+            *reinterpret_cast<Vec16<H>*>(o1 + j0) = c;
         }
     }
 }
@@ -98,7 +101,7 @@ constexpr int SINC_PT = 64;                 // pooled frames per iteration
 constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 255 + 8, multiple of 8
 
 template <typename T> struct SincCfg;
-template <> struct SincCfg<bf16_t> {
+struct SincCfg16 {
     // Copy c starts at c * COPY_BYTES + 16 * ((COPY_SKEW >> 4c) & 15): start offsets (mod 256 bytes) found by search so that the
     // ds_read_b128 lane groups of the fragment pattern (positions 3 * frame + j: stride-3 rows across the 8 copies) spread over
     // the banks.  A uniform stride of 960 bytes cost one extra LDS cycle per lane group on average (PMC: bank-conflict cycles
@@ -111,6 +114,8 @@ template <> struct SincCfg<bf16_t> {
     static constexpr int BN_OFF = OUT_OFF + 2 * OUT_BYTES;     // first_bn scale[128], shift[128] (fp32)
     static constexpr int LDS = BN_OFF + 1024;
 };
+template <> struct SincCfg<bf16_t> : SincCfg16 {};
+template <> struct SincCfg<f16_t> : SincCfg16 {};
 template <> struct SincCfg<float> {
     static constexpr int COPY_BYTES = 0;
     static constexpr unsigned COPY_SKEW = 0;
@@ -128,9 +133,10 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                                                          const void* __restrict__ filt, const float* __restrict__ bn_scale,
                                                          const float* __restrict__ bn_shift, T* __restrict__ out, T* __restrict__ pre, const float* __restrict__ nscale,
                                                          const float* __restrict__ nshift, int L, int T1,
-                                                         int B, const bf16_t* __restrict__ xn, int Lp) {
+                                                         int B, const uint16_t* __restrict__ xn, int Lp) {
     typedef SincCfg<T> CF;
     constexpr bool BF = sizeof(T) == 2;
+    typedef typename std::conditional<BF, T, bf16_t>::type H;      // the 16-bit operand type (bf16 or fp16); unused on the fp32 path
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Persistent: the grid is two workgroups per CU, each owns a contiguous range of (utterance, tile) items and loads its filter
     // fragments ONCE (32 KiB per wave, every wave of every workgroup from the same 64 KiB table: with 4 tiles per workgroup and
@@ -187,12 +193,12 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         const int b = item / tiles_u, tpn = (item - b * tiles_u) * SINC_PT;
         // 4-byte DMAs (two samples per lane, LDS destination = wave-uniform base + 4 * lane): the source of an odd shift comes
         // from the second, one-sample-shifted copy of the waveform, so every source address is 4-byte aligned
-        const bf16_t* src0 = xn + (int64_t)b * 2 * Lp + 3 * tpn + 2 * lane;
+        const uint16_t* src0 = xn + (int64_t)b * 2 * Lp + 3 * tpn + 2 * lane;
         char* dst = smem + buf * CF::XLDS;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {                                // 8 copies x 4 segments of 128 samples = 32 wave-instructions, 8 per wave
             const int idx = wave + 4 * e, pc = idx >> 2, q = idx & 3;
-            const bf16_t* src = src0 + (pc & 1) * Lp + (pc & ~1) + q * 128;
+            const uint16_t* src = src0 + (pc & 1) * Lp + (pc & ~1) + q * 128;
             if (q * 128 + 2 * lane < SINC_SAMPLES)
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + pc * CF::COPY_BYTES + ((CF::COPY_SKEW >> (4 * pc)) & 15) * 16 + q * 256), 4, 0, 0);
         }
@@ -271,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base[j] + kk * 32);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[0][kk], xf, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[1][kk], xf, acc[1][j], 0, 0, 0);
+                    acc[0][j] = Half16<H>::mfma32(wfb[0][kk], xf, acc[0][j]);
+                    acc[1][j] = Half16<H>::mfma32(wfb[1][kk], xf, acc[1][j]);
                 }
             }
         } else {
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                     f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};
                     if (pre) { nsc = *reinterpret_cast<const f32x4*>(nscale + f); nsh = *reinterpret_cast<const f32x4*>(nshift + f); }
                     if (BF) {
-                        typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                        bf16x4 pk = {static_cast<bf16_t>(v[0]), static_cast<bf16_t>(v[1]), static_cast<bf16_t>(v[2]), static_cast<bf16_t>(v[3])};
+                        typedef H bf16x4 __attribute__((ext_vector_type(4)));
+                        bf16x4 pk = {static_cast<H>(v[0]), static_cast<H>(v[1]), static_cast<H>(v[2]), static_cast<H>(v[3])};
                         {   // 8-byte chunk c8 of row `row` lives at chunk c8 ^ (row & 31): the 32 rows of one store land on 32 banks
                             const int row = 32 * gw + fr_e, c8 = f >> 2;
                             *reinterpret_cast<bf16x4*>(otile + row * 256 + ((c8 ^ (row & 31)) << 3)) = pk;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                         if (pre) {
                             bf16x4 pp;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { const float t = fmaf(static_cast<float>(pk[e]), nsc[e], nsh[e]); pp[e] = static_cast<bf16_t>(t > 0.0f ? t : 0.3f * t); }
+                            for (int e = 0; e < 4; ++e) { const float t = fmaf(static_cast<float>(pk[e]), nsc[e], nsh[e]); pp[e] = static_cast<H>(t > 0.0f ? t : 0.3f * t); }
                             *reinterpret_cast<bf16x4*>(pre + oi) = pp;
                         }
                     } else {
@@ -543,15 +549,17 @@ inline int grid_for(int64_t items) {
 }  // namespace
 
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn, int Lp, const float* gamma,
-                              const float* beta) {
+                              const float* beta, int xn_dt) {
     if (xn && (Lp < L + RN_XN_TAIL || Lp % 64 != 0 || !gamma || !beta)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rn_ln_stats_kernel, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<bf16_t*>(xn), Lp, gamma, beta);
+    if (xn_dt == DT_F16) hipLaunchKernelGGL(rn_ln_stats_kernel<f16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
+    else hipLaunchKernelGGL(rn_ln_stats_kernel<bf16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<bf16_t*>(xn), Lp, gamma, beta);
     return hipGetLastError();
 }
 
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
-                          const float* bn_scale, const float* bn_shift, void* out, bool bf16, int B, int L, int T1,
+                          const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,
                           hipStream_t stream, void* pre, const float* next_scale, const float* next_shift, const void* xn, int Lp, int num_cu) {
+    const bool bf16 = dt != DT_F32;
     if (B <= 0) return hipErrorInvalidValue;
     if (T1 != (L - 250) / 3 || L < 251 + 3 || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     if (bf16 && (!xn || Lp < L + RN_XN_TAIL || Lp % 64 != 0)) return hipErrorInvalidValue;          // the bf16 kernel stages from the normalised copy
@@ -559,49 +567,59 @@ hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gam
     if (items >= (1ll << 31)) return hipErrorInvalidValue;
     const int slots = 2 * (num_cu > 0 ? num_cu : 256);               // two workgroups per CU (256 VGPRs per lane, 47 KiB of LDS each)
     dim3 grid((unsigned)(items < slots ? items : slots)), block(256);
-    if (bf16)
+    if (dt == DT_F16)
+        hipLaunchKernelGGL(rn_sinc_kernel<f16_t>, grid, block, SincCfg<f16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
+                           bn_shift, reinterpret_cast<f16_t*>(out), reinterpret_cast<f16_t*>(pre), next_scale, next_shift, L, T1, B,
+                           reinterpret_cast<const uint16_t*>(xn), Lp);
+    else if (bf16)
         hipLaunchKernelGGL(rn_sinc_kernel<bf16_t>, grid, block, SincCfg<bf16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
                            bn_shift, reinterpret_cast<bf16_t*>(out), reinterpret_cast<bf16_t*>(pre), next_scale, next_shift, L, T1, B,
-                           reinterpret_cast<const bf16_t*>(xn), Lp);
+                           reinterpret_cast<const uint16_t*>(xn), Lp);
     else
         hipLaunchKernelGGL(rn_sinc_kernel<float>, grid, block, SincCfg<float>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
                            bn_shift, reinterpret_cast<float*>(out), reinterpret_cast<float*>(pre), next_scale, next_shift, L, T1, B,
-                           static_cast<const bf16_t*>(nullptr), 0);
+                           static_cast<const uint16_t*>(nullptr), 0);
     return hipGetLastError();
 }
 
-hipError_t launch_rn_bn_act(const void* x, void* y, bool bf16, const float* scale, const float* shift, int64_t rows, int C,
+hipError_t launch_rn_bn_act(const void* x, void* y, int dt, const float* scale, const float* shift, int64_t rows, int C,
                             float slope, hipStream_t stream) {
-    const int vec = bf16 ? 8 : 4;
+    const bool bf16 = dt == DT_BF16;
+    const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec) return hipErrorInvalidValue;
     const int64_t chunks = rows * (C / vec);
-    if (bf16) hipLaunchKernelGGL(rn_bn_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, scale, shift, C, slope, chunks);
+    if (dt == DT_F16) hipLaunchKernelGGL(rn_bn_act_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, scale, shift, C, slope, chunks);
+    else if (bf16) hipLaunchKernelGGL(rn_bn_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, scale, shift, C, slope, chunks);
     else hipLaunchKernelGGL(rn_bn_act_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, scale, shift, C, slope, chunks);
     return hipGetLastError();
 }
 
-hipError_t launch_rn_maxpool3(const void* x, void* y, bool bf16, int B, int Tin, int C, hipStream_t stream) {
-    const int vec = bf16 ? 8 : 4;
+hipError_t launch_rn_maxpool3(const void* x, void* y, int dt, int B, int Tin, int C, hipStream_t stream) {
+    const bool bf16 = dt == DT_BF16;
+    const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec) return hipErrorInvalidValue;
     const int Tout = Tin / 3;
     const int64_t chunks = (int64_t)B * Tout * (C / vec);
-    if (bf16) hipLaunchKernelGGL(rn_maxpool3_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, Tin, Tout, C, chunks);
+    if (dt == DT_F16) hipLaunchKernelGGL(rn_maxpool3_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, Tin, Tout, C, chunks);
+    else if (bf16) hipLaunchKernelGGL(rn_maxpool3_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, Tin, Tout, C, chunks);
     else hipLaunchKernelGGL(rn_maxpool3_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, Tin, Tout, C, chunks);
     return hipGetLastError();
 }
 
-hipError_t launch_rn_afms_apply(const void* x, void* y, bool bf16, const float* alpha, const float* s, int B, int T, int C,
+hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alpha, const float* s, int B, int T, int C,
                                 hipStream_t stream, const float* next_scale, const float* next_shift, void* pre, float slope) {
-    const int vec = bf16 ? 8 : 4;
+    const bool bf16 = dt == DT_BF16;
+    const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     const int64_t chunks = (int64_t)B * T * (C / vec);
-    if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (bf16_t*)pre, slope);
+    if (dt == DT_F16) hipLaunchKernelGGL(rn_afms_apply_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (f16_t*)pre, slope);
+    else if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (bf16_t*)pre, slope);
     else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks, next_scale, next_shift, (float*)pre, slope);
     return hipGetLastError();
 }
 
-bool rn_tail_supported(bool bf16, int Tn, int C) {
-    const int vec = bf16 ? 8 : 4;
+bool rn_tail_supported(int dt, int Tn, int C) {
+    const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec || C % 4 || C > 512 || Tn <= 0) return false;
     const int cpr = C / vec, n4 = C / 4;
     if (TAIL_THREADS % cpr || TAIL_THREADS % n4 || n4 > TAIL_THREADS || C % (TAIL_THREADS / n4)) return false;
@@ -609,22 +627,24 @@ bool rn_tail_supported(bool bf16, int Tn, int C) {
     return (int64_t)Tn * cpr <= (int64_t)TAIL_NCH * TAIL_THREADS;                                // the utterance fits the registers
 }
 
-hipError_t launch_rn_tail(const void* x, void* y, void* pre, bool bf16, bool pool, const float* alpha, const float* WT, const float* bias,
+hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
                           const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream) {
     const int Tn = pool ? Tin / 3 : Tin;
-    if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(bf16, Tn, C) || (pre && (!next_scale || !next_shift)))
+    if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(dt, Tn, C) || (pre && (!next_scale || !next_shift)))
         return hipErrorInvalidValue;
 #define SV_TAIL(TT, P) hipLaunchKernelGGL((rn_tail_kernel<TT, P>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
                                           alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope)
-    if (bf16) { if (pool) SV_TAIL(bf16_t, true); else SV_TAIL(bf16_t, false); }
+    if (dt == DT_F16) { if (pool) SV_TAIL(f16_t, true); else SV_TAIL(f16_t, false); }
+    else if (dt == DT_BF16) { if (pool) SV_TAIL(bf16_t, true); else SV_TAIL(bf16_t, false); }
     else { if (pool) SV_TAIL(float, true); else SV_TAIL(float, false); }
 #undef SV_TAIL
     return hipGetLastError();
 }
 
-hipError_t launch_rn_attn_pool(const float* logits, const void* x, bool bf16, int B, int T, int C, float* out, hipStream_t stream) {
+hipError_t launch_rn_attn_pool(const float* logits, const void* x, int dt, int B, int T, int C, float* out, hipStream_t stream) {
     const int n = B * C;
-    if (bf16) hipLaunchKernelGGL(rn_attn_pool_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const bf16_t*)x, T, C, out, B);
+    if (dt == DT_F16) hipLaunchKernelGGL(rn_attn_pool_kernel<f16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const f16_t*)x, T, C, out, B);
+    else if (dt == DT_BF16) hipLaunchKernelGGL(rn_attn_pool_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const bf16_t*)x, T, C, out, B);
     else hipLaunchKernelGGL(rn_attn_pool_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, stream, logits, (const float*)x, T, C, out, B);
     return hipGetLastError();
 }

@@ -69,17 +69,11 @@ __device__ __forceinline__ float lrelu03(float t) { return fmaxf(t, 0.3f * t); }
 #define RB_SWZ(r) (((r) & 7) << 1)
 template <int N> struct RbInt { static constexpr int value = N; };
 
-// two bf16 in one dword: unpack to fp32 (exact), pack with round-to-nearest-even (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t bf_pack(float a, float b) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
-    const bf16x2_ r = __builtin_convertvector(f32x2_{a, b}, bf16x2_);
-    uint32_t u;
-    __builtin_memcpy(&u, &r, 4);
-    return u;
-}
+// two 16-bit values in one dword: unpack to fp32 (exact), pack with round-to-nearest-even — Half16<H>::lo / hi / pack2 (common.h),
+// H = bf16_t or f16_t (the kernel moves raw 16-byte chunks; only these conversions and the MFMA opcode know the type)
+#define bf_lo Half16<H>::lo
+#define bf_hi Half16<H>::hi
+#define bf_pack Half16<H>::pack2
 
 // The two wave groups run disjoint code in one loop; whatever the compiler hoists out of that loop (LDS addresses, per-lane
 // constants of BOTH roles) stays live across everything, pushed this kernel over its 256 registers, and every use of a spilled
@@ -90,7 +84,7 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 // out[ch][frame] += W[ch][tap*128 + c] * src[frame + tap][c] for 5 frame blocks x this wave's 32 channels.  K runs in 12 steps
 // of 32 (tap, 32 channels); the activation fragments of step s + 1 are requested while the 10 MFMAs of step s issue.
 // INIT: the accumulators start from a bf16 tile (the identity shortcut of conv2: o = y + conv2(h)) instead of zero.
-template <bool INIT>
+template <bool INIT, typename H>
 __device__ __forceinline__ void conv_k3(const char* src, const bf16x8 (&w)[2][12], f32x4 (&acc)[RB_FB][2], int r16, int q4,
                                         const char* init, int w4, int dbg = 0) {
     bf16x8 xb[3][RB_FB];
@@ -145,7 +139,7 @@ __device__ __forceinline__ void conv_k3(const char* src, const bf16x8 (&w)[2][12
         for (int fb = 0; fb < RB_FB; ++fb)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                acc[fb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][ks], xb[ks % 3][fb], acc[fb][cb], 0, 0, 0);
+                acc[fb][cb] = Half16<H>::mfma16(w[cb][ks], xb[ks % 3][fb], acc[fb][cb]);
         // inside the fenced region: two MFMAs, then one of the reads (for K step ks + 2) in their shadow — issued back to back the five
         // reads hold the wave's issue port for ~65 cycles per step that no MFMA covers (measured: +0.8k cycles per convolution)
 #pragma unroll
@@ -158,7 +152,7 @@ __device__ __forceinline__ void conv_k3(const char* src, const bf16x8 (&w)[2][12
     __builtin_amdgcn_s_setprio(0);
 }
 
-template <bool GATE>
+template <bool GATE, typename H>
 __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -264,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
                     sh2[cb] = *reinterpret_cast<const f32x4*>(smem + RB_CST + (4 * 128 + w4 * 32 + cb * 16 + 4 * q4) * 4);
                 }
                 f32x4 acc[RB_FB][2];
-                conv_k3<false>(smem + RB_P + (r & 1) * RB_RAWK * 1024, wf, acc, r16, q4, nullptr, w4, p.debug);
+                conv_k3<false, H>(smem + RB_P + (r & 1) * RB_RAWK * 1024, wf, acc, r16, q4, nullptr, w4, p.debug);
                 RB_STAMP(4)
                 char* hbuf = smem + RB_H + (r & 1) * RB_HR * 256;
                 const bool edge = (t0 == 0) || (t0 + RB_TT + 2 > p.T);            // workgroup-uniform
@@ -293,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
             const int k = r - 1;
             const int r16 = opaque(r16_), q4 = opaque(q4_);
             f32x4 acc[RB_FB][2];
-            conv_k3<true>(smem + RB_H + (k & 1) * RB_HR * 256, wf, acc, r16, q4, smem + RB_Y + (k & 1) * RB_YR * 256, w4, p.debug);
+            conv_k3<true, H>(smem + RB_H + (k & 1) * RB_HR * 256, wf, acc, r16, q4, smem + RB_Y + (k & 1) * RB_YR * 256, w4, p.debug);
             RB_STAMP(4)
 #pragma unroll
             for (int fb = 0; fb < RB_FB; ++fb) {
@@ -415,6 +409,9 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
 #endif
 #undef RB_STAMP
 }
+#undef bf_lo
+#undef bf_hi
+#undef bf_pack
 
 // AFMS gate: s[b, n] = sigmoid(bias[n] + sum_c W[n, c] * mean[b, c]), mean = (sum of the partial column sums) / Tn
 // (RawNet_baseline.py:64-66): a (B x C) x (C x C) product too small for the GEMM kernels and, done one utterance per workgroup,
@@ -494,15 +491,15 @@ hipError_t launch_rn_block128(const RnBlock128Params& p_in, int num_cu, hipStrea
     rn_block128_split(p.B, p.T, num_cu, &p.per_wg, &p.nseg, &grid);
     // the partial rows of segments an utterance does not have stay zero
     if (hipError_t e = hipMemsetAsync(p.colsum, 0, (size_t)p.B * p.nseg * 4 * 128 * sizeof(float), stream)) return e;
-    if (p.gate) {
-        static DeviceOnce attr;
-        if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(rn_block128_kernel<true>), RB_LDS)) return e;
-        hipLaunchKernelGGL(rn_block128_kernel<true>, dim3(grid), dim3(512), RB_LDS, stream, p);
-    } else {
-        static DeviceOnce attr;
-        if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(rn_block128_kernel<false>), RB_LDS)) return e;
-        hipLaunchKernelGGL(rn_block128_kernel<false>, dim3(grid), dim3(512), RB_LDS, stream, p);
+#define SV_RB(G, HH)                                                                                                       \
+    {                                                                                                                      \
+        static DeviceOnce attr;                                                                                            \
+        if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(rn_block128_kernel<G, HH>), RB_LDS)) return e; \
+        hipLaunchKernelGGL((rn_block128_kernel<G, HH>), dim3(grid), dim3(512), RB_LDS, stream, p);                         \
     }
+    if (p.f16) { if (p.gate) SV_RB(true, f16_t) else SV_RB(false, f16_t) }
+    else { if (p.gate) SV_RB(true, bf16_t) else SV_RB(false, bf16_t) }
+#undef SV_RB
     return hipGetLastError();
 }
 

@@ -86,7 +86,8 @@ class Engine:
         self.lib = _lib.load()
         cfg = _lib.default_config()
         cfg.model = {"ecapa": _lib.MODEL_ECAPA, "rawnet2": _lib.MODEL_RAWNET2, "none": _lib.MODEL_NONE}[model]
-        cfg.compute = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16, "f32x3": _lib.F32X3, "bf16x3": _lib.F32X3}[compute]
+        cfg.compute = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16, "f32x3": _lib.F32X3, "bf16x3": _lib.F32X3,
+                       "f16": _lib.F16, "fp16": _lib.F16}[compute]
         cfg.device = int(device)
         cfg.channels = int(channels)
         cfg.n_mels = int(n_mels)
@@ -102,7 +103,7 @@ class Engine:
         cfg.stream = C.c_void_p(int(stream)) if stream else None
         self.cfg = cfg
         self.model = model
-        self.compute = {_lib.BF16: "bf16", _lib.F32X3: "f32x3"}.get(cfg.compute, "f32")
+        self.compute = {_lib.BF16: "bf16", _lib.F32X3: "f32x3", _lib.F16: "f16"}.get(cfg.compute, "f32")
         self.max_batch = cfg.max_batch
         self.samples = cfg.samples
         self.frames = cfg.samples // cfg.hop_length + 1
@@ -453,6 +454,15 @@ class Engine:
         out = np.empty(n.value, dtype=np.float32)
         self._ck(self.lib.svhip_get_stage(self.h, name.encode(), out.ctypes.data, C.byref(n)))
         return out
+
+    def set_option(self, name: str, value: int):
+        """Developer / test switch of this handle (``svhip_set_option``; the SVHIP_<NAME> environment variables are only the
+        defaults a handle is created with)."""
+        self._ck(self.lib.svhip_set_option(self.h, name.encode(), int(value)))
+
+    def trim_scratch(self):
+        """Free the scoring / metrics scratch the handle has grown (``svhip_trim_scratch``)."""
+        self._ck(self.lib.svhip_trim_scratch(self.h))
 
     def profile(self, on=True, only=None):
         """HIP events around every kernel launch (``only``: just the launches with that label — fewer events in the stream)."""

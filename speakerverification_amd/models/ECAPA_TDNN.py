@@ -44,6 +44,7 @@ class ECAPA_TDNN(HipModule):
         features = str(kwargs.get("features", "melspectrogram")).strip()
         self.log_input = features == "melspectrogram"                                          # ECAPA_TDNN.py:473
         compute = compute or kwargs.get("hip_compute", "f32")
+        compute = {"half": "bf16"}.get(compute, compute)        # "half" = each model's own 16-bit mode (ECAPA: bf16, RawNet2: f16)
         hop = kwargs.get("hop_length", 80)
         self._hop = hop
         # the mel front-end of the fused waveform path takes the same keywords the reference's feature factory reads

@@ -25,7 +25,10 @@ class RawNet2(HipModule):
         if int(audio_spec["sample_rate"]) != 16000:
             raise NotImplementedError("the sinc front-end is built for sample_rate 16000 (RawNet2_custom.py:55-63)")
         self.nb_samp = int(audio_spec["sentence_len"] * audio_spec["sample_rate"])      # LayerNorm(nb_samp), :58-60
+        # hip_compute: "f32" (exact fp32 MFMA) | "f32x3" | "f16" (fp16 storage + fp16 MFMA: RawNet2's fast mode) | "bf16" (the same
+        # kernels on bf16: range-safe, but RawNet2 loses two digits to bf16 weight rounding) | "half" = this model's 16-bit mode (f16)
         compute = compute or kwargs.get("hip_compute", "f32")
+        compute = {"half": "f16", "fp16": "f16"}.get(compute, compute)
         max_batch = int(max_batch or kwargs.get("embed_batch", 256))
         super().__init__(synth.rawnet2_param_spec(nOut=nOut, nb_samp=self.nb_samp, att_dim=att_dim),
                          dict(embed_dim=nOut), device=device if device is not None else kwargs.get("device"),

@@ -84,15 +84,15 @@ def test_fbank_bf16x3_split_path(kind):
 @pytest.mark.parametrize("L", [32000, 512, 5200, 10320, 15439])
 def test_fbank_64_frame_kernel_equals_the_32_frame_kernel(monkeypatch, compute, L):
     """the 64-frame workgroup (one bin pair per wave, basis streamed once per 64 frames) against the 32-frame kernel it replaced
-    (SVHIP_FBANK32=1), on lengths whose last tile holds one frame tile, two, or a single frame: the exact-fp32 form multiplies the
+    (option fbank32), on lengths whose last tile holds one frame tile, two, or a single frame: the exact-fp32 form multiplies the
     same taps in the same order and must agree BIT FOR BIT; the split form differs only in |X|^2 = re^2 + im^2 vs sqrt-then-square."""
     eng = Engine(model="none", compute=compute, max_batch=5, samples=L)
     rng = np.random.default_rng(L)
     wav = (rng.standard_normal((5, L)) * 0.1).astype(np.float32)
     new = eng.fbank(wav)
-    monkeypatch.setenv("SVHIP_FBANK32", "1")
+    eng.set_option("fbank32", 1)
     old = eng.fbank(wav)
-    monkeypatch.delenv("SVHIP_FBANK32")
+    eng.set_option("fbank32", 0)
     assert new.shape == old.shape and np.isfinite(new).all()
     if compute == "f32":
         np.testing.assert_array_equal(new, old)

@@ -76,7 +76,7 @@ def test_scaling_and_silence(big):
 @pytest.fixture(scope="module")
 def big_rn():
     sd = synth.synth_state_dict(synth.rawnet2_param_spec(), seed=1)
-    eng = Engine(model="rawnet2", compute="bf16", embed_dim=320, max_batch=256)
+    eng = Engine(model="rawnet2", compute="f16", embed_dim=320, max_batch=256)
     eng.load_state_dict(sd)
     eng.finalize()
     wav = synth.synth_waveforms(256, 32000, seed=20220830)
@@ -104,9 +104,9 @@ def test_rawnet2_full_batch_properties(big_rn):
     ref = f32.embed_wave(wav[:16])
     f32.close()
     c = cos_rows(a[:16], ref)
-    print("rawnet2 bf16 B=256 vs f32: cos", c.min(), "max err / scale", np.abs(a[:16] - ref).max() / np.abs(ref).max())
-    assert c.min() >= 0.99
-    assert np.abs(a[:16] - ref).max() <= 0.15 * np.abs(ref).max()
+    print("rawnet2 f16 B=256 vs f32: cos", c.min(), "max err / scale", np.abs(a[:16] - ref).max() / np.abs(ref).max())
+    assert c.min() >= 0.999                                       # the 16-bit bars of ECAPA's bf16 mode
+    assert np.abs(a[:16] - ref).max() <= 0.03 * np.abs(ref).max()
 
 
 def test_bench_shard_path_at_world_one(capsys):

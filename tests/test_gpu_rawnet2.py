@@ -39,7 +39,29 @@ def test_rawnet2_fp32_matches_reference(golden_dir, compute):
     assert m(x[:1]).shape == (320,)
 
 
-def test_rawnet2_bf16_close(golden_dir):
+def test_rawnet2_f16_close(golden_dir):
+    """RawNet2's 16-bit mode is fp16 (SVHIP_F16, hip_compute='f16' / 'half'): held to the bars of ECAPA's bf16 mode — cosine >= 0.999 to
+    the reference's fp32 embedding and max error <= 3 % of the embedding scale.  Why not bf16: tests/analysis/rn_bf16_sites.py
+    (a CPU restatement with one storage point rounded at a time) shows that the bf16 rounding of the conv WEIGHTS alone — layer1.0's
+    above all — moves this fixture's second utterance to cosine 0.994 (9 % of the scale), more than every bf16 activation together
+    (0.9995); fp16 has the same MFMA rate and three more mantissa bits."""
+    g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
+    m = make("f16", int(g["seed_w"]))
+    x = synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"]))
+    out = m(x)
+    ref = g["out"]
+    cos = np.sum(out * ref, axis=1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+    rel = float(np.abs(out - ref).max() / np.abs(ref).max())
+    print("rawnet2 f16 rel", rel, "cos", cos)
+    assert rel <= 0.03 and float(cos.min()) >= 0.999
+    assert make("half", int(g["seed_w"]))._compute == "f16"           # "half" = the model's own 16-bit mode
+
+
+def test_rawnet2_bf16_mode_is_the_range_safe_fallback(golden_dir):
+    """The same kernels on bf16 stay selectable (hip_compute='bf16': bf16's exponent range for checkpoints whose activations could
+    pass fp16's 65504).  Its stated tolerance is the loose one its arithmetic supports on this un-normalised residual stack:
+    cosine >= 0.99 and max error <= 15 % of the embedding scale (the CPU restatement of the same storage points predicts
+    0.9945 / 9.1 % on this fixture, and that is what the kernels give)."""
     g = np.load(os.path.join(golden_dir, "rawnet2.npz"))
     m = make("bf16", int(g["seed_w"]))
     x = synth.synth_waveforms(int(g["B"]), 32000, seed=int(g["seed_x"]))
@@ -48,9 +70,7 @@ def test_rawnet2_bf16_close(golden_dir):
     cos = np.sum(out * ref, axis=1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
     rel = float(np.abs(out - ref).max() / np.abs(ref).max())
     print("rawnet2 bf16 rel", rel, "cos", cos)
-    # bf16 storage through 8 un-normalised residual blocks + a bf16 sinc front-end: stated tolerance is
-    # cosine >= 0.99 to the fp32 reference embedding and max error <= 15 % of the embedding scale
-    assert rel <= 0.15 and float(cos.min()) >= 0.994          # (pinned just under the measured values: 0.99965 / 0.99461)
+    assert rel <= 0.15 and float(cos.min()) >= 0.99
 
 
 def test_rawnet2_rejects_other_lengths():
@@ -65,7 +85,7 @@ def test_rawnet2_batch_sizes(B):
     sd = synth.synth_state_dict(synth.rawnet2_param_spec(), seed=1)
     wav = synth.synth_waveforms(B, 32000, seed=3)
     outs = {}
-    for compute in ("f32", "bf16"):
+    for compute in ("f32", "bf16", "f16"):
         eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B)
         eng.load_state_dict(sd)
         eng.finalize()
@@ -74,20 +94,22 @@ def test_rawnet2_batch_sizes(B):
             one = eng.embed_wave(wav[:1]).reshape(1, -1)
             assert float(np.abs(one - outs["f32"][:1]).max()) <= 1e-4 * max(1.0, float(np.abs(one).max()))
         eng.close()
-    a, b = outs["f32"], outs["bf16"]
-    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-    assert np.isfinite(b).all() and cos.min() >= 0.99, cos
+    for mode, bar in (("bf16", 0.99), ("f16", 0.999)):
+        a, b = outs["f32"], outs[mode]
+        cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        assert np.isfinite(b).all() and cos.min() >= bar, (mode, cos)
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("L,B", [(8000, 5), (24000, 3), (40000, 2), (32000, 40), (50000, 2)])
-def test_fused_blocks_other_geometries(L, B, monkeypatch):
+def test_fused_blocks_other_geometries(L, B, half, monkeypatch):
     """csrc/rn_block128.hip (the fused 128-channel residual blocks) on other utterance lengths / batch sizes: tile counts that do
     not divide, several utterances per workgroup, short last tiles — against the unfused kernel sequence (same bf16 storage
     points, so the two agree to bf16 round-off) and the fp32 engine."""
     sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=2)
     wav = synth.synth_waveforms(B, L, seed=5)
     outs = {}
-    for name, compute, unfused in (("f32", "f32", False), ("unfused", "bf16", True), ("fused", "bf16", False)):
+    for name, compute, unfused in (("f32", "f32", False), ("unfused", half, True), ("fused", half, False)):
         if unfused:
             monkeypatch.setenv("SVHIP_RN_UNFUSED", "1")
         else:
@@ -138,36 +160,38 @@ def test_fused_tail_fp32_matches_separate_passes(L, B, monkeypatch):
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("L", [16001, 20003])
-def test_bf16_sample_counts_that_are_not_a_multiple_of_8(L):
+def test_bf16_sample_counts_that_are_not_a_multiple_of_8(L, half):
     """The bf16 sinc kernel stages its operand by LDS-DMA from the pre-normalised bf16 waveform (two zero-tailed copies one sample
     apart); utterance lengths that are not a multiple of 8 take the scalar branch of the pass that writes them."""
     B = 3
     sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=9)
     wav = synth.synth_waveforms(B, L, seed=10)
     outs = {}
-    for compute in ("f32", "bf16"):
+    for compute in ("f32", half):
         eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L)
         eng.load_state_dict(sd)
         eng.finalize()
         outs[compute] = eng.embed_wave(wav).reshape(B, -1)
         eng.close()
-    a, b = outs["f32"], outs["bf16"]
+    a, b = outs["f32"], outs[half]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.isfinite(b).all() and cos.min() >= 0.99, cos
 
 
-def _ulps_bf16(a, b):
-    """|a - b| in units of the bf16 spacing (8 significant bits) at the scale of the element's ROW (one frame, 128 channels): the
+def _ulps_bf16(a, b, bits=8):
+    """|a - b| in units of the 16-bit type's spacing (bf16: 8 significant bits, fp16: 11) at the scale of the element's ROW (one frame, 128 channels): the
     tensor is lrelu(bn(x)), so an element may sit at a zero crossing where its own magnitude says nothing about the rounding
     of the x it came from"""
     m = np.maximum(np.abs(a), np.abs(b)).max(axis=-1, keepdims=True)
-    ulp = np.exp2(np.floor(np.log2(np.maximum(m, 1e-30))) - 7)
+    ulp = np.exp2(np.floor(np.log2(np.maximum(m, 1e-30))) - (bits - 1))
     return np.abs(a - b) / ulp
 
 
+@pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("L,B", [(32000, 3), (32000, 40), (20000, 7)])
-def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor(L, B, monkeypatch):
+def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor(L, B, half, monkeypatch):
     """the embedding-level bars (cosine >= 0.9, 3 % of the scale) could hide a wrong halo row or a mis-swizzled channel
     block in one tile.  SVHIP_RN_SNAP=2 keeps lrelu(bn1(x)) as block 2 reads it — the first tensor that both the fused
     128-channel kernels (rn_block128 x 2 + gates) and the separate kernel sequence store — and the two must agree element for
@@ -183,7 +207,7 @@ def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor
             monkeypatch.setenv("SVHIP_RN_UNFUSED", "1")
         else:
             monkeypatch.delenv("SVHIP_RN_UNFUSED", raising=False)
-        eng = Engine(model="rawnet2", compute="bf16", embed_dim=320, max_batch=B, samples=L)
+        eng = Engine(model="rawnet2", compute=half, embed_dim=320, max_batch=B, samples=L)
         eng.load_state_dict(sd)
         eng.finalize()
         eng.profile(True)
@@ -195,9 +219,9 @@ def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor
         eng.close()
     a, b = snaps["fused"], snaps["unfused"]
     assert a.shape == b.shape and a.shape[1] == ((L - 250) // 3) // 9
-    u = _ulps_bf16(a, b)
+    u = _ulps_bf16(a, b, 8 if half == "bf16" else 11)
     frac = float((a != b).mean())
-    print(f"L={L} B={B}: {frac:.4%} of the elements differ, max {u.max():.2f} bf16 ulps")
+    print(f"L={L} B={B} {half}: {frac:.4%} of the elements differ, max {u.max():.2f} ulps")
     assert float(u.max()) <= 2.0, (float(u.max()), np.unravel_index(u.argmax(), u.shape))
     assert frac <= 0.05
     # every frame region is covered by the comparison: first / last frames of the first and last utterance are non-trivial
@@ -206,7 +230,7 @@ def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor
             assert np.abs(b[bi, t]).max() > 0
 
 
-@pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "bf16", 50, 3),
+@pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "f16", 50, 3),
                                                    ("ecapa", "bf16", 64, 2), ("ecapa", "f32", 70, 2)])
 def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, lanes, monkeypatch):
     """SVHIP_LANES slices a batch over up to four streams (offsets into every per-utterance workspace buffer, lane

@@ -241,11 +241,9 @@ def test_fused_asnorm_at_scale():
     rmu, rsd = o_scoring.asnorm_stats(E[idx].cpu().numpy(), cohort.cpu().numpy(), top)
     assert float(np.abs(mu[idx].cpu().numpy() - rmu).max()) <= 1e-6
     assert float(np.abs(sd[idx].cpu().numpy() - rsd).max() / rsd.min()) <= 1e-4
-    os.environ["SVHIP_ASNORM_SLAB"] = "1"
-    try:
-        mu2, sd2 = eng.asnorm_stats(E[:50_000], cohort, top)
-    finally:
-        del os.environ["SVHIP_ASNORM_SLAB"]
+    eng.set_option("asnorm_slab", 1)            # (the environment is only read when a handle is created)
+    mu2, sd2 = eng.asnorm_stats(E[:50_000], cohort, top)
+    eng.set_option("asnorm_slab", 0)
     assert eng.asnorm_last_fallback == -1
     assert float((mu2 - mu[:50_000]).abs().max()) <= 1e-6 and float((sd2 - sd[:50_000]).abs().max()) <= 1e-6
     eng.close()
@@ -285,7 +283,7 @@ def test_whole_trial_scoring_modes(eng, n_files, n_crops, D, P):
 def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
     """D = 192 runs the fused AS-norm kernel on SIX bf16 MFMAs per product block (every fp32 value split exactly into three bf16
     parts; the three smallest of the nine partial products, <= 2^-26 relative, dropped): scores to fp32 rounding.  Against the
-    exact-fp32-MFMA form of the same kernel (SVHIP_ASNORM_F32MFMA=1) and against the float64 oracle, on a cohort with ties and a
+    exact-fp32-MFMA form of the same kernel (option asnorm_f32mfma) and against the float64 oracle, on a cohort with ties and a
     ragged last block; same bars as the fp32 form."""
     eng = Engine(model="none", max_batch=1)
     rng = np.random.Generator(np.random.PCG64(606))
@@ -297,9 +295,9 @@ def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
     cohort[7] = cohort[9]
     mu6, sd6 = eng.asnorm_stats(E, cohort, top)
     assert eng.asnorm_last_fallback == 0
-    monkeypatch.setenv("SVHIP_ASNORM_F32MFMA", "1")
+    eng.set_option("asnorm_f32mfma", 1)
     mu1, sd1 = eng.asnorm_stats(E, cohort, top)
-    monkeypatch.delenv("SVHIP_ASNORM_F32MFMA")
+    eng.set_option("asnorm_f32mfma", 0)
     assert eng.asnorm_last_fallback == 0
     rmu, rsd = o_scoring.asnorm_stats(E, cohort, top)
     print("x6 vs f64 oracle: mu", float(np.abs(mu6 - rmu).max()), "sd rel", float((np.abs(sd6 - rsd) / rsd).max()),
