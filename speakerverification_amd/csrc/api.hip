@@ -133,6 +133,9 @@ struct svhip_handle {
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
+    float *d_ones = nullptr, *d_zeros = nullptr;      // 4096 ones / zeros: stand-ins for absent per-channel vectors (GemmParams::ones / zeros)
+    size_t rn_buf_bytes = 0;      // RawNet2: payload bytes of each activation buffer; a 256-byte zero tail follows (the zero page of the
+                                  // persistent conv-gather kernel must sit behind its A operand, within 4 GiB)
     void* s32_buf = nullptr;      // SVHIP_F32X3: the A operand of the current big GEMM in the S32 split layout (M x 3C x 4 bytes)
     void *side_a = nullptr, *side_b = nullptr;      // pending S32 side outputs of the next conv_gemm (GemmParams::side_*), consumed by it
     int side_lda = 0, side_ldb = 0, side_c = 0;
@@ -774,14 +777,21 @@ int alloc_workspace(svhip_handle* h) {
     if ((rc = dev_alloc(h, &h->d_pstats, B * c.n_mels * 2))) return rc;
     if ((rc = dev_alloc(h, &h->d_zero, 64))) return rc;
     SV_HIP(h, hipMemset(h->d_zero, 0, 256));
+    {
+        std::vector<float> one(4096, 1.0f), zero(4096, 0.0f);
+        if ((rc = dev_upload(h, &h->d_ones, one))) return rc;
+        if ((rc = dev_upload(h, &h->d_zeros, zero))) return rc;
+    }
     if ((rc = dev_alloc(h, &h->d_emb, B * (size_t)c.embed_dim))) return rc;
     if (c.model == SVHIP_MODEL_RAWNET2) {
         h->rn_T1 = (c.samples - 250) / 3;
         const size_t per_utt = (size_t)h->rn_T1 * 128;           // largest activation: (T1, 128); later stages shrink 3x per doubling
+        h->rn_buf_bytes = B * per_utt * e;
         for (int i = 0; i < 6; ++i) {
             char* q;
             if ((rc = dev_alloc(h, &q, B * per_utt * e + 256))) return rc;
             h->rn_buf[i] = q;
+            SV_HIP(h, hipMemset(q + h->rn_buf_bytes, 0, 256));          // the zero tail (no kernel writes past the payload)
         }
         if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
         if (h->bf16) {                                           // LayerNorm output as bf16, zero-tailed rows (operand of the bf16 sinc kernel)
@@ -835,6 +845,17 @@ int alloc_workspace(svhip_handle* h) {
     return SVHIP_OK;
 }
 
+// zero page of a conv-gather GEMM whose A operand starts at `A`: the zero tail of the RawNet2 activation buffer that holds A (behind
+// the operand, within 4 GiB: what gemm_pw3's 16-bit conv-gather form needs), else the handle's stand-alone zero page
+const void* zero_page_for(const svhip_handle* h, const void* A) {
+    const char* a = static_cast<const char*>(A);
+    for (int i = 0; i < 6; ++i) {
+        const char* b = static_cast<const char*>(h->rn_buf[i]);
+        if (b && a >= b && a < b + h->rn_buf_bytes) return b + h->rn_buf_bytes;
+    }
+    return h->d_zero;
+}
+
 // ---- GEMM call helper -------------------------------------------------------------------------------
 int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void* A, int lda, void* Y, int ldy, int M,
               int act1, int act2 = ACT_NONE, const void* A2 = nullptr, int lda2 = 0, const float* bias_utt = nullptr,
@@ -844,7 +865,8 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.colsum = colsum; p.colsum_sq = colsum_sq; p.colsum_stride = colsum_stride;
     h->last_colsum_done = false;
     h->side_done = false;
-    p.R = R; p.ldr = ldr; p.zero_page = h->d_zero;
+    p.R = R; p.ldr = ldr; p.zero_page = zero_page_for(h, A);
+    p.zeros = h->d_zeros; p.ones = h->d_ones; p.cv_off = h->opt.cv_off;
     p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
     p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
     p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np;
@@ -886,7 +908,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
     const GemmRoute route = gemm_route(p, bf);
-    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
+    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW3CV ? "gemm_pw3cv16" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
                          : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
     if (h->opt.layer_labels) {            // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
@@ -1142,7 +1164,8 @@ int ecapa_forward(svhip_handle* h, const float* d_feat, int B) {
 // conv2 + 1 x 1 shortcut of a RawNet2 block as ONE conv-gather GEMM: K = 3 * cout conv columns of hb, then cin columns of `pre`
 static GemmParams conv2sc_params(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
     GemmParams p;
-    p.A = hb; p.W = K.conv2sc_W; p.Y = o; p.zero_page = h->d_zero;
+    p.A = hb; p.W = K.conv2sc_W; p.Y = o; p.zero_page = zero_page_for(h, hb);
+    p.zeros = h->d_zeros; p.ones = h->d_ones; p.cv_off = h->opt.cv_off;
     p.M = M; p.N = K.cout; p.K = K.conv2.K; p.Kp = K.conv2.K + K.cin; p.Wrows = K.conv2.Np;
     p.lda = K.cout; p.ldy = K.cout; p.T = T; p.taps = 3; p.dil = 1; p.cin = K.cout; p.pad_mode = PAD_ZERO;
     p.A3 = pre; p.lda3 = K.cin; p.K3 = K.cin;
@@ -1152,6 +1175,17 @@ static GemmParams conv2sc_params(svhip_handle* h, const svhip_handle::RnBlock& K
 static bool conv2sc_fits(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
     const GemmParams p = conv2sc_params(h, K, pre, hb, o, M, T);
     return gemm_pw2_supported(p, true) && gemm_route(p, true) == ROUTE_PW2;
+}
+
+// would conv_gemm route this residual-free convolution to the persistent conv-gather kernel?
+static bool conv_cv_persistent(svhip_handle* h, const ConvLayer& L, const void* A, int lda, int M, int T, int pad_mode) {
+    GemmParams p;
+    p.A = A; p.W = L.W; p.Y = h->d_emb;      // (Y: any 16-byte aligned pointer; the route does not depend on it)
+    p.bias = L.bias; p.scale = L.scale; p.shift = L.shift; p.zeros = h->d_zeros; p.ones = h->d_ones; p.zero_page = zero_page_for(h, A);
+    p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np; p.lda = lda; p.ldy = L.N; p.T = T;
+    p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
+    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.cv_off = h->opt.cv_off;
+    return h->bf16 && gemm_route(p, true) == ROUTE_PW3CV;
 }
 
 // RawNet2.forward (models/RawNet2_custom.py:161-227) on device-resident waveforms (B, L), utterances [b0, b0 + B) of the call,
@@ -1256,6 +1290,8 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // A 1 x 1 shortcut rides in conv2's GEMM as extra K columns when the 256 x 256 kernel takes it (no shortcut tensor in HBM)
         const bool fold_sc = K.has_shortcut && K.conv2sc_W && !no_tail && conv2sc_fits(h, K, pre, hb, o, M, T);
         const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
+        const void* resid_in_tail = nullptr;
+        const bool tail_fused = !no_tail && rn_tail_supported(dt, K.downsample ? T / 3 : T, K.cout);
         if (K.has_shortcut && !fold_sc) {
             if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
             resid = sc;
@@ -1263,8 +1299,16 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
         if (fold_sc) {
             GemmParams p = conv2sc_params(h, K, pre, hb, o, M, T);
-            if ((rc = run(h, "gemm_pw2_conv", (double)M * (K.conv2.flops_per_row + K.shortcut.flops_per_row), [&]() { return launch_gemm(p, true, st); }))) return rc;
-        } else if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, K.cout))) return rc;
+            const char* lbl = "gemm_pw2_conv";
+            char shaped2[96];
+            if (h->opt.layer_labels) { snprintf(shaped2, sizeof(shaped2), "%s M%d N%d K%d+%d", lbl, M, K.cout, K.conv2.K, K.cin); lbl = shaped2; }
+            if ((rc = run(h, lbl, (double)M * (K.conv2.flops_per_row + K.shortcut.flops_per_row), [&]() { return launch_gemm(p, true, st); }))) return rc;
+        } else {
+            // identity shortcut: with the fused block tail and conv2 on the persistent conv-gather kernel (which has no residual
+            // operand) the tail adds the block input; otherwise conv2's epilogue does
+            if (!K.has_shortcut && tail_fused && bf && conv_cv_persistent(h, K.conv2, hb, K.cout, M, T, PAD_ZERO)) { resid_in_tail = x; resid = nullptr; }
+            if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, resid ? K.cout : 0))) return rc;
+        }
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
@@ -1272,12 +1316,13 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // the block output itself is read only by an identity shortcut of the next block (or as a debug stage)
         const bool x_dead = stop_after < 0 && npre && (bi == 7 || h->rn_blocks[bi + 1].has_shortcut);
         const int Tn = K.downsample ? T / 3 : T;
-        if (!no_tail && rn_tail_supported(dt, Tn, K.cout)) {
+        if (tail_fused) {
             // max-pool + AFMS + next pre-activation in one launch, the pooled activation held in registers      :228-229, :62-68
             char tl[48] = "rn_tail";
             if (h->opt.layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
             if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
-                     return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st);
+                     return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st,
+                                           resid_in_tail);
                  }))) return rc;
             T = Tn;
         } else {

@@ -44,9 +44,9 @@ __device__ __forceinline__ void act4(float (&v)[4], const f32x4& a, const f32x4&
         for (int e = 0; e < 4; ++e) {
             float t = a[e];
             if (EPI == EPI_RELU) t = fmaxf(t, 0.0f);
-            if (EPI == EPI_LRELU03) t = t > 0.0f ? t : 0.3f * t;
+            if (EPI == EPI_LRELU03) t = fmaxf(t, 0.3f * t);               // == t > 0 ? t : 0.3 t, without the compare mask
             t = fmaf(t, sc4[e], sh4[e]);
-            if (EPI == EPI_BN_LRELU03) t = t > 0.0f ? t : 0.3f * t;      // RawNet2: conv -> bn2 -> lrelu (act1 none, act2 lrelu)
+            if (EPI == EPI_BN_LRELU03) t = fmaxf(t, 0.3f * t);            // RawNet2: conv -> bn2 -> lrelu (act1 none, act2 lrelu)
             v[e] = t;
         }
     }

@@ -28,6 +28,8 @@
 // with the column sums 0.25 against 0.30), K = 3072 1.50 against 1.57 ms.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "gemm_epi.h"
@@ -84,10 +86,22 @@ constexpr int ABL = 0;
 // in flight per CU (a 128 x 128 / four-wave re-cut with two workgroups per CU), not built.  Letting the two empty wave columns skip
 // their fragment reads and MFMAs (they keep the DMA stream, waits and barriers) changed the step by nothing (88.7 us): the clock rose
 // and the K loop's cycle count with it (44 k -> 52 k) — that loop runs at the pace of its gathered operand stream, not of the matrix pipe.
-template <int EPI, int CS, bool X3, bool R2 = false, bool CV = false>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
+//
+// CV on 16-bit operands (round 4; H = bf16_t or f16_t): the same gather with 64-wide K tiles — a 128-byte K tile is 64 channels of ONE
+// tap, so cin % 64 == 0 (RawNet2's k = 3 convolutions of blocks 2 - 5: cin = 128 / 256 / 512; ECAPA's blocks.0 with its 80 mel
+// channels zero-padded to 128).  Zero padding (RawNet2) as well as reflect: a row outside its utterance reads the zero page (a
+// 32-bit offset from the K tile's base: the host places the zero page behind the operand).  No residual operand: an identity shortcut is
+// added by the consumer (rn_tail), so that this kernel's epilogue stays free of ordinary loads.  Measured at B = 256 (fp16, in the model /
+// tools/gemm_bench back to back): block 2 conv1 (K = 384) 90 us against 100 on the per-tile kernel (719 against 622 TFLOP/s back to
+// back), the K = 768 convolutions of blocks 3 / 4 62.6 against 69.6 us.  What bounds these shapes is not the gather (the plain pointwise
+// GEMM of the same shape runs at 784 TFLOP/s): N = 256 is one N tile, so no operand is reused between tiles, and 391 tiles on 256 CUs
+// are 1.53 rounds.  A form with the 1 x 1 shortcut of blocks 2 / 5 appended to conv2's K axis (as gemm_pw2's CONV == 2) was built and
+// measured no faster than that kernel (193.6 against 182.0 us, 129.6 against 119.4): those two launches stay on gemm_pw2.
+template <int EPI, int CS, bool X3, bool R2 = false, bool CV = false, typename H = bf16_t>          // CS: 0 no column sums, 1 sums, 2 sums and sums of squares
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
-    static_assert(!CV || (X3 && !R2), "the conv-gather form (CV) is the pointwise X3 kernel with gathered X rows");
+    static_assert(!CV || !R2, "the conv-gather form (CV) is the pointwise kernel with gathered X rows");
+    static_assert(!X3 || std::is_same<H, bf16_t>::value, "the split-bf16 forms are bf16 by construction");
     constexpr bool GATHER = R2 || CV;          // X half-tiles = im2col view of a dilated convolution over the rows of an utterance
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = (X3 ? 32 : 16) + 8 * CS;    // vector-memory stores a wave issues in one tile's epilogue
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     uint32_t xt[2] = {0, 0};                       // R2: frame index (inside its utterance) of the lane's X rows, [jj] = lo | hi << 16
     const char* abase = nullptr;
     const char* wbase = nullptr;
+    const bool zero_pad = CV && !X3 && p.pad_mode == PAD_ZERO;
     int dsto[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) dsto[jj] = (wave * 2 + jj) * 1024;
@@ -143,16 +158,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
             for (int ty = 0; ty < 2; ++ty) {
                 const int m = min((rho >> 6) * 128 + ty * 64 + (rho & 63), mmax);
-                xo[ty][jj] = (uint32_t)((m + (GATHER ? 8 : 0)) * p.lda * ESZ + c * 16);
-                if (GATHER) { const int t = (m0 + m) % p.T; xt[jj] = ty == 0 ? (uint32_t)t : (xt[jj] | ((uint32_t)t << 16)); }
+                // (24-bit multiplies — v_mad_u32_u24, a 32-bit result: as a plain 32-bit product hipcc emits v_mad_u64_u32 and keeps the
+                //  dead high half allocated with the low one, a second VGPR per offset; rows and row bytes < 2^24: pw3_offsets_fit)
+                xo[ty][jj] = __umul24((uint32_t)(m + (GATHER ? 8 : 0)), (uint32_t)(p.lda * ESZ)) + (uint32_t)(c * 16);
+                if (GATHER) {
+                    // frame inside its utterance = (m0 + m) mod T by the host's multiplier ceil(2^32 / T) (GemmParams::t_magic, an SGPR):
+                    // the quotient is exact or one too large, fixed by one add.  (Written as `% p.T` the compiler keeps a per-lane
+                    // reciprocal of T alive across the whole tile loop — one VGPR too many for the 16-bit conv-gather instances,
+                    // whose spill reload sat inside the K loop.)
+                    const uint32_t mm = (uint32_t)(m0 + m);
+                    int t = (int)(mm - __umulhi(mm, p.t_magic) * (uint32_t)p.T);
+                    t = t < 0 ? t + p.T : t;
+                    xt[jj] = ty == 0 ? (uint32_t)t : (xt[jj] | ((uint32_t)t << 16));
+                }
                 const int n = min((rho >> 5) * 64 + ty * 32 + (rho & 31), nmax);
-                wo[ty][jj] = (uint32_t)(n * p.Kp * ESZ + c * 16);
+                wo[ty][jj] = __umul24((uint32_t)n, (uint32_t)(p.Kp * ESZ)) + (uint32_t)(c * 16);
             }
         }
     };
-    // K tiles per tap = cin / 32 (p.cin: the channel count of a row of A, a multiple of 32); tap = kt / ktpt by multiplication
-    // (kt < 64); K tiles past the last tap (padding of the K tile count to an even number) re-read the last tap: their weights are 0
-    const int ktpt = GATHER ? (p.cin >> 5) : 1;
+    // K tiles per tap = cin / 32 (X3: 32 k per 128-byte K tile) or cin / 64 (16-bit operands): p.cin is the channel count of a row of
+    // A; tap = kt / ktpt by multiplication (kt < 64); K tiles past the last tap (padding of the K tile count to an even number)
+    // re-read the last tap: their weights are 0
+    const int ktpt = GATHER ? (p.cin * ESZ) >> 7 : 1;
     const int tap_mul = GATHER ? 65536 / ktpt + 1 : 0;
     auto issue = [&](int ty, int kt) {
         char* base = smem + ((kt & 1) * 4 + ty) * HT;
@@ -160,13 +187,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         const int tap = gather ? min((kt * tap_mul) >> 16, p.taps - 1) : 0;
         const char* ub = (ty < 2 ? abase : wbase) + (int64_t)(gather ? min(kt - tap * ktpt, ktpt - 1) : kt) * 128;
         const int shift = gather ? (tap - (p.taps >> 1)) * p.dil : 0;
+        // zero padding (16-bit CV form): a row outside its utterance reads the zero page, addressed as a 32-bit offset from this K tile's
+        // base like every other row (the host puts the zero page behind A, within 4 GiB: gemm_pw3cv16_supported), so the select is one
+        // v_cndmask on the offset and the SGPR base + VGPR offset addressing stays
+        const uint32_t zoff = (CV && !X3) ? (uint32_t)(reinterpret_cast<uintptr_t>(p.zero_page) - reinterpret_cast<uintptr_t>(ub)) : 0u;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             uint32_t o = ty < 2 ? xo[ty][jj] : wo[ty - 2][jj];
             if (gather) {       // the row of frame reflect(t + shift) of the same utterance: a few rows either way (int32 arithmetic)
                 const int t = (int)((xt[jj] >> (ty * 16)) & 0xffffu);
-                const int d = reflect_idx(t + shift, p.T) - t;
-                o = (uint32_t)((int)o + d * p.lda * ESZ);
+                if (CV && !X3) {
+                    const int tt = t + shift;
+                    const int d = zero_pad ? shift : reflect_idx(tt, p.T) - t;
+                    const uint32_t oo = (uint32_t)((int)o + d * p.lda * ESZ);
+                    o = (zero_pad && (unsigned)tt >= (unsigned)p.T) ? zoff : oo;
+                } else {
+                    const int d = reflect_idx(t + shift, p.T) - t;
+                    o = (uint32_t)((int)o + d * p.lda * ESZ);
+                }
             }
             asm volatile("" : "+v"(o));          // the zero-extension stays in this block: SGPR base + 32-bit VGPR offset addressing
             const char* s = ub + o;
@@ -290,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks)                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                acc16[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WARR[j][X3 ? (ks == 2) : ks], xf[i][X3 ? (ks == 1) : ks], acc16[(I0) + i][(J0) + j], 0, 0, 0); \
+                acc16[(I0) + i][(J0) + j] = Half16<H>::mfma16(WARR[j][X3 ? (ks == 2) : ks], xf[i][X3 ? (ks == 1) : ks], acc16[(I0) + i][(J0) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_s_barrier();
 #define PW3_KTILE(REM_, KT_, WCUR, WNXT, RLX_, HOOK)                                       \
@@ -560,8 +598,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                         acc16[i][2 * jp] = f32x4{v0[0], v0[1], v0[2], v0[3]};
                         acc16[i][2 * jp + 1] = f32x4{v1[0], v1[1], v1[2], v1[3]};
                     }
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(bf16_pack2(v0[0], v0[1]), bf16_pack2(v1[0], v1[1]), false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(bf16_pack2(v0[2], v0[3]), bf16_pack2(v1[2], v1[3]), false, false);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(Half16<H>::pack2(v0[0], v0[1]), Half16<H>::pack2(v1[0], v1[1]), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(Half16<H>::pack2(v0[2], v0[3]), Half16<H>::pack2(v1[2], v1[3]), false, false);
                     const int m = m0 + wm * 128 + i * 16 + r16e;
                     if (m < p.M && !(ABL & 8))
                         *reinterpret_cast<u32x4*>(yl + (int64_t)i * 16 * p.ldy * 2) = u32x4{s0[0], s1[0], s0[1], s1[1]};
@@ -686,7 +724,17 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_cv(const GemmParams& p, hipStream_t stream) {
+// the kernel forms its per-lane byte offsets with 24-bit multiplies and 32-bit sums
+inline bool pw3_offsets_fit(const GemmParams& p, int esz) {
+    return (int64_t)p.M + 512 < (1 << 24) && (int64_t)p.lda * esz < (1 << 24) && (int64_t)p.Kp * esz < (1 << 24) && (int64_t)p.Wrows < (1 << 24) &&
+           ((int64_t)p.M + 512) * p.lda * esz < ((int64_t)1 << 32) && (int64_t)p.Wrows * p.Kp * esz < ((int64_t)1 << 32);
+}
+
+inline uint32_t t_magic_of(int T) { return (uint32_t)(0xFFFFFFFFull / (uint32_t)T) + 1u; }       // ceil(2^32 / T), T >= 2
+
+hipError_t launch_cv(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.t_magic = t_magic_of(p.T);
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_GELU, 0, true, false, true>), PW3_LDS)) return e;
@@ -703,12 +751,25 @@ hipError_t launch_cs(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+template <int EPI, typename H>
+hipError_t launch_cv16_inst(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.t_magic = t_magic_of(p.T);
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, 0, false, false, true, H>), PW3_LDS)) return e;
+    const int cap = pw3_grid_cap(p);
+    hipLaunchKernelGGL((gemm_pw3_kernel<EPI, 0, false, false, true, H>), dim3(ntiles < cap ? ntiles : cap), dim3(512), PW3_LDS, stream, p);
+    return hipGetLastError();
+}
+
 // The persistent kernel takes the plain pointwise layers of the 256 x 256 kernel's contract (no conv-gather, no residual) with
 // whole N tiles, at least four K tiles, all three per-channel vectors present, and more tiles than CUs (below that a persistent
 // workgroup has no second tile to overlap anything with).
 bool gemm_pw3_supported(const GemmParams& p, bool bf16) {
     if (!gemm_pw2_supported(p, bf16)) return false;
     if (p.taps > 1 || p.R || p.A3 || p.f16) return false;
+    if (!pw3_offsets_fit(p, 2)) return false;
     if (p.N % 256 != 0 || p.Kp < 256) return false;
     if (!p.bias || !p.scale || !p.shift) return false;
     if (p.act2 != ACT_NONE || !(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU)) return false;
@@ -738,6 +799,7 @@ hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream) {
 // The X3 form (p.x3 == 2: A and W in the S32 split layout, fp32 out): the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p) {
     if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.taps > 1 || p.y_s32) return false;
+    if (!pw3_offsets_fit(p, 4)) return false;
     if (p.act1 != ACT_GELU || p.act2 != ACT_NONE) return false;
     if (!p.bias || !p.scale || !p.shift) return false;
     if (p.N % 256 != 0 || p.K != p.Kp || p.K % 64 != 0 || p.K < 128 || p.lda < p.K || p.lda % 32 != 0 || p.ldy % 4 != 0) return false;      // whole 32-k blocks, an even number of them
@@ -757,6 +819,7 @@ bool gemm_pw3x3_supported(const GemmParams& p) {
 // R / Y2: R = the next chunk of the fp32 tdnn1 output (row stride ldr), Y2 = U_{j+1} (M, lda2) S32.
 bool gemm_pw3r2_supported(const GemmParams& p) {
     if (p.x3 != 2 || p.taps != 3 || p.A2 || p.A3 || p.bias_utt || p.colsum || p.out_f32) return false;
+    if (!pw3_offsets_fit(p, 4)) return false;
     if (!(p.cin == 64 || p.cin == 128) || p.N != p.cin || p.K != 3 * p.cin || p.Kp != p.K) return false;
     if (p.act1 != ACT_RELU || p.act2 != ACT_NONE || p.pad_mode != PAD_REFLECT) return false;
     if (!p.bias || !p.scale || !p.shift || !p.Y) return false;
@@ -769,8 +832,10 @@ bool gemm_pw3r2_supported(const GemmParams& p) {
     return (p.M + 255) / 256 > pw3_grid_cap(p);
 }
 
-hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream) {
-    if (!gemm_pw3r2_supported(p)) return hipErrorInvalidValue;
+hipError_t launch_gemm_pw3r2(const GemmParams& p_in, hipStream_t stream) {
+    if (!gemm_pw3r2_supported(p_in)) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    p.t_magic = t_magic_of(p.T);
     const int ntiles = (p.M + 255) / 256;
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI_RELU, 0, true, true>), PW3_LDS)) return e;
@@ -789,6 +854,7 @@ hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream) {
 // multiple of 64 (zero columns), reflect padding inside each utterance, GELU -> BN, fp32 out.
 bool gemm_pw3cv_supported(const GemmParams& p) {
     if (p.x3 != 2 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.colsum || p.side_c) return false;
+    if (!pw3_offsets_fit(p, 4)) return false;
     if (p.taps < 3 || p.taps > 7 || !(p.taps & 1) || p.pad_mode != PAD_REFLECT || p.dil < 1 || (p.taps >> 1) * p.dil > 8) return false;
     if (p.act1 != ACT_GELU || p.act2 != ACT_NONE || !p.bias || !p.scale || !p.shift) return false;
     if (p.cin % 32 != 0 || p.cin < 32 || p.lda != p.cin || p.K != p.taps * p.cin || p.Kp % 64 != 0 || p.Kp < p.K || p.Kp - p.K >= 64 || p.Kp > 63 * 32) return false;
@@ -803,6 +869,45 @@ bool gemm_pw3cv_supported(const GemmParams& p) {
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream) {
     if (!gemm_pw3cv_supported(p)) return hipErrorInvalidValue;
     return launch_cv(p, stream);
+}
+
+// The conv-gather form on 16-bit operands (bf16, or fp16 with p.f16): odd taps, cin % 64 == 0 (a 128-byte K tile = 64 channels of one
+// tap), reflect or zero padding inside each utterance, epilogues GELU -> BN (ECAPA blocks.0), BN -> LeakyReLU(0.3) (RawNet2 conv1), none
+// (conv2).  The kernel reads its three
+// per-channel vectors by DMA: absent ones are replaced by the caller's constant vectors (GemmParams::zeros / ones, >= N floats).
+bool gemm_pw3cv16_supported(const GemmParams& p) {
+    if (p.x3 || p.out_f32 || p.bias_utt || p.A2 || p.A3 || p.R || p.colsum || p.side_c || p.y_s32) return false;
+    if (!pw3_offsets_fit(p, 2)) return false;
+    if (p.taps < 3 || p.taps > 7 || !(p.taps & 1) || p.dil < 1 || (p.taps >> 1) * p.dil > 8) return false;
+    if (!(p.pad_mode == PAD_REFLECT || (p.pad_mode == PAD_ZERO && p.zero_page))) return false;
+    if (p.pad_mode == PAD_ZERO) {      // the zero page is addressed as a 32-bit offset from any K tile base of A: behind A's rows, within 4 GiB
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p.A), z = reinterpret_cast<uintptr_t>(p.zero_page);
+        if (z < a0 + (uintptr_t)p.M * p.lda * 2 || z - a0 >= ((uintptr_t)1 << 32) - (uintptr_t)16 * p.lda * 2 - 4096) return false;
+    }
+    const bool gelu = p.act1 == ACT_GELU && p.act2 == ACT_NONE, bnlr = p.act1 == ACT_NONE && p.act2 == ACT_LRELU03, none = p.act1 == ACT_NONE && p.act2 == ACT_NONE;
+    if (!(gelu || bnlr || none) || (p.f16 && gelu)) return false;
+    if (!(p.bias || p.zeros) || !(p.scale || p.ones) || !(p.shift || p.zeros) || ((p.scale == nullptr) != (p.shift == nullptr))) return false;
+    if (p.cin % 64 != 0 || p.cin < 64 || p.lda < p.cin || p.lda % 8 != 0 || p.K != p.taps * p.cin) return false;
+    if (p.Kp != p.K) return false;
+    if (p.Kp % 128 != 0 || p.Kp < 256 || p.Kp > 63 * 64) return false;             // an even number (>= 4) of 64-wide K tiles, kt < 64
+    if (p.N % 256 != 0 || p.ldy % 8 != 0 || p.Wrows < p.N) return false;
+    if (p.T <= (p.taps >> 1) * p.dil || p.T >= 65536 || p.M <= 0 || p.M % p.T != 0) return false;
+    if ((int64_t)(p.M + 16) * p.lda * 2 >= (int64_t)1 << 31) return false;         // 32-bit per-lane byte offsets
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) |
+         reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift) |
+         reinterpret_cast<uintptr_t>(p.zeros) | reinterpret_cast<uintptr_t>(p.ones) | reinterpret_cast<uintptr_t>(p.zero_page)) & 15) return false;
+    if (p.num_cu <= 0 || p.num_cu > 1024) return false;
+    return ((p.M + 255) / 256) * (p.N / 256) > pw3_grid_cap(p);
+}
+
+hipError_t launch_gemm_pw3cv16(const GemmParams& p_in, hipStream_t stream) {
+    if (!gemm_pw3cv16_supported(p_in)) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    if (!p.bias) p.bias = p.zeros;
+    if (!p.scale) { p.scale = p.ones; p.shift = p.zeros; }
+    if (p.act2 == ACT_LRELU03) return p.f16 ? launch_cv16_inst<EPI_BN_LRELU03, f16_t>(p, stream) : launch_cv16_inst<EPI_BN_LRELU03, bf16_t>(p, stream);
+    if (p.act1 == ACT_GELU) return launch_cv16_inst<EPI_GELU, bf16_t>(p, stream);
+    return p.f16 ? launch_cv16_inst<EPI_NONE, f16_t>(p, stream) : launch_cv16_inst<EPI_NONE, bf16_t>(p, stream);
 }
 
 }  // namespace svhip

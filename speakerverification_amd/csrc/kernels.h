@@ -66,6 +66,8 @@ struct GemmParams {
     float* colsum = nullptr;
     int colsum_sq = 0;
     int64_t colsum_stride = 0;
+    const float* zeros = nullptr;    // >= N zero floats / >= N ones: stand-ins for absent bias / scale / shift vectors in the kernels that
+    const float* ones = nullptr;     // read all three by DMA (gemm_pw3's 16-bit conv-gather form)
     const void* zero_page = nullptr; // >= 64 zero bytes (LDS-DMA source for padded k / out-of-range frames in the conv-gather pw2 path)
     void* Y2 = nullptr;             // gemm_pw3's Res2Net step form only: second output (the next step's input), row stride lda2
     const void* R = nullptr;        // optional residual (M, ldr) in the activation dtype, added last
@@ -82,12 +84,14 @@ struct GemmParams {
     void* side_b = nullptr;
     int side_lda = 0, side_ldb = 0, side_c = 0;
     int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
+    int cv_off = 0;                 // developer option cv_off: 16-bit conv-gather GEMMs stay on the per-tile kernel
     int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
                                     // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
     int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
     int T = 1;
+    uint32_t t_magic = 0;     // gemm_pw3's gather forms: ceil(2^32 / T), filled by their launchers (frame index = row mod T without a division)
     int taps = 1, dil = 1, cin = 0, pad_mode = 0;
     int act1 = 0, act2 = 0;
     int out_f32 = 0;          // bf16 compute only: store fp32 instead of bf16
@@ -115,7 +119,9 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
 //   PW         gemm_pw with its default tile;  GENERIC  the register-staged kernel of gemm.hip
 //   PW3        the persistent form of PW2 with the epilogue taken from the accumulators (gemm_pw3.hip): plain pointwise layers
 //              with more tiles than CUs (ECAPA's tdnn1 / tdnn2 / mfa)
-enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3, ROUTE_PW3 = 4 };
+//   PW3CV      the persistent kernel's conv-gather form on 16-bit operands: k = 3 / 5 convolutions with cin % 64 == 0 and more tiles
+//              than CUs (RawNet2 blocks 2 - 5, ECAPA blocks.0 with padded input rows)
+enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3, ROUTE_PW3 = 4, ROUTE_PW3CV = 5 };
 GemmRoute gemm_route(const GemmParams& p, bool bf16);
 bool gemm_pw_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow = false);
@@ -135,6 +141,8 @@ bool r2_step_supported(const GemmParams& p);               // r2_step.hip: the R
 hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3cv_supported(const GemmParams& p);          // conv-gather X3 form (odd taps, reflect): see gemm_pw3.hip
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream);
+bool gemm_pw3cv16_supported(const GemmParams& p);        // conv-gather form on bf16 / fp16 operands (reflect or zero padding)
+hipError_t launch_gemm_pw3cv16(const GemmParams& p, hipStream_t stream);
 // one Res2Net step of an F32X3 handle on the same kernel (dilated k = 3 conv gathered from an S32 input, outputs in S32)
 bool gemm_pw3r2_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream);
@@ -289,7 +297,8 @@ hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alp
 // pooled activation held in registers; rn_tail_supported says whether (Tn, C) fits (else the four separate passes run)
 bool rn_tail_supported(int dt, int Tn, int C);
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
-                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream);
+                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream,
+                          const void* res = nullptr);       // res: the block input, added to x before the pool (16-bit handles; see rn_tail_kernel)
 // Fused 128 -> 128 pooled RawNetBasicBlock (rn_block128.hip, bf16): previous block's AFMS gate on the way in, BN + LeakyReLU,
 // conv1 + BN + LeakyReLU, conv2 + identity shortcut, max_pool1d(3), per-tile column sums of the pooled output.
 struct RnBlock128Params {

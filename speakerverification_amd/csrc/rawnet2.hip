@@ -449,11 +449,15 @@ __global__ __launch_bounds__(256) void rn_attn_pool_kernel(const float* __restri
 // embeddings by up to 4 % of their scale against the separate passes on random weights (the gate scales a whole block output).
 constexpr int TAIL_THREADS = 1024, TAIL_NCH = 16;
 
-template <typename T, bool POOL>
+// RES: x is conv2's output WITHOUT the identity shortcut (the persistent conv-gather GEMM has no residual operand); the block input
+// `res` (B, Tin, C) is added here, before the pool — the sum is formed in fp32 and rounded once, where the GEMM epilogue rounded the
+// conv output and then the sum.
+template <typename T, bool POOL, bool RES>
 __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ pre,
                                                                const float* __restrict__ alpha, const float* __restrict__ WT,
                                                                const float* __restrict__ bias, const float* __restrict__ nscale,
-                                                               const float* __restrict__ nshift, int Tin, int Tn, int C, float slope) {
+                                                               const float* __restrict__ nshift, int Tin, int Tn, int C, float slope,
+                                                               const T* __restrict__ res) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float part[8192];                     // 32 KiB: column-sum partials, then the gate's partial dot products
     __shared__ float mean[512], gate[512];
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
     const int cpr = C / VEC, rstep = TAIL_THREADS / cpr;
     const int cc = tid % cpr, r0 = tid / cpr, c = cc * VEC;
     const T* xb = x + b * Tin * (int64_t)C + c;
+    const T* rb = RES ? res + b * Tin * (int64_t)C + c : nullptr;
     Vec16<T> held[TAIL_NCH];
     float sum[VEC];
 #pragma unroll
@@ -474,10 +479,23 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
                 const T* q = xb + (int64_t)(3 * t) * C;
                 const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(q), bb = *reinterpret_cast<const Vec16<T>*>(q + C),
                                d = *reinterpret_cast<const Vec16<T>*>(q + 2 * C);
+                if (RES) {
+                    const T* r = rb + (int64_t)(3 * t) * C;
+                    const Vec16<T> ra = *reinterpret_cast<const Vec16<T>*>(r), rbb = *reinterpret_cast<const Vec16<T>*>(r + C),
+                                   rd = *reinterpret_cast<const Vec16<T>*>(r + 2 * C);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), d.get(j)));
+                    for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j) + ra.get(j), bb.get(j) + rbb.get(j)), d.get(j) + rd.get(j)));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), d.get(j)));
+                }
             } else {
                 held[i] = *reinterpret_cast<const Vec16<T>*>(xb + (int64_t)t * C);
+                if (RES) {
+                    const Vec16<T> r = *reinterpret_cast<const Vec16<T>*>(rb + (int64_t)t * C);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) held[i].set(j, held[i].get(j) + r.get(j));
+                }
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum[j] += held[i].get(j);
@@ -628,15 +646,18 @@ bool rn_tail_supported(int dt, int Tn, int C) {
 }
 
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
-                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream) {
+                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream, const void* res) {
     const int Tn = pool ? Tin / 3 : Tin;
     if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(dt, Tn, C) || (pre && (!next_scale || !next_shift)))
         return hipErrorInvalidValue;
-#define SV_TAIL(TT, P) hipLaunchKernelGGL((rn_tail_kernel<TT, P>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
-                                          alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope)
-    if (dt == DT_F16) { if (pool) SV_TAIL(f16_t, true); else SV_TAIL(f16_t, false); }
-    else if (dt == DT_BF16) { if (pool) SV_TAIL(bf16_t, true); else SV_TAIL(bf16_t, false); }
-    else { if (pool) SV_TAIL(float, true); else SV_TAIL(float, false); }
+    if (res && dt == DT_F32) return hipErrorInvalidValue;       // (the residual form exists for the 16-bit handles, whose conv2 may run without one)
+#define SV_TAIL(TT, P, R) hipLaunchKernelGGL((rn_tail_kernel<TT, P, R>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
+                                             alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope, (const TT*)res)
+#define SV_TAIL16(TT) { if (res) { if (pool) SV_TAIL(TT, true, true); else SV_TAIL(TT, false, true); } else { if (pool) SV_TAIL(TT, true, false); else SV_TAIL(TT, false, false); } }
+    if (dt == DT_F16) SV_TAIL16(f16_t)
+    else if (dt == DT_BF16) SV_TAIL16(bf16_t)
+    else { if (pool) SV_TAIL(float, true, false); else SV_TAIL(float, false, false); }
+#undef SV_TAIL16
 #undef SV_TAIL
     return hipGetLastError();
 }

@@ -261,3 +261,41 @@ def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, la
         cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
         assert cos.min() >= 0.9999, cos.min()
         assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("half", ["bf16", "f16"])
+@pytest.mark.parametrize("L,B,cus", [(32000, 6, 3), (32000, 40, 16), (20000, 9, 2)])
+def test_persistent_conv_gather_matches_the_per_tile_kernel(L, B, cus, half):
+    """Round 4: the k = 3 convolutions of blocks 2 - 5 run on gemm_pw3's conv-gather form for 16-bit operands (persistent 256 x 256
+    kernel, 64-channel K tiles inside one tap, zero padding through a zero page behind the operand) whenever a layer has more tiles
+    than the grid; option pw3_cus caps the grid so that these small batches take the route (several tiles per workgroup, masked last
+    tiles), option cv_off keeps the per-tile kernel.  Block 2's conv1 (BN + LeakyReLU epilogue) multiplies the same K tiles in the
+    same order and rounds once (its conv2 + folded shortcut stays on the per-tile kernel): the block output must agree BIT FOR BIT.  Blocks 3 / 4 have an identity shortcut, which the persistent route hands to the block tail (sum
+    in fp32, one rounding instead of two): the embeddings agree to 16-bit round-off."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=6)
+    wav = synth.synth_waveforms(B, L, seed=12)
+    eng = Engine(model="rawnet2", compute=half, embed_dim=320, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    eng.set_option("pw3_cus", cus)
+    res = {}
+    for off in (1, 0):
+        eng.set_option("cv_off", off)
+        eng.set_option("rn_stop", 3)
+        eng.embed_wave(wav)
+        x3 = eng.get_stage("rn_x").copy()
+        eng.set_option("rn_stop", -1)
+        eng.profile(True)
+        emb = eng.embed_wave(wav).reshape(B, -1)
+        labels = eng.profile_results()
+        eng.profile(False)
+        res[off] = (x3, emb, labels)
+    eng.close()
+    assert "gemm_pw3cv16" not in res[1][2] and res[0][2]["gemm_pw3cv16"]["launches"] >= 3, (sorted(res[0][2]), sorted(res[1][2]))
+    assert np.isfinite(res[0][1]).all() and np.abs(res[1][0]).max() > 0
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    a, b = res[0][1], res[1][1]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    rel = float(np.abs(a - b).max() / np.abs(b).max())
+    print(f"{half} L={L} B={B}: persistent vs per-tile conv-gather: cos {cos.min():.6f}, max diff / scale {rel:.2e}")
+    assert cos.min() >= (0.9999 if half == "bf16" else 0.999999) and rel <= (2e-2 if half == "bf16" else 3e-3)

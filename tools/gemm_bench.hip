@@ -74,12 +74,12 @@ int main(int argc, char** argv) {
     }
     size_t maxA = (size_t)M * 3 * C, maxW = (size_t)3 * C * 3 * C + 128 * 3 * C, maxY = (size_t)M * 3 * C;
     void *A, *A2, *W, *Y; float *bias, *scale, *shift;
-    CK(hipMalloc(&A, maxA * esz)); CK(hipMalloc(&A2, maxA * esz)); CK(hipMalloc(&W, maxW * esz)); CK(hipMalloc(&Y, maxY * 4));
+    CK(hipMalloc(&A, maxA * esz + 256)); CK(hipMemset((char*)A + maxA * esz, 0, 256)); CK(hipMalloc(&A2, maxA * esz)); CK(hipMalloc(&W, maxW * esz)); CK(hipMalloc(&Y, maxY * 4));
     CK(hipMalloc(&bias, 4096 * 4)); CK(hipMalloc(&scale, 4096 * 4)); CK(hipMalloc(&shift, 4096 * 4));
     if (bf16) { fill_bf16<<<2048, 256>>>((uint16_t*)A, maxA, 1, dscale); fill_bf16<<<2048, 256>>>((uint16_t*)A2, maxA, 2, dscale); fill_bf16<<<2048, 256>>>((uint16_t*)W, maxW, 3, 0.05f * dscale); }
     else { fill_f32<<<2048, 256>>>((float*)A, maxA, 1, 1.0f); fill_f32<<<2048, 256>>>((float*)A2, maxA, 2, 1.0f); fill_f32<<<2048, 256>>>((float*)W, maxW, 3, 0.05f); }
     fill_f32<<<16, 256>>>(bias, 4096, 4, 0.1f); fill_f32<<<16, 256>>>(scale, 4096, 5, 1.0f); fill_f32<<<16, 256>>>(shift, 4096, 6, 0.1f);
-    void* zp; CK(hipMalloc(&zp, 256)); CK(hipMemset(zp, 0, 256));
+    void* zp = (char*)A + maxA * esz;      // zero page BEHIND the A operand (gemm_pw3's 16-bit conv-gather form addresses it as a 32-bit offset)
     float* csum; const int64_t csr = (int64_t)(M / 256 + 2) * 16 * 3 * C; CK(hipMalloc(&csum, 2 * csr * 4));
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -94,6 +94,7 @@ int main(int argc, char** argv) {
         for (int rd = 0; rd < rounds; ++rd)
         for (int debug : debugs) {
             p.debug = debug;
+            p.cv_off = (debug & 32768) ? 1 : 0;            // 32768: conv-gather shapes on the per-tile kernel
             if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; } else { p.colsum = nullptr; }
             for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
             CK(hipStreamSynchronize(st));
@@ -112,7 +113,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpyAsync(hcs, dcs, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
             }
             printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s  cs %.6e %.6e  [%s]\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, hcs[0], hcs[1],
-                   gemm_route(p, bf16) == ROUTE_PW3 ? "pw3" : gemm_route(p, bf16) == ROUTE_PW2 ? "pw2" : "other");
+                   gemm_route(p, bf16) == ROUTE_PW3 ? "pw3" : gemm_route(p, bf16) == ROUTE_PW3CV ? "pw3cv16" : gemm_route(p, bf16) == ROUTE_PW2 ? "pw2" : "other");
             if ((debug & 128) && p.colsum && gemm_pw2_supported(p, bf16)) {
                 // per-utterance column sums from the partials (the arithmetic of colsum_finalize_kernel), as an order-sensitive checksum:
                 // the 8-row-group layout of pw2 and the 2-row-group layout of pw3 must agree to bf16 rounding of the summed values
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
                 }
                 printf("    colsum (RG %d): weighted sum %.9e  abs sum %.9e  sq %.9e\n", RG, a1, a2, q1);
             }
-            if ((debug & 16384) && gemm_route(p, bf16) == ROUTE_PW3) {      // stage cycle totals of the persistent kernel, per wave
+            if ((debug & 16384) && (gemm_route(p, bf16) == ROUTE_PW3 || gemm_route(p, bf16) == ROUTE_PW3CV)) {      // stage cycle totals of the persistent kernel, per wave
                 const int nwg = 256;
                 unsigned long long* dts; CK(hipMalloc(&dts, (size_t)nwg * 512)); CK(hipMemset(dts, 0, (size_t)nwg * 512));
                 p.ts = dts;
