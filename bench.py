@@ -62,7 +62,11 @@ def parse():
     ap.add_argument("--utts-per-gpu", type=int, default=125000, help="--config shard: utterances per GPU (1 M / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the rawnet2 / ecapa_f32 / pcie sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rawnet2 / ecapa_f32 / pcie / latency sub-records")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="N > 1: if the RCCL communicator cannot be created, carry the all-gather over gloo (host round trip) instead of "
+                         "failing; the record then says so.  Without this flag a multi-GPU run that is not on RCCL exits non-zero.")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the extra back-to-back run reported as `sustained` (0: skip)")
     return ap.parse_args()
 
 
@@ -364,6 +368,53 @@ def sub_bench(model, compute, B, local, dev, wavs, steps=10, warmup=2):
     return rec
 
 
+def latency_bench(local, dev, wavs, batches=(1, 10, 20, 32), modes=("bf16", "f32x3"), full_rate=None):
+    """The reference API's native operating point (row a14): `embed_utterance` / per-file enrolment embeds B = num_eval = 10 - 20 crops
+    of ONE file per call (src/model.py:675-704, yaml/configuration-voxceleb.yaml:156).  One engine per mode, created for the Python
+    wrapper's default max_batch = 256, called with B rows: `ms_per_call` = a synchronous call (host launch overhead + the GPU work of
+    one call, what a per-file loop sees); `utt_per_s` = the same calls enqueued back to back (a loop over files without a host sync);
+    launches per call and the per-kernel table of one call."""
+    import torch
+    res = {}
+    for mode in modes:
+        eng = make_engine("ecapa", mode, BATCH, local)
+        rows = {}
+        for b in batches:
+            w = wavs[0][:b].contiguous()
+            out = torch.empty((b, eng.embed_dim), device=dev, dtype=torch.float32)
+            for _ in range(3):
+                eng.embed_wave(w, out=out, async_=True)
+            torch.cuda.synchronize()
+            n = 30
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.embed_wave(w, out=out, async_=True)
+                torch.cuda.synchronize()
+            t_sync = (time.perf_counter() - t0) / n
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.embed_wave(w, out=out, async_=True)
+            torch.cuda.synchronize()
+            t_pipe = (time.perf_counter() - t0) / n
+            eng.profile(True)
+            eng.embed_wave(w, out=out, async_=True)
+            torch.cuda.synchronize()
+            prof = eng.profile_results()
+            eng.profile(False)
+            rec = {"ms_per_call": t_sync * 1e3, "utt_per_s_sync": b / t_sync, "ms_per_call_pipelined": t_pipe * 1e3, "utt_per_s": b / t_pipe,
+                   "launches_per_call": int(sum(v["launches"] for v in prof.values())),
+                   "gpu_ms_in_kernels": sum(v["ms"] for v in prof.values()),
+                   "kernels": {k: round(v["ms"] * 1e3, 1) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+            if full_rate and mode == "bf16":
+                rec["fraction_of_B256_rate"] = rec["utt_per_s"] / full_rate
+            rows[str(b)] = rec
+        res[mode] = rows
+        eng.close()
+    res["note"] = ("kernels: us per call of the eight longest labels (every launch bracketed by events: the bracketed call is slower than "
+                   "ms_per_call); utt_per_s = pipelined calls, no host sync between them")
+    return res
+
+
 def multi_stream_bench(model, compute, B, local, dev, wavs, n_streams=3, steps=30):
     """serving pattern: `n_streams` engines on their own streams take alternate batches, so the small, under-filled kernels of one
     batch run beside the big ones of another (RawNet2's late blocks are grids of 86 - 400 workgroups).  Reported next to the
@@ -531,9 +582,10 @@ def verify_last_step(eng, wav_last, emb_last, local, dev):
     return rec
 
 
-def make_comm(eng, ranks):
-    """RCCL communicator under the C ABI; if RCCL cannot come up on this node the run still completes over the gloo group
-    (host round trip) and says so in `allgather_carrier`."""
+def make_comm(eng, ranks, allow_gloo=False):
+    """RCCL communicator under the C ABI.  If RCCL cannot come up the run FAILS (every rank exits non-zero) — a number measured over a
+    gloo host round trip must not carry an N-GPU label by accident — unless --allow-gloo asks for the fallback, which the record then
+    names in `allgather_carrier`."""
     if not ranks.launched:
         return None, "none (1 GPU, no launcher)"
     from speakerverification_amd import distributed as sv_dist
@@ -549,7 +601,14 @@ def make_comm(eng, ranks):
     if ranks.min(ok) == 0:          # all ranks must agree on the carrier
         if comm is not None:
             eng.lib.svhip_comm_destroy(eng.h)
-        return None, "torch.distributed gloo all_gather (RCCL communicator could not be created on this node)"
+        if not allow_gloo:
+            ranks.close()
+            raise SystemExit("bench.py: the RCCL communicator could not be created on every rank and --allow-gloo was not given: "
+                             "refusing to report a multi-GPU number over a host round trip")
+        return None, "torch.distributed gloo all_gather (RCCL communicator could not be created on this node; --allow-gloo)"
+    rw = eng.comm_rank_world()
+    if rw != (ranks.rank, ranks.world):
+        raise SystemExit(f"bench.py: the library's communicator reports rank/world {rw}, the launcher {(ranks.rank, ranks.world)}")
     return comm, "svhip_allgather_rows (RCCL under the C ABI)"
 
 
@@ -565,6 +624,41 @@ def gather_rows(eng, comm, ranks, local, out):
         out.copy_(host)
     else:
         out.copy_(local)
+
+
+def block_checksum(block):
+    """order-independent, exact checksum of an fp32 block: the int64 sum of its words read as int32"""
+    import torch
+    return int(block.contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+
+def verify_gather(ranks, shard, gathered, n_local, regen_embed, rows=8, min_cos=0.9999):
+    """Does the gathered matrix hold EVERY rank's block, and the right utterances in it?  (reference: all_gather_object,
+    src/model.py:400-411.)  (a) every rank checksums its own block before the exchange; the checksums travel over the control plane
+    (gloo) and are compared on every rank with the checksums of the blocks as they arrived: bit-exact, every byte of every block;
+    (b) rank 0 regenerates the first `rows` utterances of every OTHER rank's block (the synthetic stream is a pure function of the
+    utterance index), embeds them itself and compares with the gathered rows: cosine >= `min_cos` (a row of a 16-bit engine moves by
+    round-off with its position in the batch).  Device-agnostic (tests drive it on CPU tensors over gloo at W = 3)."""
+    import torch
+    world, rank = ranks.world, ranks.rank
+    mine = block_checksum(shard[:n_local])
+    reported = ranks.gather_int64(mine)
+    arrived = [block_checksum(gathered[r * n_local:(r + 1) * n_local]) for r in range(world)]
+    rec = {"block_checksums": reported, "blocks_bitwise_ok": bool(arrived == reported)}
+    worst, checked = 1.0, 0
+    if rank == 0:
+        for r in range(1, world):
+            n = min(rows, n_local)
+            ref = regen_embed(r, n)
+            got = gathered[r * n_local:r * n_local + n]
+            cos = torch.nn.functional.cosine_similarity(got.float(), ref.float().to(got.device), dim=1)
+            worst = min(worst, float(cos.min().item()))
+            checked += n
+    rec["cross_rank_rows_checked"] = checked
+    rec["cross_rank_min_cosine"] = worst if checked else None
+    ok_here = rec["blocks_bitwise_ok"] and worst >= min_cos
+    rec["cross_rank_ok"] = bool(ranks.min(1.0 if ok_here else 0.0) == 1.0)       # every rank's byte check and rank 0's content check
+    return rec
 
 
 class Ranks:
@@ -605,6 +699,15 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_int64(self, x: int):
+        """one integer per rank, on every rank (control plane)"""
+        if self.dist is None:
+            return [int(x)]
+        import torch
+        out = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(out, torch.tensor([int(x)], dtype=torch.int64))
+        return [int(t.item()) for t in out]
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -643,7 +746,7 @@ def synth_batches(eng, n_batches, B, first_utt, dev, seed=SEED_STREAM):
     return wavs
 
 
-def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True, carrier=""):
+def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True, carrier="", regen_embed=None):
     """after embedding: ONE all-gather of the (n_local, D) block per rank, then config-4-style scoring of the gathered matrix,
     row-sharded by enrol index: rank r scores the trials (i, pi(i)) with i in its block, and computes the AS-norm cohort
     statistics of its own rows (gathered with a second, small all-gather of (n_local, 2))."""
@@ -665,6 +768,9 @@ def shard_tail(eng, comm, ranks, shard, dev, n_local, do_scoring=True, carrier="
     lo = rank * n_local
     own_block_ok = bool(torch.equal(gathered[lo:lo + n_local], shard))
     rec["own_block_intact"] = own_block_ok
+    rec["rccl_world"] = eng.comm_rank_world()[1] if comm is not None else 0
+    if regen_embed is not None:
+        rec.update(verify_gather(ranks, shard, gathered, n_local, regen_embed))
     if not do_scoring:
         return rec, gathered
     N = world * n_local
@@ -707,7 +813,7 @@ def run_batch(args, ranks, dev):
     rank, world, local = ranks.rank, ranks.world, ranks.local
     eng = make_engine(args.model, args.compute, B, local)
     embed = eng.embed_dim
-    comm, carrier = make_comm(eng, ranks)
+    comm, carrier = make_comm(eng, ranks, args.allow_gloo)
 
     # synthetic waveforms, resident in HBM before the timed region: NBATCH distinct batches per rank, rotated
     wavs = synth_batches(eng, NBATCH, B, rank * NBATCH * B, dev)
@@ -727,7 +833,26 @@ def run_batch(args, ranks, dev):
     check = verify_last_step(eng, wavs[(K - 1) % NBATCH], shard[(K - 1) * B:K * B], local, dev)
     shard_rec = None
     if ranks.launched:
-        shard_rec, _ = shard_tail(eng, comm, ranks, shard, dev, K * B, carrier=carrier)
+        def regen(r, n):          # the first n rows of rank r's block = its step 0 = utterances [r * NBATCH * B, ...) of the stream
+            w = torch.empty((n, SAMPLES), device=dev, dtype=torch.float32)
+            eng.synth_waveforms(SEED_STREAM, r * NBATCH * B, n, SAMPLES, out=w, async_=True)
+            o = torch.empty((n, embed), device=dev, dtype=torch.float32)
+            eng.embed_wave(w, out=o, async_=True)
+            torch.cuda.synchronize()
+            return o
+        shard_rec, _ = shard_tail(eng, comm, ranks, shard, dev, K * B, carrier=carrier, regen_embed=regen)
+    sustained = None
+    if args.sustain_seconds > 0 and rank == 0 and world == 1:
+        # the K timed steps above are ~0.1 s on a clock-limited chip: the same loop back to back for >= 2 s, reported next to it
+        n_s = max(K, int(args.sustain_seconds / max(dt / K, 1e-6)) + 1)
+        scratch = torch.empty((B, embed), device=dev, dtype=torch.float32)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for k in range(n_s):
+            eng.embed_wave(wavs[k % NBATCH], out=scratch, async_=True)
+        torch.cuda.synchronize()
+        d_s = time.perf_counter() - ts
+        sustained = {"seconds": d_s, "steps": n_s, "value": n_s * B / d_s, "unit": "embeddings/s", "ms_per_step": d_s / n_s * 1e3}
     n_all = min(K, 10)
     kern = kernel_table(eng, wavs, B, n_all, dev) if rank == 0 else {}
 
@@ -755,6 +880,7 @@ def run_batch(args, ranks, dev):
         }
         if shard_rec is not None:
             line["shard"] = shard_rec
+        line["sustained"] = sustained
         line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline and args.model == "ecapa") else None
         if world == 1 and not args.no_scoring and args.model == "ecapa":
             try:
@@ -772,6 +898,7 @@ def run_batch(args, ranks, dev):
                              ("ecapa_f32", lambda: sub_bench("ecapa", "f32", B, local, dev, wavs, steps=3, warmup=1)),
                              ("ecapa_f32x3", lambda: sub_bench("ecapa", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
                              ("rawnet2_f32x3", lambda: sub_bench("rawnet2", "f32x3", B, local, dev, wavs, steps=4, warmup=1)),
+                             ("latency", lambda: latency_bench(local, dev, wavs, full_rate=total_utts / dt)),
                              ("fusion", lambda: fusion_bench(B, local, dev, wavs)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:
@@ -792,7 +919,7 @@ def run_shard(args, ranks, dev, keep=False):
     rank, world, local = ranks.rank, ranks.world, ranks.local
     n_local = args.utts_per_gpu
     eng = make_engine(args.model, args.compute, B, local)
-    comm, carrier = make_comm(eng, ranks)
+    comm, carrier = make_comm(eng, ranks, args.allow_gloo)
     shard = torch.empty((n_local, eng.embed_dim), device=dev, dtype=torch.float32)
     wav = [torch.empty((B, SAMPLES), device=dev, dtype=torch.float32) for _ in range(2)]
     first = rank * n_local
@@ -819,7 +946,14 @@ def run_shard(args, ranks, dev, keep=False):
     dt = ranks.max(time.perf_counter() - t0)
     prof = eng.profile_results()
     eng.profile(False)
-    rec, _ = shard_tail(eng, comm, ranks, shard, dev, n_local, carrier=carrier)
+    def regen(r, n):              # the first n utterances of rank r's block of the SEED_SHARD stream
+        w = torch.empty((n, SAMPLES), device=dev, dtype=torch.float32)
+        eng.synth_waveforms(SEED_SHARD, r * n_local, n, SAMPLES, out=w, async_=True)
+        o = torch.empty((n, eng.embed_dim), device=dev, dtype=torch.float32)
+        eng.embed_wave(w, out=o, async_=True)
+        torch.cuda.synchronize()
+        return o
+    rec, _ = shard_tail(eng, comm, ranks, shard, dev, n_local, carrier=carrier, regen_embed=regen if ranks.launched else None)
     line = None
     if rank == 0:
         total = world * n_local

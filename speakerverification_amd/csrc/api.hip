@@ -75,6 +75,7 @@ struct svhip_handle {
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
+        int r2_slices = -1;       // bf16 Res2Net chain: time slices per utterance (-1: by batch size, 0 / 1: whole utterances, n: forced)
     } opt;
     bool bf16 = false;                        // 16-bit storage handle: bf16, or fp16 when `f16` is set (the flag keeps its round-1 name)
     bool f16 = false;                         // SVHIP_F16: the 16-bit type is IEEE half (RawNet2)
@@ -1049,13 +1050,15 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         } else if (bf && res2net_chain_supported(C, T, h->res2[i][0].dil, h->res2[i][0].Kp)) {
             Res2Params rp;
             rp.H1 = H1; rp.H2 = H2; rp.ld = C; rp.T = T; rp.dil = h->res2[i][0].dil; rp.Kp = h->res2[i][0].Kp;
+            // small batches (the reference's per-file calls: B = num_eval crops): time slices, so that the chip is not left to B workgroups
+            rp.slices = h->opt.r2_slices >= 0 ? std::max(1, h->opt.r2_slices) : res2net_chain_slices(B, C, T, rp.dil, h->num_cu);
             double fl = 0;
             for (int j = 0; j < 7; ++j) {
                 rp.W[j] = h->res2[i][j].W; rp.bias[j] = h->res2[i][j].bias;
                 rp.scale[j] = h->res2[i][j].scale; rp.shift[j] = h->res2[i][j].shift;
                 fl += (double)M * h->res2[i][j].flops_per_row;
             }
-            if ((rc = run(h, "res2net_chain", fl, [&]() { return launch_res2net_chain(rp, B, C, st); }))) return rc;
+            if ((rc = run(h, rp.slices > 1 ? "res2net_slices" : "res2net_chain", fl, [&]() { return launch_res2net_chain(rp, B, C, st); }))) return rc;
         } else {
             if ((rc = run(h, "copy_cols", 0, [&]() { return launch_copy_cols(H1, C, H2, C, bf, M, C8, st); }))) return rc;
             for (int j = 1; j < 8; ++j) {
@@ -1466,7 +1469,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1);
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2206,7 +2209,8 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off}};
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
+        {"r2_slices", &o.r2_slices}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

@@ -166,8 +166,11 @@ struct Res2Params {
     const float* scale[7] = {};
     const float* shift[7] = {};
     int debug = 0;               // tools/res2_bench ablations (only read in -DSVHIP_GEMM_DEBUG builds)
+    int slices = 1;              // > 1: every utterance is cut into this many time slices, one workgroup each (res2net_chain_slices)
+    int Tc = 0;                  // filled by the launcher: core frames per slice
 };
 bool res2net_chain_supported(int C, int T, int dil, int Kp);
+int res2net_chain_slices(int B, int C, int T, int dil, int num_cu);
 hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -22,6 +22,13 @@
 // workgroups started 8 / 16 / 24 k cycles late (s_sleep) so that half of the CUs hit their row passes out of phase with the other
 // half: 0.424 / 0.444 / 0.449 ms per three launches against 0.427 — the bursts are not what the time goes to; the same chain on 16 waves
 // per workgroup (4 m-tiles per wave, 128 VGPRs): 0.46 ms — each weight fragment then feeds 4 MFMAs instead of 7 and the kernel spills.
+//
+// Time slices (round 4, small batches): one workgroup per utterance leaves most of the chip idle at the reference API's own batch size
+// (B = num_eval = 10 - 20 crops of one file: 20 workgroups, ~96 us per launch whatever B is — the chain is seven dependent stages).
+// With Res2Params::slices = S > 1 a workgroup owns the frames [c0, c1) of an utterance plus a halo of 7 * dil frames either side (the
+// dependency cone of seven k = 3 stages): stage j leaves the outermost j * dil halo rows wrong, never a core row; only core rows are
+// stored.  Same arithmetic per row, so the outputs are bit-identical to the whole-utterance form; fewer m-tiles per wave (MIT 3 / 2
+// instead of 7 / 4), 80 / 48 KiB of LDS.  The launcher slices when S * B workgroups still fit the chip at once.
 #include "common.h"
 #include "kernels.h"
 
@@ -36,35 +43,43 @@ constexpr bool R2DBG = false;
 #endif
 constexpr int R2_TMAX = 416;         // 13 MFMA m-tiles; T = 401 for 2 s @ 16 kHz
 
-template <int CW> struct R2Cfg {
+// MIT: m-tiles (32 frames) per wave: 7 / 4 = whole utterances of up to 416 frames, 3 / 2 = time slices of up to 192 / 256 rows
+template <int CW, int MIT> struct R2Cfg {
     static constexpr int ROWB = CW * 2;                 // bytes per LDS row (256 / 128)
     static constexpr int NCH = ROWB / 16;               // 16-byte chunks per row (16 / 8)
-    static constexpr int U_BYTES = R2_TMAX * ROWB;
-    static constexpr int W_BYTES = CW * ROWB;           // one tap: CW rows x CW k
-    static constexpr int LDS = U_BYTES + W_BYTES;       // 136 KiB / 60 KiB
     static constexpr int NT = CW / 32;                  // n-tiles (4 / 2)
     static constexpr int MW = 8 / NT;                   // wave groups along M (2 / 4)
-    static constexpr int MI = (13 + MW - 1) / MW;       // m-tiles per wave (7 / 4)
+    static constexpr int MI = MIT;                      // m-tiles per wave
+    static constexpr int TMAX = MW * MI * 32 < R2_TMAX ? MW * MI * 32 : R2_TMAX;      // rows of the LDS image
+    static constexpr int U_BYTES = TMAX * ROWB;
+    static constexpr int W_BYTES = CW * ROWB;           // one tap: CW rows x CW k
+    static constexpr int LDS = U_BYTES + W_BYTES;       // whole utterances: 136 KiB / 60 KiB; slices: 80 / 48 KiB
     static constexpr int WCH = CW * NCH / 512;          // weight chunks per thread per tap (4 / 1)
     static __device__ __forceinline__ int swz(int row) { return CW == 128 ? (row & 15) : ((row >> 1) & 7); }
 };
 
-template <int CW>
+template <int CW, int MIT>
 __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
-    typedef R2Cfg<CW> CF;
+    typedef R2Cfg<CW, MIT> CF;
     constexpr int ROWB = CF::ROWB, NCH = CF::NCH, MI = CF::MI, WCH = CF::WCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* U = smem;
     char* Wt = smem + CF::U_BYTES;
 
-    const int b = blockIdx.x;
-    const int T = p.T;
+    // the rows this workgroup holds: local row r <-> frame l0 + r of utterance b; it stores the core frames [c0, c1)
+    const int S = p.slices > 1 ? p.slices : 1;
+    const int b = (int)blockIdx.x / S, si = (int)blockIdx.x - b * S;
+    const int Tg = p.T;                                 // frames of the utterance (reflect padding acts at ITS ends)
+    const int c0 = S > 1 ? si * p.Tc : 0, c1 = S > 1 ? min(Tg, c0 + p.Tc) : Tg;
+    const int l0 = S > 1 ? max(0, c0 - 7 * p.dil) : 0, l1 = S > 1 ? min(Tg, c1 + 7 * p.dil) : Tg;
+    const int T = l1 - l0;                              // local rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % CF::NT, wq = wave / CF::NT;
     const int fr = lane & 31, fh = lane >> 5;
-    const bf16_t* __restrict__ H1 = reinterpret_cast<const bf16_t*>(p.H1) + (int64_t)b * T * p.ld;
-    bf16_t* __restrict__ H2 = reinterpret_cast<bf16_t*>(p.H2) + (int64_t)b * T * p.ld;
+    const bf16_t* __restrict__ H1 = reinterpret_cast<const bf16_t*>(p.H1) + ((int64_t)b * Tg + l0) * p.ld;
+    bf16_t* __restrict__ H2 = reinterpret_cast<bf16_t*>(p.H2) + ((int64_t)b * Tg + l0) * p.ld;
+    const int s0 = c0 - l0, s1 = c1 - l0;               // local rows that are stored
 
     // ---- weight slab prefetch (global -> registers), write (registers -> LDS) ----------------------
     u32x4 wregs[WCH];
@@ -100,19 +115,19 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
         const char* h1b = reinterpret_cast<const char*>(H1);
         char* h2b = reinterpret_cast<char*>(H2);
         for (int it0 = 0; it0 * RSTEP < T; it0 += RB0) {
-            u32x4 c0[RB0], c1[RB0];
+            u32x4 cc0[RB0], cc1[RB0];
 #pragma unroll
             for (int k = 0; k < RB0; ++k)
                 if (row0 + (it0 + k) * RSTEP < T) {
-                    c0[k] = *reinterpret_cast<const u32x4*>(h1b + goff0 + (uint32_t)(it0 + k) * gstep);
-                    c1[k] = *reinterpret_cast<const u32x4*>(h1b + CW * 2 + goff0 + (uint32_t)(it0 + k) * gstep);
+                    cc0[k] = *reinterpret_cast<const u32x4*>(h1b + goff0 + (uint32_t)(it0 + k) * gstep);
+                    cc1[k] = *reinterpret_cast<const u32x4*>(h1b + CW * 2 + goff0 + (uint32_t)(it0 + k) * gstep);
                 }
 #pragma unroll
             for (int k = 0; k < RB0; ++k) {
                 const int row = row0 + (it0 + k) * RSTEP;
                 if (row < T) {
-                    *reinterpret_cast<u32x4*>(h2b + goff0 + (uint32_t)(it0 + k) * gstep) = c0[k];
-                    *reinterpret_cast<u32x4*>(U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4)) = c1[k];
+                    if (row >= s0 && row < s1) *reinterpret_cast<u32x4*>(h2b + goff0 + (uint32_t)(it0 + k) * gstep) = cc0[k];
+                    *reinterpret_cast<u32x4*>(U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4)) = cc1[k];
                 }
             }
         }
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 
         constexpr int RSTEP = 512 / NCH;                            // rows per trip of the whole workgroup (32 / 64)
         constexpr int RB = 7;                                       // row chunks per thread per group
-        constexpr int NPRE = (R2_TMAX / RSTEP + RB - 1) / RB * RB;  // row chunks per thread: 14 / 7
+        constexpr int NPRE = (CF::TMAX / RSTEP + RB - 1) / RB * RB; // row chunks per thread: 14 / 7 (slices: 7 / 7)
         const bool noglob = R2DBG && (p.debug & 1);
 
         // every row chunk of c_{s+1} is requested before the last tap's MFMAs and consumed in the row pass below
@@ -160,7 +175,9 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int t = (wq + CF::MW * i) * 32 + fr_t + delta;
-                const int row = min(reflect_idx(t, T), T - 1);
+                // reflect at the ends of the UTTERANCE; rows outside this slice's image are clamped (they only feed halo rows
+                // that are already outside the dependency cone of the core)
+                const int row = min(max(reflect_idx(l0 + t, Tg) - l0, 0), T - 1);
                 rbase[i] = row * ROWB;
                 rsw[i] = CF::swz(row);
             }
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
                 const int row = c / NCH, ch = c % NCH;
                 char* up = U + row * ROWB + ((ch ^ CF::swz(row)) << 4);
                 const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
-                *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
+                if (row >= s0 && row < s1) *reinterpret_cast<bf16x8*>(H2 + (int64_t)row * p.ld + s * CW + ch * 8) = y;
                 if (s < 7) {
                     const bf16x8 cn = *reinterpret_cast<const bf16x8*>(H1 + (int64_t)row * p.ld + (s + 1) * CW + ch * 8);
                     bf16x8 u;
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
                         if (row < T) {
                             char* up = U + row * ROWB + ((ch0 ^ CF::swz(row)) << 4);
                             const bf16x8 y = *reinterpret_cast<const bf16x8*>(up);
-                            if (!noglob) *reinterpret_cast<bf16x8*>(h2s + goff0 + (uint32_t)(it0 + k) * gstep) = y;
+                            if (!noglob && row >= s0 && row < s1) *reinterpret_cast<bf16x8*>(h2s + goff0 + (uint32_t)(it0 + k) * gstep) = y;
                             if (s < 7 && !noglob) {
                                 const bf16x8 cv = __builtin_bit_cast(bf16x8, cpre[it0 + k]);
                                 bf16x8 u;
@@ -266,24 +283,46 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
     }
 }
 
-template <int CW>
-hipError_t launch_cw(const Res2Params& p, int B, hipStream_t stream) {
+template <int CW, int MIT>
+hipError_t launch_cw(const Res2Params& p, int grid, hipStream_t stream) {
     static DeviceOnce attr;
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(res2net_chain_kernel<CW>), R2Cfg<CW>::LDS)) return e;
-    hipLaunchKernelGGL(res2net_chain_kernel<CW>, dim3(B), dim3(512), R2Cfg<CW>::LDS, stream, p);
+    constexpr int lds = R2Cfg<CW, MIT>::LDS;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(res2net_chain_kernel<CW, MIT>), lds)) return e;
+    hipLaunchKernelGGL((res2net_chain_kernel<CW, MIT>), dim3(grid), dim3(512), lds, stream, p);
     return hipGetLastError();
 }
 
 }  // namespace
+
+// time slices for small batches: the smallest S >= 2 whose slices (core + two halos of 7 * dil frames) fit the short LDS image and whose
+// S * B workgroups are all resident at once (two per CU: 80 / 48 KiB of LDS each); 1 = whole utterances
+int res2net_chain_slices(int B, int C, int T, int dil, int num_cu) {
+    const int cw = C / 8;
+    const int tmax_s = cw == 128 ? R2Cfg<128, 3>::TMAX : R2Cfg<64, 2>::TMAX;
+    for (int S = 2; S <= 8; ++S) {
+        const int tc = (T + S - 1) / S;
+        if ((int64_t)S * B > (int64_t)num_cu) break;
+        if (tc + 14 * dil <= tmax_s && tc > 14 * dil) return S;
+    }
+    return 1;
+}
 
 bool res2net_chain_supported(int C, int T, int dil, int Kp) {
     const int cw = C / 8;
     return (cw == 64 || cw == 128) && T <= R2_TMAX && T > 2 * dil && Kp == 3 * cw;
 }
 
-hipError_t launch_res2net_chain(const Res2Params& p, int B, int C, hipStream_t stream) {
-    if (!res2net_chain_supported(C, p.T, p.dil, p.Kp) || B <= 0 || p.ld % 8 != 0) return hipErrorInvalidValue;
-    return C / 8 == 128 ? launch_cw<128>(p, B, stream) : launch_cw<64>(p, B, stream);
+hipError_t launch_res2net_chain(const Res2Params& p_in, int B, int C, hipStream_t stream) {
+    if (!res2net_chain_supported(C, p_in.T, p_in.dil, p_in.Kp) || B <= 0 || p_in.ld % 8 != 0) return hipErrorInvalidValue;
+    Res2Params p = p_in;
+    if (p.slices > 1) {
+        const int tmax_s = C / 8 == 128 ? R2Cfg<128, 3>::TMAX : R2Cfg<64, 2>::TMAX;
+        p.Tc = (p.T + p.slices - 1) / p.slices;
+        if (p.Tc + 14 * p.dil > tmax_s || p.Tc <= 14 * p.dil) return hipErrorInvalidValue;
+        return C / 8 == 128 ? launch_cw<128, 3>(p, B * p.slices, stream) : launch_cw<64, 2>(p, B * p.slices, stream);
+    }
+    p.slices = 1;
+    return C / 8 == 128 ? launch_cw<128, 7>(p, B, stream) : launch_cw<64, 4>(p, B, stream);
 }
 
 }  // namespace svhip

@@ -296,6 +296,12 @@ class Engine:
         self._ck(self.lib.svhip_comm_init(self.h, C.create_string_buffer(id_bytes, _lib.COMM_ID_BYTES), int(rank), int(world)))
         self.comm_rank, self.comm_world = int(rank), int(world)
 
+    def comm_rank_world(self):
+        """(rank, world) as the library's RCCL communicator reports them (svhip_comm_rank)"""
+        r, w = C.c_int32(), C.c_int32()
+        self._ck(self.lib.svhip_comm_rank(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def allgather_rows(self, local, out=None, async_=False):
         """(rows, D) fp32 block of every rank -> (world * rows, D) on every rank: ONE RCCL all-gather on the handle's stream."""
         rows, D = local.shape

@@ -387,3 +387,27 @@ def test_f32x3_res2net_step_kernels_agree(monkeypatch, T, B, cus):
     errs["emb"] = float(np.abs(st["small"][0] - st["big"][0]).max()) / max(1.0, float(np.abs(st["big"][0]).max()))
     print(f"T={T} B={B} r2_step vs gemm_pw3r2:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["emb"] <= 3e-5 and max(errs.values()) <= 1e-4, errs
+
+
+@pytest.mark.parametrize("C,T_samples,B", [(1024, 32000, 5), (512, 32000, 3), (1024, 24000, 2), (256, 32000, 4)])
+def test_res2net_time_slices_match_whole_utterances(C, T_samples, B):
+    """Round 4 (small batches, the reference API's own operating point: embed_utterance embeds num_eval = 10 - 20 crops of ONE file per
+    call, src/model.py:675-704): the fused Res2Net chain cuts every utterance into time slices with a halo of 7 * dilation frames
+    (the dependency cone of seven k = 3 stages) when a batch would leave most of the chip idle.  A core row sees the same operands in
+    the same order as in the whole-utterance kernel: block outputs and embeddings must agree BIT FOR BIT (option r2_slices: 0 =
+    whole utterances, 3 = forced, -1 = by batch size)."""
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=3)
+    wav = synth.synth_waveforms(B, T_samples, seed=14)
+    eng = Engine(model="ecapa", compute="bf16", channels=C, max_batch=B, samples=T_samples)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    outs = {}
+    for mode in (0, 3, -1):
+        eng.set_option("r2_slices", mode)
+        emb = eng.embed_wave(wav)
+        outs[mode] = (emb.copy(), eng.get_stage("blocks.1").copy(), eng.get_stage("blocks.3").copy())
+    eng.close()
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][1]).max() > 0
+    for mode in (3, -1):
+        for a, b in zip(outs[0], outs[mode]):
+            np.testing.assert_array_equal(a, b)

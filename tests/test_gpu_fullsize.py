@@ -48,6 +48,14 @@ def test_utterances_do_not_see_their_batch(big):
     assert cos_rows(small, full[:8]).min() >= 0.99995
     one = eng.embed_wave(wav[100:101])
     assert cos_rows(one, full[100:101]).min() >= 0.99995
+    # the reference API's own batch (embed_utterance: num_eval = 10 - 20 crops of one file per call, src/model.py:675-704) takes the
+    # small-batch routes (time-sliced Res2Net chain, 16-wave small-M linears): the same rows to bf16 round-off
+    eng.profile(True)
+    twenty = eng.embed_wave(wav[40:60])
+    labels = eng.profile_results()
+    eng.profile(False)
+    assert "res2net_slices" in labels and "res2net_chain" not in labels, sorted(labels)
+    assert cos_rows(twenty, full[40:60]).min() >= 0.99995
 
 
 def test_bf16_full_batch_tracks_the_fp32_path(big):
@@ -118,7 +126,7 @@ def test_bench_shard_path_at_world_one(capsys):
     import bench
     from oracle import synthwave as o_synth
     args = argparse.Namespace(gpus=1, steps=1, warmup=1, compute="bf16", batch=256, model="ecapa", config="shard", utts_per_gpu=2000,
-                              no_cpu_baseline=True, no_scoring=False, no_extras=True)
+                              no_cpu_baseline=True, no_scoring=False, no_extras=True, allow_gloo=False, sustain_seconds=0.0)
     dev = torch.device("cuda", 0)
     ranks = bench.Ranks(args)
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
@@ -193,7 +201,7 @@ def test_profile_filter_brackets_only_the_named_kernel():
     eng.profile(True)
     eng.embed_wave(wav)
     every = eng.profile_results()
-    assert {"fbank", "gemm_pw2", "res2net_chain", "asp_bf16", "se_apply"} <= set(every)
+    assert {"fbank", "gemm_pw2", "res2net_slices", "asp_bf16", "se_apply"} <= set(every)         # (B = 8: the time-sliced chain)
     assert every["gemm_pw2"]["launches"] == only["gemm_pw2"]["launches"]
     eng.profile(False)
     eng.embed_wave(wav)

@@ -340,3 +340,62 @@ def test_primary_engine_geometry_comes_from_the_configured_crop_length():
     assert m._primary == 32000
     assert ECAPA_TDNN.MainModel(nOut=192, channels=[64] * 4 + [192])._primary is None          # unknown until the first call
     assert RawNet2_custom.MainModel(nOut=320, front_proc="sinc", aggregate="asp", audio_spec=spec)._primary == 32000
+
+
+def _verify_gather_worker(rank, world, port, corrupt, q):
+    """bench.verify_gather on CPU tensors over gloo: the check the N-GPU bench runs on its gathered embedding matrix"""
+    import argparse
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ranks = bench.Ranks(argparse.Namespace(gpus=world))
+    try:
+        n_local, D = 37, 24
+
+        def embed(utt):                      # a pure function of the utterance index, like the synthetic stream + the engine
+            g = torch.Generator().manual_seed(1000 + int(utt))
+            return torch.randn(D, generator=g)
+
+        shard = torch.stack([embed(rank * n_local + i) for i in range(n_local)])
+        blocks = [torch.zeros_like(shard) for _ in range(world)]
+        ranks.dist.all_gather(blocks, shard)
+        gathered = torch.cat(blocks)
+        if corrupt == "bytes" and rank == 1:
+            gathered[2 * n_local + 5, 3] += 1e-3           # one word of rank 2's block arrives wrong on rank 1 only
+        if corrupt == "swap":                               # every rank sees ranks 1 and 2 exchanged: checksums of the blocks disagree
+            gathered = torch.cat([blocks[0], blocks[2], blocks[1]])
+        if corrupt == "content":                            # bytes arrive intact, but rank 2 embedded the WRONG utterances
+            pass
+        regen = lambda r, n: torch.stack([embed(r * n_local + i + (7 if (corrupt == "content" and r == 2) else 0)) for i in range(n)])
+        rec = bench.verify_gather(ranks, shard, gathered, n_local, regen)
+        q.put((rank, rec))
+    finally:
+        ranks.close()
+
+
+@pytest.mark.parametrize("corrupt", ["none", "bytes", "swap", "content"])
+def test_bench_cross_rank_verification_at_world_three(corrupt):
+    """at N > 1 the bench must prove that the OTHER ranks' blocks arrived (it only checked its own).  Three gloo
+    ranks on the CPU: the clean exchange passes; a flipped word on one rank, two blocks exchanged, and a rank that embedded the wrong
+    utterances each make `cross_rank_ok` false on EVERY rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + {"none": 0, "bytes": 1, "swap": 2, "content": 3}[corrupt]
+    procs = [ctx.Process(target=_verify_gather_worker, args=(r, 3, port, corrupt, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    recs = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert recs[r]["cross_rank_ok"] == (corrupt == "none"), (corrupt, recs)
+        assert len(recs[r]["block_checksums"]) == 3
+    assert recs[0]["cross_rank_rows_checked"] == 16 and recs[1]["cross_rank_rows_checked"] == 0
+    if corrupt == "none":
+        assert all(recs[r]["blocks_bitwise_ok"] for r in range(3)) and recs[0]["cross_rank_min_cosine"] > 0.99999
+    if corrupt == "bytes":
+        assert [recs[r]["blocks_bitwise_ok"] for r in range(3)] == [True, False, True]
+    if corrupt == "content":
+        assert all(recs[r]["blocks_bitwise_ok"] for r in range(3)) and recs[0]["cross_rank_min_cosine"] < 0.9
