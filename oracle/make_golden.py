@@ -320,6 +320,76 @@ def golden_e2e(ref):
     print("e2e fixture: scores", out["scores_ne2"][:4], "...")
 
 
+def golden_e2e_speakers(ref):
+    """A second end-to-end case with SENSITIVE scores (tests/e2e_data.py: four synthetic speakers, asp_bn statistics calibrated to the
+    files): the reference's ModelHandling.evaluateFromList (cosine), prepare('cohorts') and, on the reference's own embeddings, its
+    ZT_norm_similarity per trial.  The calibrated asp_bn statistics are part of the fixture (inputs are data)."""
+    import tempfile
+
+    import model as ref_model                     # reference src/model.py (the stubs of golden_e2e are installed)
+    from tests.e2e_data import make_e2e_speaker_files, E2E2_SEED_W
+    tmp = tempfile.mkdtemp(prefix="svhip_e2e2_")
+    files, trial_path, lines = make_e2e_speaker_files(tmp)
+    C = 512
+    args = dict(
+        device="cpu", gpu=0, model={"name": "ECAPA_TDNN", "nOut": 192},
+        criterion={"name": "AAmSoftmaxAP", "margin": 0.25, "scale": 30},
+        classifier={"input_size": 192, "out_neurons": 10},
+        optimizer={"name": "adam", "weight_decay": 2e-5, "lr_decay": 0.95},
+        callbacks={"name": "steplr"}, features="melspectrogram", include_top=False, n_mels=80, nClasses=10,
+        lr=0.001, step_size=10, channels=[C] * 4 + [3 * C],
+        dataloader_options={"nPerSpeaker": 2, "num_workers": 0, "batch_size": 2},
+        audio_spec={"sample_rate": 16000, "channels": 1, "sentence_len": 2.0, "win_len": 0.025, "hop_len": 0.01},
+        augment=False, augment_options={"augment_chain": []}, save_folder=tmp,
+    )
+    enc = ref_model.SpeakerEncoder(**args)
+    net = ref_model.WrappedModel(enc)
+    mh = ref_model.ModelHandling(net, **args)
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=E2E2_SEED_W)
+    enc.__S__.load_state_dict(torch_sd(sd), strict=True)
+    net.eval()           # (embed_utterance alone does not leave training mode; evaluateFromList / testFromList do)
+    # calibrate asp_bn to the pooled statistics of these files (what training would have done): hook the reference's asp module
+    pooled = []
+    hk = dict(enc.__S__.named_modules())["asp"].register_forward_hook(lambda m, i, o: pooled.append(o.detach().reshape(o.shape[0], -1)))
+    for f in files:
+        mh.embed_utterance(f, num_eval=2, normalize=False)
+    hk.remove()
+    P = torch.cat(pooled).double()
+    mu = P.mean(0)
+    var = P.var(0, unbiased=False) + 1e-3 * float(P.abs().mean()) ** 2
+    sd["asp_bn.norm.running_mean"] = mu.float().numpy()
+    sd["asp_bn.norm.running_var"] = var.float().numpy()
+    enc.__S__.load_state_dict(torch_sd(sd), strict=True)
+    net.eval()
+    out = {"asp_bn_running_mean": sd["asp_bn.norm.running_mean"], "asp_bn_running_var": sd["asp_bn.norm.running_var"]}
+    sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options=args["dataloader_options"],
+                                      cohorts_path="unused", num_eval=2, scoring_mode="cosine")
+    out["scores_ne2"] = np.array(sc, np.float64)
+    out["labels_ne2"] = np.array(lab, np.int64)
+    embs = {f: mh.embed_utterance(f, num_eval=2, normalize=False) for f in files}
+    out["embeddings_ne2"] = np.stack([embs[f].numpy() for f in files])
+    meta = os.path.join(tmp, "train_meta.txt")
+    with open(meta, "w") as fh:
+        fh.writelines(f"spk{i // 2} {f}\n" for i, f in enumerate(files))
+    cohort_path = os.path.join(tmp, "cohort.npy")
+    assert mh.prepare(save_path=cohort_path, prepare_type="cohorts", num_eval=2, source=meta) is True
+    cohort = np.load(cohort_path)
+    out["cohort_ne2"] = cohort
+    zt = []
+    for ln in lines:
+        _, a, b = ln.split()
+        r = torch.nn.functional.normalize(embs[a], p=2, dim=1)
+        c = torch.nn.functional.normalize(embs[b], p=2, dim=1)
+        zt.append(ref.utils.similarity_measure("zt_norm", r, c, cohorts=cohort, top=3))
+    out["zt_norm_top3"] = np.array(zt, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "e2e_speakers.npz"), **out)
+    s_ = out["scores_ne2"]
+    same = s_[out["labels_ne2"] == 1]
+    print("e2e speakers fixture: cosine scores span %.3f .. %.3f (same-speaker %.3f .. %.3f); zt_norm span %.2f .. %.2f"
+          % (s_.min(), s_.max(), same.min(), same.max(), min(zt), max(zt)))
+    assert s_.max() - s_.min() >= 0.3
+
+
 def golden_fusion(ref):
     """Raw_ECAPA_sinc_asp (the repo's fusion model, next row SURVEY 8f-3): ECAPA C=512 on raw mel power
     (features='raw': NO log / mean-norm, ECAPA_TDNN.py:473) concatenated with RawNet2 sinc/asp (512-192 dims)."""
@@ -373,6 +443,12 @@ def main():
         import traceback
         traceback.print_exc()
         print("e2e fixture skipped:", repr(e))
+    try:
+        golden_e2e_speakers(ref)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        print("e2e speakers fixture skipped:", repr(e))
     try:
         golden_fusion(ref)
     except Exception as e:  # pragma: no cover

@@ -128,3 +128,56 @@ def test_evaluate_from_list_f32x3_matches_reference(tmp_path, golden_dir):
     err = float(np.abs(np.array(sc) - g["scores_ne2"]).max())
     print("f32x3 e2e cosine score error", err)
     assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("compute", ["f32", "f32x3"])
+def test_speaker_fixture_with_sensitive_scores_matches_reference(tmp_path, golden_dir, compute):
+    """the 28 golden scores of the config-1 case span 0.9970 - 0.9996, so a plumbing error worth less than 1e-3
+    of cosine would pass it.  This case (tests/e2e_data.py: four synthetic speakers x two files, asp_bn statistics calibrated to
+    the files as a trained BatchNorm's would be; generated by the REFERENCE'S ModelHandling in oracle/make_golden.py) has cosine
+    scores from 0.05 to 0.78, same-speaker pairs on top: swapped files, a wrong crop or a wrong crop mean move a score by tenths.
+    The calibrated BatchNorm divides the pooled statistics by their small spread over the files (~50 x amplification), so this is
+    also the hardest fixture for the arithmetic: measured, exact fp32 is within 3.3e-6 of the reference's scores and the split-bf16
+    mode (2^-17 per product) within 2.6e-5 — both are held to north_star's 1e-4."""
+    import torch
+    from speakerverification_amd import scoring
+    from tests.e2e_data import E2E2_SEED_W, make_e2e_speaker_files
+    tmp = str(tmp_path)
+    g = np.load(os.path.join(golden_dir, "e2e_speakers.npz"))
+    args = dict(ARGS, hip_compute=compute, save_folder=tmp)
+    net = WrappedModel(SpeakerEncoder(**args))
+    mh = ModelHandling(net, **args)
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E2_SEED_W)
+    sd["asp_bn.norm.running_mean"] = g["asp_bn_running_mean"]
+    sd["asp_bn.norm.running_var"] = g["asp_bn_running_var"]
+    net.module.load_state_dict({"__S__." + k: v for k, v in sd.items()})
+    files, trial_path, lines = make_e2e_speaker_files(tmp)
+    sc, lab, tr = mh.evaluateFromList(listfilename=trial_path, distributed=False, dataloader_options={}, cohorts_path="unused",
+                                      num_eval=2, scoring_mode="cosine")
+    ref = g["scores_ne2"]
+    assert lab == list(g["labels_ne2"]) and len(sc) == 28
+    assert ref.max() - ref.min() >= 0.3 and ref[g["labels_ne2"] == 1].min() > ref[g["labels_ne2"] == 0].max() - 0.3      # the fixture IS sensitive
+    err = float(np.abs(np.array(sc) - ref).max())
+    emb = np.stack([mh.embed_utterance(f, num_eval=2, normalize=False).numpy() for f in files])
+    e_err = float(np.abs(emb - g["embeddings_ne2"]).max() / np.abs(g["embeddings_ne2"]).max())
+    # a mixed-up file order or crop would show here as O(0.1): the check that the scores are attached to the right trials
+    shuffled = np.abs(np.array(sc) - ref[::-1]).max()
+    print(f"{compute}: speaker fixture: cosine score error {err:.2e}, embedding error / scale {e_err:.2e} (reversed trial list would give {shuffled:.2f})")
+    bar = 1e-4
+    assert err <= bar and e_err <= bar and shuffled > 0.1
+    # cohort preparation (speaker means) and AS-norm over this cohort, top 3 of 4: the reference's ZT_norm_similarity per trial
+    meta = os.path.join(tmp, "train_meta.txt")
+    with open(meta, "w") as fh:
+        fh.writelines(f"spk{i // 2} {f}\n" for i, f in enumerate(files))
+    cpath = os.path.join(tmp, "cohort.npy")
+    assert mh.prepare(save_path=cpath, prepare_type="cohorts", num_eval=2, source=meta) is True
+    cohort = np.load(cpath)
+    assert float(np.abs(cohort - g["cohort_ne2"]).max()) <= bar
+    feats = torch.nn.functional.normalize(torch.from_numpy(emb), p=2, dim=2).numpy()
+    index = {f: i for i, f in enumerate(files)}
+    ia = [index[ln.split()[1]] for ln in lines]
+    ib = [index[ln.split()[2]] for ln in lines]
+    zt = scoring.score_trials(feats, ia, ib, "norm", cohorts=g["cohort_ne2"], top=3)
+    z_err = float(np.abs(np.asarray(zt) - g["zt_norm_top3"]).max())
+    print(f"{compute}: AS-norm (top 3 of 4) error {z_err:.2e} on scores spanning {g['zt_norm_top3'].min():.2f} .. {g['zt_norm_top3'].max():.2f}")
+    assert z_err <= 50 * bar           # (s - mu) / sigma with sigma ~ 0.1 - 0.3 over three cohort scores

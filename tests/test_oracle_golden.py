@@ -203,3 +203,35 @@ def test_fbank_definition_of_record_is_frozen(golden_dir):
         assert r64.shape == g[name + "_f64"].shape
         assert np.abs(r64 - g[name + "_f64"]).max() <= 1e-12 * peak, name
         assert np.abs(r32 - g[name + "_f32"]).max() <= 2e-6 * peak, name      # fp32 conv summation order may differ across hosts
+
+
+def test_oracle_reproduces_the_speaker_fixture_end_to_end(golden_dir, tmp_path):
+    """tests/golden/e2e_speakers.npz (the reference's ModelHandling on four synthetic speakers, asp_bn calibrated to the files:
+    cosine scores 0.05 - 0.78) against the oracle chain on the CPU: WAV -> eval-mode crops (speakerverification_amd.audio, pinned by
+    crop.npz) -> oracle fbank -> oracle ECAPA -> L2-normalise -> mean |cos| over aligned crops.  Pins the oracle (not the product)
+    on a fixture whose scores are sensitive to file order, cropping and crop means."""
+    from speakerverification_amd import audio
+    from tests.e2e_data import E2E2_SEED_W, make_e2e_speaker_files
+    g = np.load(os.path.join(golden_dir, "e2e_speakers.npz"))
+    files, trial_path, lines = make_e2e_speaker_files(str(tmp_path))
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=E2E2_SEED_W)
+    sd["asp_bn.norm.running_mean"] = g["asp_bn_running_mean"]
+    sd["asp_bn.norm.running_var"] = g["asp_bn_running_var"]
+    tsd = o_ecapa.to_torch_sd(sd)
+    torch.set_num_threads(8)
+    embs = {}
+    with torch.no_grad():
+        for f in files:
+            crops = audio.loadWAV(f, {"sample_rate": 16000, "sentence_len": 2.0}, evalmode=True, num_eval=2)
+            mel = o_fbank.melspectrogram(torch.from_numpy(np.asarray(crops, np.float32)))
+            embs[f] = o_ecapa.ecapa_forward(mel, tsd)
+    got = np.stack([embs[f].numpy() for f in files])
+    assert float(np.abs(got - g["embeddings_ne2"]).max()) <= 1e-4 * float(np.abs(g["embeddings_ne2"]).max())
+    sc = []
+    for ln in lines:
+        _, a, b = ln.split()
+        r = torch.nn.functional.normalize(embs[a], p=2, dim=1)
+        c = torch.nn.functional.normalize(embs[b], p=2, dim=1)
+        sc.append(o_scoring.cosine_similarity(r, c))
+    assert float(np.abs(np.array(sc) - g["scores_ne2"]).max()) <= 1e-5
+    assert g["scores_ne2"].max() - g["scores_ne2"].min() >= 0.3
