@@ -1766,6 +1766,25 @@ int scratch(svhip_handle* h, int slot, size_t bytes, void** out) {
     *out = h->scr[slot];
     return SVHIP_OK;
 }
+// Scratch retention policy: the slab of the AS-norm slab path (up to 2 GiB) and the staging copies of HOST-pointer calls
+// (N x D x 4 bytes for the embedding matrix) are released at the end of the call once they exceed 256 MiB — they would otherwise sit
+// beside the model engines' workspaces for the life of the process-wide scoring handle.  The slots of the device-resident fast path
+// (candidate lists, cohort planes: re-used every call) stay; svhip_trim_scratch frees everything.
+void release_big_scratch(svhip_handle* h, bool staged_host) {
+    const size_t cap = (size_t)256 << 20;
+    auto drop = [&](int slot) {
+        if (h->scr[slot] && h->scr_cap[slot] > cap) {
+            (void)hipStreamSynchronize(h->stream);
+            if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+            (void)hipFree(h->scr[slot]);
+            h->scr[slot] = nullptr; h->scr_cap[slot] = 0;
+        }
+    };
+    drop(svhip_handle::SCR_SLAB);
+    if (staged_host)
+        for (int s_ : {svhip_handle::SCR_IN0, svhip_handle::SCR_IN1, svhip_handle::SCR_IN2, svhip_handle::SCR_IN3, svhip_handle::SCR_IN4,
+                       svhip_handle::SCR_OUT0, svhip_handle::SCR_OUT1, svhip_handle::SCR_OUT2, svhip_handle::SCR_SPLIT}) drop(s_);
+}
 struct TempBuf {      // device staging for host-pointer calls, in a scratch slot of the handle
     svhip_handle* h; int slot;
     int in(const void* src, size_t bytes, bool is_dev, const void** out) {
@@ -2001,7 +2020,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             fp.E = (const float*)dE + r0 * D; fp.N = rows;
             fp.cand = (float*)cand + b * cand_elems; fp.cnt = (int32_t*)cnt + b * cnt_elems;
             if (nbuf == 2 && c >= 2) SV_HIP(h, hipStreamWaitEvent(h->stream, h->aux_ev[2 + b], 0));       // the statistics of chunk c - 2 have read this buffer
-            if ((rc = run(h, "asnorm_fused", 2.0 * rows * K * D, [&]() { return launch_asnorm_fused(fp, D, h->stream); }))) return rc;
+            if ((rc = run(h, "asnorm_fused", 2.0 * rows * K * D, [&]() { return launch_asnorm_fused(fp, D, h->stream); }))) {
+                if (nbuf == 2 && h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+                return rc;
+            }
             hipStream_t st2 = h->stream;
             if (nbuf == 2) {
                 SV_HIP(h, hipEventRecord(h->aux_ev[b], h->stream));
@@ -2013,7 +2035,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                 return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2);
             });
             h->cur = h->stream;
-            if (rc) return rc;
+            if (rc) {           // leave no aux-stream work pending behind a failed call
+                if (nbuf == 2) (void)hipStreamSynchronize(h->aux_stream);
+                return rc;
+            }
             if (nbuf == 2) SV_HIP(h, hipEventRecord(h->aux_ev[2 + b], h->aux_stream));
         }
         if (nbuf == 2) for (int b = 0; b < std::min(c, 2); ++b) SV_HIP(h, hipStreamWaitEvent(h->stream, h->aux_ev[2 + b], 0));
@@ -2042,7 +2067,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         SV_HIP(h, hipMemcpyAsync(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
         SV_HIP(h, hipMemcpyAsync(sigma, dS, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
     }
-    if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
+    if (!(din && dout && (flags & SVHIP_ASYNC))) {
+        SV_HIP(h, hipStreamSynchronize(h->stream));
+        release_big_scratch(h, !din || !dout);
+    }
     return SVHIP_OK;
 }
 

@@ -80,7 +80,14 @@ def score_trials(feats, ia, ib, mode="cosine", cohorts=None, top=200, device=0):
     ib = np.ascontiguousarray(ib, dtype=np.int32)
     eng = scoring_engine(device)
     if len(ia) == 0:
+        if on_dev:
+            import torch
+            return torch.zeros((0,), dtype=torch.float32, device=feats.device)
         return np.zeros((0,), np.float32)
+    # the C ABI range-checks host indices only; on the device-resident path they are uploaded first, so the check happens here (O(P))
+    n_files = int(feats.shape[0])
+    if int(ia.min()) < 0 or int(ib.min()) < 0 or int(ia.max()) >= n_files or int(ib.max()) >= n_files:
+        raise ValueError(f"trial indexes outside [0, {n_files})")
     if on_dev:                                # indices follow the embeddings into HBM (8 P bytes over PCIe)
         feats = feats.contiguous()
         ia, ib = _engine.to_device(ia, feats.device.index), _engine.to_device(ib, feats.device.index)

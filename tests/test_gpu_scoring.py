@@ -241,6 +241,14 @@ def test_fused_asnorm_at_scale():
     rmu, rsd = o_scoring.asnorm_stats(E[idx].cpu().numpy(), cohort.cpu().numpy(), top)
     assert float(np.abs(mu[idx].cpu().numpy() - rmu).max()) <= 1e-6
     assert float(np.abs(sd[idx].cpu().numpy() - rsd).max() / rsd.min()) <= 1e-4
+    # the TWO-STREAM form of the fused path (candidate statistics of chunk c on a second stream under the MFMA kernel of
+    # chunk c + 1: aux stream, four events, two candidate buffers) runs only for N > 131 072 with the fp32-MFMA form — three chunks here
+    eng.set_option("asnorm_f32mfma", 1)
+    mu3, sd3 = eng.asnorm_stats(E, cohort, top)
+    eng.set_option("asnorm_f32mfma", 0)
+    assert eng.asnorm_last_fallback == 0
+    assert float((mu3 - mu).abs().max()) <= 5e-7 and float((sd3 - sd).abs().max()) <= 5e-7
+    assert float(np.abs(mu3[idx].cpu().numpy() - rmu).max()) <= 1e-6
     eng.set_option("asnorm_slab", 1)            # (the environment is only read when a handle is created)
     mu2, sd2 = eng.asnorm_stats(E[:50_000], cohort, top)
     eng.set_option("asnorm_slab", 0)

@@ -28,7 +28,11 @@ def label(name):
     a = [x.strip() for x in args.strip("<>").split(",")] if args else []
     lb = base[:-len("_kernel")]
     if base == "gemm_pw3_kernel" and len(a) >= 4:
-        lb = "gemm_pw3r2" if a[3] in ("true", "1") else "gemm_pw3x3" if a[2] in ("true", "1") else "gemm_pw3"
+        cv = len(a) >= 5 and a[4] in ("true", "1")
+        x3 = a[2] in ("true", "1")
+        lb = "gemm_pw3r2" if a[3] in ("true", "1") else ("gemm_pw3cv" if cv else "gemm_pw3x3") if x3 else "gemm_pw3cv16" if cv else "gemm_pw3"
+    elif base == "res2net_chain_kernel" and len(a) >= 2 and a[1] in ("3", "2"):
+        lb = "res2net_slices"
     elif base == "gemm_pw2_kernel" and len(a) >= 3 and a[2] in ("true", "1"):
         lb = "gemm_pw2_conv"
     elif base == "gemm_kernel":
