@@ -71,7 +71,9 @@ struct svhip_handle {
         int rn_snap = -1;         // RawNet2: keep block n's pre-activation as stage "rn_snap"
         int rn_unfused = 0;       // RawNet2: the separate kernel sequence instead of rn_block128 / rn_tail / the folded shortcut
         int asnorm_slab = 0;      // AS-norm statistics on the slab path
-        int asnorm_f32mfma = 0;   // AS-norm fused kernel on the exact fp32 MFMA instead of six bf16 MFMAs
+        int asnorm_f32mfma = 0;   // AS-norm fused kernel on the exact fp32 MFMA instead of a split form
+        int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
+        int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
@@ -236,6 +238,24 @@ inline uint16_t f32_to_bf16_rne(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// host twin of common.h's x3_hi / x3_lo: a weight as (hi << 16) | lo in the planes' type (IEEE half; bf16 under -DSVHIP_X3_BF16)
+inline uint32_t x3_split_word(float v) {
+#ifdef SVHIP_X3_BF16
+    const uint16_t hi = f32_to_bf16_rne(v);
+    uint32_t hu = (uint32_t)hi << 16;
+    float hf; memcpy(&hf, &hu, 4);
+    return hu | f32_to_bf16_rne(v - hf);
+#else
+    const float c = std::fmin(std::fmax(v, -65504.0f), 65504.0f);
+    const _Float16 h = static_cast<_Float16>(c);
+    const float r = std::fmin(std::fmax(v - static_cast<float>(h), -65504.0f), 65504.0f);
+    const _Float16 l = static_cast<_Float16>(r);
+    uint16_t hb, lb;
+    memcpy(&hb, &h, 2); memcpy(&lb, &l, 2);
+    return ((uint32_t)hb << 16) | lb;
+#endif
 }
 
 // a weight in the handle's 16-bit storage type
@@ -526,12 +546,7 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
         L.W = d;
         if (h->x3) {
             std::vector<uint32_t> ws(packed.size());
-            for (size_t i = 0; i < packed.size(); ++i) {
-                const uint16_t hi = f32_to_bf16_rne(packed[i]);
-                uint32_t hu = (uint32_t)hi << 16;
-                float hf; memcpy(&hf, &hu, 4);
-                ws[i] = hu | f32_to_bf16_rne(packed[i] - hf);
-            }
+            for (size_t i = 0; i < packed.size(); ++i) ws[i] = x3_split_word(packed[i]);      // (hi plane << 16) | lo plane, x3_t of common.h
             uint32_t* dsplit;
             if ((rc = dev_upload(h, &dsplit, ws))) return rc;
             L.Wsplit = dsplit;
@@ -1468,7 +1483,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         svhip_handle::DevOpts& o = h->opt;
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
-        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA");
+        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
         o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1);
     }
     h->esz = h->bf16 ? 2 : 4;
@@ -1916,10 +1931,12 @@ static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64
     return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
 }
 
-// F32X3 handles: B as split words in a scratch slot of the handle (nullptr on exact handles)
+// B as split words (hi half << 16 | lo half) in a scratch slot of the handle: the score GEMMs run as three fp16 MFMAs per product on
+// every handle since round 4 — with half planes the split form is fp32-grade (a score of unit vectors within ~4e-8 of the float64
+// oracle, the exact fp32 MFMA 3.5e-8) at twice the fp32 matrix rate; option score_f32mfma keeps the exact fp32 MFMA.
 static int split_b(svhip_handle* h, const float* dB, int64_t Nb, int D, void** out) {
     *out = nullptr;
-    if (!h->x3) return SVHIP_OK;
+    if (h->opt.score_f32mfma && !h->x3) return SVHIP_OK;
     if (int rc = scratch(h, svhip_handle::SCR_SPLIT, (size_t)Nb * D * 4, out)) return rc;
     return run(h, "split_words", 0, [&]() { return launch_split_words(dB, *out, Nb * D, h->stream); });
 }
@@ -1990,7 +2007,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         const size_t mb_bytes = (size_t)(D + 32) * D * 4;          // [MB | slice partials of its computation]
         const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 2;
         // (the exact default is the six-bf16-MFMA form where it is built: scores to fp32 rounding at 2.7 x the fp32 matrix rate)
-        const bool x6 = asnorm_fused6_supported(D) && !h->opt.asnorm_f32mfma;
+        // (the exact default is a split form where it is built: scores to fp32 rounding at several times the fp32 matrix rate — two half
+        //  planes / three fp16 MFMAs (D = 192, 256); option asnorm_x6: three bf16 planes / six bf16 MFMAs, round 3's form, D = 192)
+        const int nplanes = h->opt.asnorm_x6 ? 3 : 2;
+        const bool x6 = asnorm_fused6_supported(D, nplanes) && !h->opt.asnorm_f32mfma;
         // (x6: the candidate kernel takes 1.7 ms of 17 on its own and 7 when it shares the CUs with the matrix kernel: one stream.
         //  The fp32-MFMA form keeps the second stream: 26.1 - 26.9 against 27.5 ms)
         const int nbuf = (N > chunk && !x6) ? 2 : 1;
@@ -2010,8 +2030,8 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         fp.cohort = (const float*)dC; fp.K = K; fp.MB = (const float*)mb; fp.z = asnorm_tail_z(K, top);
         if (x6) {
             void* planes = (char*)mb + mb_bytes + mom_bytes;
-            if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream); }))) return rc;
-            fp.planes = planes;
+            if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream, nplanes); }))) return rc;
+            fp.planes = planes; fp.nplanes = nplanes;
         }
         int c = 0;
         for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
@@ -2237,7 +2257,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}};
     for (auto& t : table)
         if (n == t.key) {

@@ -179,16 +179,23 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused_kernel(AsnormFusedParams 
 // Same structure as above (embeddings = B operand in registers, cohort blocks through LDS, lane-local selection, exact moments as
 // leading pseudo-cohort blocks); the cohort image (pseudo rows first, then the K cohort rows) is split into three bf16 planes once
 // per call (split3_planes_kernel).  D = 192 only: the B operand is 144 VGPRs.
-template <int D>
+//
+// NPL = 2 ("h3", round 4, the default): TWO planes of IEEE half and THREE fp16 MFMAs per product block (hi.hi + hi.lo + lo.hi).  A half
+// plane carries 11 significant bits, so hi + lo holds 22 (2^-23 relative) while lo is a normal half, and below |v| = 2^-3 — where
+// the components of unit embeddings live — lo is a subnormal half with an ABSOLUTE quantum of 2^-24: a component is represented to
+// 3e-8 absolute, a score of unit vectors to ~4e-8 (measured against the float64 oracle: tests), the same class as x6, at half the MFMAs,
+// two thirds of the LDS bytes and 96 instead of 144 operand VGPRs (D = 256 fits as well).
+template <int D, int NPL>
 __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CH = D / 8;                       // 16-byte chunks (8 bf16) per row of a plane
+    constexpr int CH = D / 8;                       // 16-byte chunks (8 values) per row of a plane
     constexpr int PL = 32 * D * 2;                  // one plane of a block of 32 rows
-    constexpr int BLK = 3 * PL;
-    constexpr int NDMA = 3 * 32 * CH / 256;         // DMA instructions per thread per block
+    constexpr int BLK = NPL * PL;
+    constexpr int NDMA = NPL * 32 * CH / 256;       // DMA instructions per thread per block
     constexpr int NP = D / 32 + 1;                  // pseudo-cohort blocks: rows of M, then cbar
     constexpr int NS = D / 16;                      // MFMA k steps per block
-    static_assert(D % 64 == 0 && (3 * 32 * CH) % 256 == 0 && CH % 8 == 0, "block image: whole DMA rounds, chunk groups of 8");
+    static_assert(D % 64 == 0 && (NPL * 32 * CH) % 256 == 0 && CH % 8 == 0, "block image: whole DMA rounds, chunk groups of 8");
+    static_assert(NPL == 2 || NPL == 3, "two half planes or three bf16 planes");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,21 +207,34 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
     const uint32_t eoff = (uint32_t)((valid ? row : p.N - 1) * D);                  // < 2^31 elements per launch (host check)
     const float* __restrict__ erow = p.E + eoff;
 
-    // B operand: embedding j, k = 16 s + 8 h .. + 7 for k step s, in three bf16 parts
-    bf16x8 bh[NS], bm[NS], bl[NS];
+    // B operand: embedding j, k = 16 s + 8 h .. + 7 for k step s, in three bf16 parts (or two half parts: bh, bm)
+    bf16x8 bh[NS], bm[NS], bl[NPL == 3 ? NS : 1];
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(erow + 16 * s_ + 8 * h);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(erow + 16 * s_ + 8 * h + 4);
+        if (NPL == 3) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float v = u < 4 ? v0[u] : v1[u - 4];
-            const bf16_t a = static_cast<bf16_t>(v);
-            const float r1 = v - static_cast<float>(a);
-            const bf16_t b = static_cast<bf16_t>(r1);
-            bh[s_][u] = a;
-            bm[s_][u] = b;
-            bl[s_][u] = static_cast<bf16_t>(r1 - static_cast<float>(b));
+            for (int u = 0; u < 8; ++u) {
+                const float v = u < 4 ? v0[u] : v1[u - 4];
+                const bf16_t a = static_cast<bf16_t>(v);
+                const float r1 = v - static_cast<float>(a);
+                const bf16_t b = static_cast<bf16_t>(r1);
+                bh[s_][u] = a;
+                bm[s_][u] = b;
+                bl[s_][u] = static_cast<bf16_t>(r1 - static_cast<float>(b));
+            }
+        } else {
+            f16x8 a8, b8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const f16_t a = static_cast<f16_t>(v);
+                a8[u] = a;
+                b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
+            }
+            bh[s_] = __builtin_bit_cast(bf16x8, a8);
+            bm[s_] = __builtin_bit_cast(bf16x8, b8);
         }
     }
 
@@ -247,19 +267,25 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
         // A fragments are read ONE k step ahead of their six MFMAs, fenced (left alone hipcc issues each ds_read right in front of
         // the wait of the MFMAs that use it, and a wave then sits out the LDS latency every k step whenever its SIMD partner is
         // not in its own MFMA phase: matrix pipe busy 0.58)
-        bf16x8 ah = rd(buf, 0, 0), am = rd(buf, 1, 0), al = rd(buf, 2, 0);
+        bf16x8 ah = rd(buf, 0, 0), am = rd(buf, 1, 0), al = NPL == 3 ? rd(buf, 2, 0) : ah;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             bf16x8 nh = ah, nm = am, nl = al;
-            if (s_ + 1 < NS) { nh = rd(buf, 0, s_ + 1); nm = rd(buf, 1, s_ + 1); nl = rd(buf, 2, s_ + 1); }
+            if (s_ + 1 < NS) { nh = rd(buf, 0, s_ + 1); nm = rd(buf, 1, s_ + 1); if (NPL == 3) nl = rd(buf, 2, s_ + 1); }
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);      // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[s_], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[s_], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[s_], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+            if (NPL == 3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+            } else {            // (planes: h = hi, m = lo)
+                acc = Half16<f16_t>::mfma32(am, bh[s_], acc);
+                acc = Half16<f16_t>::mfma32(ah, bm[s_], acc);
+                acc = Half16<f16_t>::mfma32(ah, bh[s_], acc);
+            }
             __builtin_amdgcn_sched_barrier(0);
             ah = nh; am = nm; al = nl;
         }
@@ -328,6 +354,18 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
         planes[i] = a;
         planes[n + i] = b;
         planes[2 * n + i] = static_cast<bf16_t>(r1 - static_cast<float>(b));
+    }
+}
+// ... -> two half planes [2][rows_total][D] (hi, lo) for the three-fp16-MFMA form
+__global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
+                                                            f16_t* __restrict__ planes) {
+    const int64_t n = (int64_t)(n0 + n1) * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D;
+        const float v = __builtin_amdgcn_fmed3f(r < n0 ? A[i] : B[i - (int64_t)n0 * D], -65504.0f, 65504.0f);
+        const f16_t a = static_cast<f16_t>(v);
+        planes[i] = a;
+        planes[n + i] = static_cast<f16_t>(v - static_cast<float>(a));
     }
 }
 
@@ -442,14 +480,16 @@ hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, f
     return hipGetLastError();
 }
 
-bool asnorm_fused6_supported(int D) { return D == 192; }
+// planes = 2: two half planes, three fp16 MFMAs (D = 192 / 256); planes = 3: three bf16 planes, six bf16 MFMAs (D = 192)
+bool asnorm_fused6_supported(int D, int planes) { return planes == 2 ? (D == 192 || D == 256) : (planes == 3 && D == 192); }
 size_t asnorm_planes_bytes(int D, int K) { return (size_t)3 * (D + 32 + K) * D * 2; }
 
-hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream) {
-    if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0) return hipErrorInvalidValue;
+hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes) {
+    if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0 || !(nplanes == 2 || nplanes == 3)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)(D + 32 + K) * D;
     const int64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
+    if (nplanes == 2) hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<f16_t*>(planes));
+    else hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
     return hipGetLastError();
 }
 
@@ -457,13 +497,21 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
     if (p.N <= 0) return hipSuccess;
     if (!asnorm_fused_supported(D, p.K, 1) || !p.E || !p.cohort || !p.MB || !p.cand || !p.cnt) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(p.E) | reinterpret_cast<uintptr_t>(p.cohort) | reinterpret_cast<uintptr_t>(p.MB)) & 15) return hipErrorInvalidValue;
-    if (p.planes) {                                       // the six-bf16-MFMA form
-        if (!asnorm_fused6_supported(D) || (reinterpret_cast<uintptr_t>(p.planes) & 15) || p.N > (int64_t)1 << 21) return hipErrorInvalidValue;      // (32-bit lane offsets)
-        static DeviceOnce attr6;
-        const int lds6 = 2 * 3 * 32 * 192 * 2;
-        if (hipError_t e = set_max_dynamic_lds(attr6, reinterpret_cast<const void*>(asnorm_fused6_kernel<192>), lds6)) return e;
-        hipLaunchKernelGGL((asnorm_fused6_kernel<192>), dim3((unsigned)((p.N + 127) / 128)), dim3(256), lds6, stream, p);
-        return hipGetLastError();
+    if (p.planes) {                                       // the split forms: three fp16 MFMAs on two half planes / six bf16 MFMAs on three
+        if (!asnorm_fused6_supported(D, p.nplanes) || (reinterpret_cast<uintptr_t>(p.planes) & 15) || p.N > (int64_t)1 << 21) return hipErrorInvalidValue;      // (32-bit lane offsets)
+        const dim3 grid((unsigned)((p.N + 127) / 128));
+#define SV_AF6(DD, NP)                                                                                                      \
+        {                                                                                                                   \
+            static DeviceOnce attr6;                                                                                        \
+            constexpr int lds6 = 2 * NP * 32 * DD * 2;                                                                      \
+            if (hipError_t e = set_max_dynamic_lds(attr6, reinterpret_cast<const void*>(asnorm_fused6_kernel<DD, NP>), lds6)) return e; \
+            hipLaunchKernelGGL((asnorm_fused6_kernel<DD, NP>), grid, dim3(256), lds6, stream, p);                           \
+            return hipGetLastError();                                                                                       \
+        }
+        if (p.nplanes == 3) SV_AF6(192, 3)
+        if (D == 192) SV_AF6(192, 2)
+        SV_AF6(256, 2)
+#undef SV_AF6
     }
     switch (D) {
         case 192: return launch_fused_d<192>(p, stream);

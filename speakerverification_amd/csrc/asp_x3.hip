@@ -105,16 +105,16 @@ __global__ __launch_bounds__(AX_THREADS, 2) void asp_x3_kernel(AspX3Params p) {
     auto convert = [&](int buf) {
         const f32x4* q = reinterpret_cast<const f32x4*>(raw + buf * AX_RAW + sfr * 512 + (tid & 15) * 32);
         const f32x4 v0 = q[0], v1 = q[1];
-        bf16x8 hi, lo;
+        x3x8_t hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = j < 4 ? v0[j] : v1[j - 4];
-            const bf16_t hb = static_cast<bf16_t>(v);
+            const x3_t hb = x3_hi(v);
             hi[j] = hb;
-            lo[j] = static_cast<bf16_t>(v - static_cast<float>(hb));
+            lo[j] = x3_lo(v, hb);
         }
-        *reinterpret_cast<bf16x8*>(planes + soff) = hi;
-        *reinterpret_cast<bf16x8*>(planes + AX_PLANE + soff) = lo;
+        *reinterpret_cast<x3x8_t*>(planes + soff) = hi;
+        *reinterpret_cast<x3x8_t*>(planes + AX_PLANE + soff) = lo;
     };
 
     // (__syncthreads() carries a fence that drains vmcnt: LDS traffic only needs lgkmcnt(0) + the raw barrier)
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(AX_THREADS, 2) void asp_x3_kernel(AspX3Params p) {
             const int o = r * 256 + (((2 * ks + h) ^ (r & 15)) << 4);
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(planes + o);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(planes + AX_PLANE + o);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[ks], acc, 0, 0, 0);     // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], acc, 0, 0, 0);
+            acc = X3H::mfma32(al, wh[ks], acc);     // small terms first
+            acc = X3H::mfma32(ah, wl[ks], acc);
+            acc = X3H::mfma32(ah, wh[ks], acc);
         }
         // lane-local online softmax over this lane's 16 frames of channel c
         if (mt * 32 + 32 > T) {                                                // frames past the utterance: weight 0

@@ -397,9 +397,8 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
             const Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
             Vec16<T> xv;
             if (VEC == 4 && x32) {
-                typedef bf16_t bf16x4r_ __attribute__((ext_vector_type(4)));
                 const char* q = x32 + m * (int64_t)ldx32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
-                const bf16x4r_ xh = *reinterpret_cast<const bf16x4r_*>(q), xl = *reinterpret_cast<const bf16x4r_*>(q + 64);
+                const x3x4_t xh = *reinterpret_cast<const x3x4_t*>(q), xl = *reinterpret_cast<const x3x4_t*>(q + 64);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv.set(j, static_cast<float>(xh[j]) + static_cast<float>(xl[j]));
             } else {
@@ -410,18 +409,17 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
             for (int j = 0; j < VEC; ++j) o.set(j, fmaf(hv.get(j), g[j], xv.get(j)));
             if (out) *reinterpret_cast<Vec16<T>*>(out + m * ldo + c) = o;
             if (VEC == 4 && s32) {
-                typedef bf16_t bf16x4_ __attribute__((ext_vector_type(4)));
-                bf16x4_ hi, lo;
+                x3x4_t hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = o.get(j);
-                    const bf16_t hb = static_cast<bf16_t>(v);
+                    const x3_t hb = x3_hi(v);
                     hi[j] = hb;
-                    lo[j] = static_cast<bf16_t>(v - static_cast<float>(hb));
+                    lo[j] = x3_lo(v, hb);
                 }
                 char* q = s32 + m * (int64_t)ld32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
-                *reinterpret_cast<bf16x4_*>(q) = hi;
-                *reinterpret_cast<bf16x4_*>(q + 64) = lo;
+                *reinterpret_cast<x3x4_t*>(q) = hi;
+                *reinterpret_cast<x3x4_t*>(q + 64) = lo;
             }
         }
     }
@@ -595,8 +593,8 @@ hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, cons
 __global__ __launch_bounds__(256) void split_words_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float v = src[i];
-        const bf16_t h = static_cast<bf16_t>(v);
-        const bf16_t l = static_cast<bf16_t>(v - static_cast<float>(h));
+        const x3_t h = x3_hi(v);
+        const x3_t l = x3_lo(v, h);
         uint16_t hb, lb;
         __builtin_memcpy(&hb, &h, 2);
         __builtin_memcpy(&lb, &l, 2);
@@ -617,18 +615,17 @@ __global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict_
             a = *reinterpret_cast<const f32x4*>(src + row * ld + k0);
             b = *reinterpret_cast<const f32x4*>(src + row * ld + k0 + 4);
         }
-        typedef bf16_t bf16x8_ __attribute__((ext_vector_type(8)));
-        bf16x8_ hi, lo;
+        x3x8_t hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = e < 4 ? a[e] : b[e - 4];
-            const bf16_t h = static_cast<bf16_t>(v);
+            const x3_t h = x3_hi(v);
             hi[e] = h;
-            lo[e] = static_cast<bf16_t>(v - static_cast<float>(h));
+            lo[e] = x3_lo(v, h);
         }
         char* o = dst + row * (int64_t)ldd * 4 + (k0 >> 5) * 128 + (k0 & 31) * 2;
-        *reinterpret_cast<bf16x8_*>(o) = hi;
-        *reinterpret_cast<bf16x8_*>(o + 64) = lo;
+        *reinterpret_cast<x3x8_t*>(o) = hi;
+        *reinterpret_cast<x3x8_t*>(o + 64) = lo;
     }
 }
 
@@ -648,9 +645,8 @@ __global__ __launch_bounds__(256) void unsplit_s32_kernel(const char* __restrict
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / per_row;
         const int c = (int)(i - row * per_row) * 4;
-        typedef bf16_t bf16x4u_ __attribute__((ext_vector_type(4)));
         const char* q = src + row * (int64_t)lds32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
-        const bf16x4u_ hi = *reinterpret_cast<const bf16x4u_*>(q), lo = *reinterpret_cast<const bf16x4u_*>(q + 64);
+        const x3x4_t hi = *reinterpret_cast<const x3x4_t*>(q), lo = *reinterpret_cast<const x3x4_t*>(q + 64);
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = static_cast<float>(hi[j]) + static_cast<float>(lo[j]);

@@ -113,14 +113,18 @@ __device__ __forceinline__ float epilogue_act1(float v) {
 }
 
 // fp32 value pair -> bf16 hi / lo parts (x = hi + lo up to 2^-17 relative): eight k-values of one fragment row
+// (planes of x3_t, common.h: IEEE half since round 4 — 2^-23 relative while lo is a normal half; the fragments travel as raw 16-byte vectors)
 __device__ __forceinline__ void split_hi_lo(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    x3x8_t h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const bf16_t ha = static_cast<bf16_t>(a[e]), hb = static_cast<bf16_t>(b[e]);
-        hi[e] = ha; hi[4 + e] = hb;
-        lo[e] = static_cast<bf16_t>(a[e] - static_cast<float>(ha));
-        lo[4 + e] = static_cast<bf16_t>(b[e] - static_cast<float>(hb));
+        const x3_t ha = x3_hi(a[e]), hb = x3_hi(b[e]);
+        h[e] = ha; h[4 + e] = hb;
+        l[e] = x3_lo(a[e], ha);
+        l[4 + e] = x3_lo(b[e], hb);
     }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
 }
 
 // X3 (T = float only, SVHIP_F32X3 handles): every product as three bf16 MFMAs on hi / lo-split fragments (see gemm_pw.hip)
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = X3H::mfma32(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = X3H::mfma32(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = X3H::mfma32(ah[i], bh[j], acc[i][j]);
                     }
             }
         } else {

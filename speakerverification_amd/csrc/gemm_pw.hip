@@ -105,14 +105,18 @@ template <> struct Frag<f16_t> {           // SVHIP_F16 handles (RawNet2): the b
 // CONV: the A operand is the im2col view of a dilated 1-D convolution (per-lane DMA source = frame
 // t + (tap - taps/2)*dil of the same utterance, reflect / zero padded; padded chunks read a zero page).
 // fp32 value pair -> bf16 hi / lo parts (x = hi + lo up to 2^-17 relative): eight k-values of one fragment row
+// (planes of x3_t, common.h: IEEE half since round 4 — 2^-23 relative while lo is a normal half; the fragments travel as raw 16-byte vectors)
 __device__ __forceinline__ void split_hi_lo(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    x3x8_t h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const bf16_t ha = static_cast<bf16_t>(a[e]), hb = static_cast<bf16_t>(b[e]);
-        hi[e] = ha; hi[4 + e] = hb;
-        lo[e] = static_cast<bf16_t>(a[e] - static_cast<float>(ha));
-        lo[4 + e] = static_cast<bf16_t>(b[e] - static_cast<float>(hb));
+        const x3_t ha = x3_hi(a[e]), hb = x3_hi(b[e]);
+        h[e] = ha; h[4 + e] = hb;
+        l[e] = x3_lo(a[e], ha);
+        l[4 + e] = x3_lo(b[e], hb);
     }
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
 }
 
 // X3 (T = float only): fp32 operands in memory and LDS, each product formed as THREE bf16 MFMAs on hi / lo-split fragments
@@ -259,15 +263,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pw_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = X3H::mfma32(wl[j], xh[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = X3H::mfma32(wh[j], xl[i], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = X3H::mfma32(wh[j], xh[i], acc[i][j]);
             }
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             continue;

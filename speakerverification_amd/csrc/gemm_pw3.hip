@@ -101,7 +101,7 @@ template <int EPI, int CS, bool X3, bool R2 = false, bool CV = false, typename H
 __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     static_assert(!R2 || (X3 && CS == 0), "the Res2Net step form exists for the X3 kernel only");
     static_assert(!CV || !R2, "the conv-gather form (CV) is the pointwise kernel with gathered X rows");
-    static_assert(!X3 || std::is_same<H, bf16_t>::value, "the split-bf16 forms are bf16 by construction");
+    typedef typename std::conditional<X3, x3_t, H>::type MH;       // MFMA operand type: the split forms' planes are x3_t (common.h)
     constexpr bool GATHER = R2 || CV;          // X half-tiles = im2col view of a dilated convolution over the rows of an utterance
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = (X3 ? 32 : 16) + 8 * CS;    // vector-memory stores a wave issues in one tile's epilogue
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks)                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-                acc16[(I0) + i][(J0) + j] = Half16<H>::mfma16(WARR[j][X3 ? (ks == 2) : ks], xf[i][X3 ? (ks == 1) : ks], acc16[(I0) + i][(J0) + j]); \
+                acc16[(I0) + i][(J0) + j] = Half16<MH>::mfma16(WARR[j][X3 ? (ks == 2) : ks], xf[i][X3 ? (ks == 1) : ks], acc16[(I0) + i][(J0) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                  \
     __builtin_amdgcn_s_barrier();
 #define PW3_KTILE(REM_, KT_, WCUR, WNXT, RLX_, HOOK)                                       \
@@ -430,14 +430,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             };
             // a lane's four values -> 8 bytes of the hi plane and 8 bytes of the lo plane of its block
             auto put_s32 = [&](const f32x4& v, int ml, int nl) {
-                typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
                 uint32_t hd[2], ld[2];
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
-                    hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
-                    ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
-                }
+                for (int d = 0; d < 2; ++d) x3_split2(v[2 * d], v[2 * d + 1], hd[d], ld[d]);
                 const int kh = (nl & 31) >> 3;                  // chunk of the hi plane holding channels nl .. nl + 3 (lo: + 4)
                 char* blk = smem + ml * 512 + (nl >> 5) * 128 + (nl & 4) * 2;
                 *reinterpret_cast<uint2*>(blk + ((kh ^ (ml & 7)) << 4)) = make_uint2(hd[0], hd[1]);
@@ -556,12 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                     if (side_chunk < 2) {
                         uint32_t hd[2], ld[2];
 #pragma unroll
-                        for (int d = 0; d < 2; ++d) {
-                            typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
-                            const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
-                            hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
-                            ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
-                        }
+                        for (int d = 0; d < 2; ++d) x3_split2(v[2 * d], v[2 * d + 1], hd[d], ld[d]);
                         const auto s0 = __builtin_amdgcn_permlane16_swap(hd[0], ld[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(hd[1], ld[1], false, false);
                         if (in) *reinterpret_cast<u32x4*>(sbase + (int64_t)m * sld + boff) = u32x4{s0[0], s1[0], s0[1], s1[1]};

@@ -361,11 +361,12 @@ struct AsnormFusedParams {
     float z = 0.0f;                 // threshold = row mean + z * row std (asnorm_tail_z)
     float* cand = nullptr;          // (N, 2, ASNORM_CAND_PER_LANE) candidate scores
     int32_t* cnt = nullptr;         // (N, 2) scores above the threshold seen by each of the two lanes (may exceed the list size)
-    const void* planes = nullptr;   // optional: [3][D + 32 + K][D] bf16 parts (h, m, l) of [MB ; cohort] (launch_asnorm_planes): the six-MFMA form
+    const void* planes = nullptr;   // optional: [nplanes][D + 32 + K][D] 16-bit parts of [MB ; cohort] (launch_asnorm_planes): the split forms
+    int nplanes = 2;                // 2: half hi | lo, three fp16 MFMAs per product block (default); 3: bf16 h | m | l, six bf16 MFMAs
 };
-bool asnorm_fused6_supported(int D);
+bool asnorm_fused6_supported(int D, int planes);
 size_t asnorm_planes_bytes(int D, int K);
-hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream);
+hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes = 2);
 bool asnorm_fused_supported(int D, int K, int top);
 float asnorm_tail_z(int K, int top);
 // `part`: cohort_moments_scratch_bytes(D) of scratch (slice partials, summed in a fixed order)

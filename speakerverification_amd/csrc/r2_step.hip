@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
             const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + i * 2048 + ((q4 ^ xkey) << 4));
             const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + i * 2048 + (((4 + q4) ^ xkey) << 4));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl, acc[i][j], 0, 0, 0);      // small terms first
+            for (int j = 0; j < 4; ++j) acc[i][j] = X3H::mfma16(wh[j], xl, acc[i][j]);      // small terms first
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = X3H::mfma16(wl[j], xh, acc[i][j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = X3H::mfma16(wh[j], xh, acc[i][j]);
         }
     }
     lds_barrier();                                  // every wave is past its last fragment read: the 64 KiB become the row image
@@ -125,14 +125,9 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         }
     };
     auto put_s32 = [&](const f32x4& v, int ml, int nl) {
-        typedef bf16_t bf16x2_ __attribute__((ext_vector_type(2)));
         uint32_t hd[2], ld[2];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const bf16_t h0 = static_cast<bf16_t>(v[2 * d]), h1 = static_cast<bf16_t>(v[2 * d + 1]);
-            hd[d] = __builtin_bit_cast(uint32_t, bf16x2_{h0, h1});
-            ld[d] = bf16_pack2(v[2 * d] - static_cast<float>(h0), v[2 * d + 1] - static_cast<float>(h1));
-        }
+        for (int d = 0; d < 2; ++d) x3_split2(v[2 * d], v[2 * d + 1], hd[d], ld[d]);
         const int kh = (nl & 31) >> 3;
         char* blk = smem + ml * 512 + (nl >> 5) * 128 + (nl & 4) * 2;
         *reinterpret_cast<uint2*>(blk + ((kh ^ (ml & 7)) << 4)) = make_uint2(hd[0], hd[1]);

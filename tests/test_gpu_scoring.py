@@ -301,7 +301,12 @@ def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
     cohort = rng.standard_normal((K, D)).astype(np.float32)
     cohort /= np.linalg.norm(cohort, axis=1, keepdims=True)
     cohort[7] = cohort[9]
+    # round 4: the default split form is TWO half planes / three fp16 MFMAs ("h3"); option asnorm_x6 selects round 3's three bf16 planes
+    mu3, sd3 = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback == 0
+    eng.set_option("asnorm_x6", 1)
     mu6, sd6 = eng.asnorm_stats(E, cohort, top)
+    eng.set_option("asnorm_x6", 0)
     assert eng.asnorm_last_fallback == 0
     eng.set_option("asnorm_f32mfma", 1)
     mu1, sd1 = eng.asnorm_stats(E, cohort, top)
@@ -313,4 +318,8 @@ def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
     assert float(np.abs(mu6 - rmu).max()) <= 1e-6 and float(np.abs(mu1 - rmu).max()) <= 1e-6
     assert float((np.abs(sd6 - rsd) / rsd).max()) <= 1e-4
     assert float(np.abs(mu6 - mu1).max()) <= 5e-7 and float(np.abs(sd6 - sd1).max()) <= 5e-7
+    print("h3 (two half planes, three fp16 MFMAs) vs f64 oracle: mu", float(np.abs(mu3 - rmu).max()), "sd rel", float((np.abs(sd3 - rsd) / rsd).max()),
+          "| h3 vs fp32 MFMA: mu", float(np.abs(mu3 - mu1).max()))
+    assert float(np.abs(mu3 - rmu).max()) <= 1e-6 and float((np.abs(sd3 - rsd) / rsd).max()) <= 1e-4
+    assert float(np.abs(mu3 - mu1).max()) <= 5e-7 and float(np.abs(sd3 - sd1).max()) <= 5e-7
     eng.close()
