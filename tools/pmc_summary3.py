@@ -13,12 +13,17 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from demangle import demangle  # noqa: E402
 
 BASE = re.compile(r"(\w+_kernel)(<[^(]*>)?")
 
 
 def label(name):
+    name = demangle(name)
     name = re.sub(r"_ZN5svhip12_GLOBAL__N_1\d+", "", name.replace("svhip::(anonymous namespace)::", "").replace("void ", ""))
     name = re.sub(r"_kernelI.*", "_kernel", name) if name.startswith(("gemm", "rn_", "se_", "prologue")) and "<" not in name else name
     m = BASE.search(name)
