@@ -77,6 +77,7 @@ struct svhip_handle {
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
+        int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
         int r2_slices = -1;       // bf16 Res2Net chain: time slices per utterance (-1: by batch size, 0 / 1: whole utterances, n: forced)
     } opt;
     bool bf16 = false;                        // 16-bit storage handle: bf16, or fp16 when `f16` is set (the flag keeps its round-1 name)
@@ -882,7 +883,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     h->last_colsum_done = false;
     h->side_done = false;
     p.R = R; p.ldr = ldr; p.zero_page = zero_page_for(h, A);
-    p.zeros = h->d_zeros; p.ones = h->d_ones; p.cv_off = h->opt.cv_off;
+    p.zeros = h->d_zeros; p.ones = h->d_ones; p.cv_off = h->opt.cv_off; p.n128_off = h->opt.n128_off;
     p.A = A; p.A2 = A2; p.W = L.W; p.Y = Y;
     p.bias = L.bias; p.bias_utt = bias_utt; p.scale = L.scale; p.shift = L.shift;
     p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np;
@@ -924,7 +925,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
     const GemmRoute route = gemm_route(p, bf);
-    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW3CV ? "gemm_pw3cv16" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
+    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW3CV ? "gemm_pw3cv16" : route == ROUTE_N128 ? "gemm_n128" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
                          : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
     if (h->opt.layer_labels) {            // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
@@ -2258,7 +2259,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
         {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
-        {"r2_slices", &o.r2_slices}};
+        {"r2_slices", &o.r2_slices}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

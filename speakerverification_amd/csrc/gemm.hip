@@ -368,6 +368,7 @@ GemmRoute gemm_route(const GemmParams& p, bool bf16) {
 #endif
     const bool pw = gemm_pw_supported(p, bf16);
     if (bf16 && p.taps > 1 && !p.cv_off && gemm_pw3cv16_supported(p)) return ROUTE_PW3CV;
+    if (bf16 && !p.n128_off && gemm_n128_supported(p)) return ROUTE_N128;
     if (!skip_pw2 && gemm_pw2_supported(p, bf16)) {
         const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         const bool pw3 = !no_pw3 && gemm_pw3_supported(p, bf16);
@@ -399,6 +400,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
         case ROUTE_PW2: return launch_gemm_pw2(p, stream);
         case ROUTE_PW3: return launch_gemm_pw3(p, stream);
         case ROUTE_PW3CV: return launch_gemm_pw3cv16(p, stream);
+        case ROUTE_N128: return launch_gemm_n128(p, stream);
         case ROUTE_PW: return launch_gemm_pw(p, bf16, stream);
         case ROUTE_PW_NARROW: return launch_gemm_pw(p, bf16, stream, true);
         default: break;

@@ -84,6 +84,7 @@ struct GemmParams {
     void* side_b = nullptr;
     int side_lda = 0, side_ldb = 0, side_c = 0;
     int num_cu = 256;               // compute units of the device (grid-size routing, gemm_route)
+    int n128_off = 0;               // developer option n128_off: N = 128 layers stay on gemm_pw
     int cv_off = 0;                 // developer option cv_off: 16-bit conv-gather GEMMs stay on the per-tile kernel
     int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
                                     // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
@@ -121,7 +122,9 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream);
 //              with more tiles than CUs (ECAPA's tdnn1 / tdnn2 / mfa)
 //   PW3CV      the persistent kernel's conv-gather form on 16-bit operands: k = 3 / 5 convolutions with cin % 64 == 0 and more tiles
 //              than CUs (RawNet2 blocks 2 - 5, ECAPA blocks.0 with padded input rows)
-enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3, ROUTE_PW3 = 4, ROUTE_PW3CV = 5 };
+//   N128       bf16 pointwise layers with N = 128 and the ReLU -> BN -> tanh epilogue (ECAPA's asp.tdnn): 128 x 128 tiles, two workgroups
+//              per CU (gemm_n128.hip), every batch size
+enum GemmRoute : int { ROUTE_PW2 = 0, ROUTE_PW = 1, ROUTE_PW_NARROW = 2, ROUTE_GENERIC = 3, ROUTE_PW3 = 4, ROUTE_PW3CV = 5, ROUTE_N128 = 6 };
 GemmRoute gemm_route(const GemmParams& p, bool bf16);
 bool gemm_pw_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw(const GemmParams& p, bool bf16, hipStream_t stream, bool narrow = false);
@@ -141,6 +144,8 @@ bool r2_step_supported(const GemmParams& p);               // r2_step.hip: the R
 hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3cv_supported(const GemmParams& p);          // conv-gather X3 form (odd taps, reflect): see gemm_pw3.hip
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream);
+bool gemm_n128_supported(const GemmParams& p);           // gemm_n128.hip
+hipError_t launch_gemm_n128(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3cv16_supported(const GemmParams& p);        // conv-gather form on bf16 / fp16 operands (reflect or zero padding)
 hipError_t launch_gemm_pw3cv16(const GemmParams& p, hipStream_t stream);
 // one Res2Net step of an F32X3 handle on the same kernel (dilated k = 3 conv gathered from an S32 input, outputs in S32)

@@ -411,3 +411,33 @@ def test_res2net_time_slices_match_whole_utterances(C, T_samples, B):
     for mode in (3, -1):
         for a, b in zip(outs[0], outs[mode]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("C,L,B", [(1024, 32000, 5), (512, 32000, 20), (1024, 2560, 9), (256, 10320, 7)])
+def test_n128_attention_gemm_matches_the_generic_route(C, L, B):
+    """Round 4: asp.tdnn (N = 128, K = 3C, per-utterance bias, ReLU -> BN -> tanh; ECAPA_TDNN.py:245-250) runs on gemm_n128 (128 x 128
+    tiles, four waves, two workgroups per CU) at every batch size; option n128_off keeps gemm_pw's 256 x 128 tile.  Same products in
+    the same K order; the epilogues differ in how tanh is evaluated (1 - 2 / (1 + e^2x) on the fast units against tanhf), i.e. by at
+    most a bf16 rounding of a few att elements: pooled statistics and embeddings agree far inside the bf16 path's own error.
+    Geometries: several tiles per utterance, short utterances (T = 33: four utterances inside one 128-row tile), a ragged last tile."""
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=5)
+    wav = synth.synth_waveforms(B, L, seed=15)
+    eng = Engine(model="ecapa", compute="bf16", channels=C, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    res = {}
+    for off in (1, 0):
+        eng.set_option("n128_off", off)
+        eng.profile(True)
+        emb = eng.embed_wave(wav)
+        labels = set(eng.profile_results())
+        eng.profile(False)
+        res[off] = (emb.copy(), eng.get_stage("asp").copy(), labels)
+    eng.close()
+    assert "gemm_n128" in res[0][2] and "gemm_n128" not in res[1][2], (sorted(res[0][2]), sorted(res[1][2]))
+    a, b = res[0][0], res[1][0]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    rel = float(np.abs(a - b).max() / np.abs(b).max())
+    srel = float(np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max())
+    print(f"C={C} L={L} B={B}: gemm_n128 vs gemm_pw: embedding cos {cos.min():.7f}, max diff / scale {rel:.2e}; pooled stats {srel:.2e}")
+    assert np.isfinite(a).all() and cos.min() >= 0.99999 and rel <= 5e-3 and srel <= 5e-3
