@@ -800,8 +800,9 @@ bool gemm_pw3x3_supported(const GemmParams& p) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024 || p.M <= 0 || p.Wrows < p.N) return false;
-    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
-    return ntiles > pw3_grid_cap(p);
+    // (any tile count: unlike the 16-bit form there is no per-tile twin to hand a small grid to, and the generic split-in-registers
+    //  kernels it would fall back to are 3 - 4 x slower than one tile per workgroup of this one)
+    return p.pw3_cus != 0;
 }
 
 // One step of a Res2Net chain on F32X3 handles (the R2 form): A = U_j (M, cin) S32, W = the step's conv weight (cin, 3 cin) S32
@@ -819,7 +820,7 @@ bool gemm_pw3r2_supported(const GemmParams& p) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.Y2) |
          reinterpret_cast<uintptr_t>(p.R) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
-    return (p.M + 255) / 256 > pw3_grid_cap(p);
+    return p.pw3_cus != 0;
 }
 
 hipError_t launch_gemm_pw3r2(const GemmParams& p_in, hipStream_t stream) {
@@ -853,7 +854,7 @@ bool gemm_pw3cv_supported(const GemmParams& p) {
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.bias) |
          reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
-    return ((p.M + 255) / 256) * (p.N / 256) > pw3_grid_cap(p);
+    return p.pw3_cus != 0;
 }
 
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream) {
