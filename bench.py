@@ -370,7 +370,7 @@ def sub_bench(model, compute, B, local, dev, wavs, steps=10, warmup=2):
     return rec
 
 
-def latency_bench(local, dev, wavs, batches=(1, 10, 20, 32), modes=("bf16", "f32x3"), full_rate=None):
+def latency_bench(local, dev, wavs, batches=(1, 10, 20, 32), modes=("bf16", "f32x3", "rawnet2_f16"), full_rate=None):
     """The reference API's native operating point (row a14): `embed_utterance` / per-file enrolment embeds B = num_eval = 10 - 20 crops
     of ONE file per call (src/model.py:675-704, yaml/configuration-voxceleb.yaml:156).  One engine per mode, created for the Python
     wrapper's default max_batch = 256, called with B rows: `ms_per_call` = a synchronous call (host launch overhead + the GPU work of
@@ -379,7 +379,7 @@ def latency_bench(local, dev, wavs, batches=(1, 10, 20, 32), modes=("bf16", "f32
     import torch
     res = {}
     for mode in modes:
-        eng = make_engine("ecapa", mode, BATCH, local)
+        eng = make_engine("rawnet2", "f16", BATCH, local) if mode == "rawnet2_f16" else make_engine("ecapa", mode, BATCH, local)
         rows = {}
         for b in batches:
             w = wavs[0][:b].contiguous()
