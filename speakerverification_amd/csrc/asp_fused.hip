@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
             const int r = g * 4 + (lane >> 4);
             const int lc = (lane & 15) ^ (r & 15);
             __builtin_amdgcn_global_load_lds((gbl_void*)(src + (int64_t)min(r, T - 1) * 256 + lc * 16),
-                                             (lds_void*)(att + g * 1024), 16, 0, 0);
+                                             (lds_void*)(att + g * 1024), 16, 0, CPOL_NT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void asp_fused_kernel(AspFusedParams p) {
             uint32_t o = xoff[q];
             if (tail) o = ((uint32_t)min(is_mt * 32 + q * 16 + (lane >> 2), T - 1) * (uint32_t)p.ldx + (uint32_t)(lane & 3) * 8u) * 2u;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((gbl_void*)(gb + o), (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(gb + o), (lds_void*)(slab + is_slot * AF_SLAB + q * 1024), 16, 0, CPOL_NT);      // (x is read once: non-temporal)
         }
         if (++is_mt == AF_MT) { is_mt = 0; ++is_pass; }
         if (++is_slot == AF_NSLOT) is_slot = 0;

@@ -67,6 +67,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // 16-byte vector of activations: 4 floats or 8 bf16.
+// cache-policy bits of a global_load_lds (the builtin's last argument; gfx940+: sc0 = 1, nt = 2, sc1 = 16).  NT marks a stream that is read
+// once: its lines are the first to leave L2 / the MALL, so they do not displace the tensors the next kernel is about to read
+// (round 4: se_apply 145 -> 103 us with non-temporal loads of its two read-once inputs).
+constexpr int CPOL_NT = 2;
+
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
@@ -87,6 +92,13 @@ template <> struct Vec16<f16_t> {
     __device__ __forceinline__ float get(int i) const { return static_cast<float>(v[i]); }
     __device__ __forceinline__ void set(int i, float x) { v[i] = static_cast<f16_t>(x); }
 };
+
+// 16-byte non-temporal load of a read-once stream (see CPOL_NT)
+template <typename T> __device__ __forceinline__ Vec16<T> ld_nt(const T* p) {
+    Vec16<T> r;
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(r.v)*>(p));
+    return r;
+}
 
 // Per-type pieces of the 16-bit kernels: H = bf16_t or f16_t.  Fragments travel as raw 16-byte vectors (bf16x8 in the kernels'
 // declarations whatever H is); only the MFMA opcode and the fp32 <-> 16-bit conversions differ.

@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
 #pragma unroll 4
         for (int t = t0 + fl; t < t1; t += 4) {
             const int64_t m = (int64_t)b * Tn + t;
-            const Vec16<T> hv = *reinterpret_cast<const Vec16<T>*>(h + m * ldh + c);
+            // (h is read exactly once, here: a non-temporal load keeps it from displacing the block input / output in L2 and the MALL)
+            Vec16<T> hv;
+            hv.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(hv.v)*>(h + m * ldh + c));
             Vec16<T> xv;
             if (VEC == 4 && x32) {
                 const char* q = x32 + m * (int64_t)ldx32 * 4 + (c >> 5) * 128 + (c & 31) * 2;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void se_apply_kernel(const T* __restrict__ h, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv.set(j, static_cast<float>(xh[j]) + static_cast<float>(xl[j]));
             } else {
-                xv = *reinterpret_cast<const Vec16<T>*>(x + m * ldx + c);
+                xv.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(xv.v)*>(x + m * ldx + c));      // (its last reader before mfa)
             }
             Vec16<T> o;
 #pragma unroll

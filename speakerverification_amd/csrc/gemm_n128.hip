@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
     auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Ab + xo[q] + kt * 128), (lds_void*)(smem + (buf * 2) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Ab + xo[q] + kt * 128), (lds_void*)(smem + (buf * 2) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);      // (one N tile: X is read once)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((gbl_void*)(Wb + wo[q] + kt * 128), (lds_void*)(smem + (buf * 2 + 1) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);

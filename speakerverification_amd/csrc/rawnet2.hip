@@ -477,12 +477,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
         if (t < Tn) {
             if (POOL) {
                 const T* q = xb + (int64_t)(3 * t) * C;
-                const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(q), bb = *reinterpret_cast<const Vec16<T>*>(q + C),
-                               d = *reinterpret_cast<const Vec16<T>*>(q + 2 * C);
+                const Vec16<T> a = ld_nt<T>(q), bb = ld_nt<T>(q + C), d = ld_nt<T>(q + 2 * C);      // (conv2's output and the block input: last reads)
                 if (RES) {
                     const T* r = rb + (int64_t)(3 * t) * C;
-                    const Vec16<T> ra = *reinterpret_cast<const Vec16<T>*>(r), rbb = *reinterpret_cast<const Vec16<T>*>(r + C),
-                                   rd = *reinterpret_cast<const Vec16<T>*>(r + 2 * C);
+                    const Vec16<T> ra = ld_nt<T>(r), rbb = ld_nt<T>(r + C), rd = ld_nt<T>(r + 2 * C);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j) + ra.get(j), bb.get(j) + rbb.get(j)), d.get(j) + rd.get(j)));
                 } else {
@@ -490,9 +488,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
                     for (int j = 0; j < VEC; ++j) held[i].set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), d.get(j)));
                 }
             } else {
-                held[i] = *reinterpret_cast<const Vec16<T>*>(xb + (int64_t)t * C);
+                held[i] = ld_nt<T>(xb + (int64_t)t * C);
                 if (RES) {
-                    const Vec16<T> r = *reinterpret_cast<const Vec16<T>*>(rb + (int64_t)t * C);
+                    const Vec16<T> r = ld_nt<T>(rb + (int64_t)t * C);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) held[i].set(j, held[i].get(j) + r.get(j));
                 }

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 #pragma unroll
             for (int k = 0; k < RB0; ++k)
                 if (row0 + (it0 + k) * RSTEP < T) {
-                    cc0[k] = *reinterpret_cast<const u32x4*>(h1b + goff0 + (uint32_t)(it0 + k) * gstep);
-                    cc1[k] = *reinterpret_cast<const u32x4*>(h1b + CW * 2 + goff0 + (uint32_t)(it0 + k) * gstep);
+                    cc0[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(h1b + goff0 + (uint32_t)(it0 + k) * gstep));      // (H1: every line is read once)
+                    cc1[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(h1b + CW * 2 + goff0 + (uint32_t)(it0 + k) * gstep));
                 }
 #pragma unroll
             for (int k = 0; k < RB0; ++k) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
 #pragma unroll
                 for (int k = 0; k < NPRE; ++k) {
                     const int rowc = min(row0 + k * RSTEP, T - 1);
-                    cpre[k] = *reinterpret_cast<const u32x4*>(h1s + ((uint32_t)rowc * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u);
+                    cpre[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(h1s + ((uint32_t)rowc * (uint32_t)p.ld + (uint32_t)ch0 * 8u) * 2u));
                 }
             }
             const bool more = !(s == 7 && tap == 2);

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
                 const int row = 4 * piece + (lane >> 4);
                 const int f = min(max(t0 - 2 + row, 0), p.T - 1);
                 const bf16_t* src = p.xin + ((int64_t)b * p.T + f) * 128 + 8 * ((lane & 15) ^ RB_SWZ(row));
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + piece * 1024), 16, 0, CPOL_NT);      // (read once: non-temporal)
             }
         }
         if (GATE && w4 == 3) {                                    // the utterance's gate row: 128 floats = 32 lanes x 16 B (the other lanes re-read it)
