@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
             const int row = pidx >> 5, pos = pidx & 31;
             const int cs = (pos & ~7) | ((pos ^ row) & 7);
             const int m = min(m0 + row, p.M - 1);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);      // (the next chunk of the tdnn1 output: read once)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
