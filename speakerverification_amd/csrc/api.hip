@@ -78,6 +78,7 @@ struct svhip_handle {
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
+        int rn_tail_big = 0;      // RawNet2 block tail: one workgroup per utterance at every batch size (tests)
         int r2_slices = -1;       // bf16 Res2Net chain: time slices per utterance (-1: by batch size, 0 / 1: whole utterances, n: forced)
     } opt;
     bool bf16 = false;                        // 16-bit storage handle: bf16, or fp16 when `f16` is set (the flag keeps its round-1 name)
@@ -1340,8 +1341,10 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
             char tl[48] = "rn_tail";
             if (h->opt.layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
             if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
+                     // (small batches: slice sums in rn_scratch, the gate in rn_gate[0]; option rn_tail_big keeps one workgroup per utterance)
+                     const bool sliced = !h->opt.rn_tail_big;
                      return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st,
-                                           resid_in_tail);
+                                           resid_in_tail, sliced ? rn_scratch : nullptr, sliced ? rn_gate[0] : nullptr, h->num_cu);
                  }))) return rc;
             T = Tn;
         } else {
@@ -1485,7 +1488,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1);
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2259,7 +2262,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
         {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
-        {"r2_slices", &o.r2_slices}, {"n128_off", &o.n128_off}};
+        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

@@ -557,6 +557,112 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
     }
 }
 
+// ---- the same tail for SMALL batches (the reference API's per-file calls: B = 10 - 20 crops) ---------------------------------------
+// One workgroup per utterance is 10 - 20 workgroups on 256 CUs, each walking load -> reduce -> matrix-vector -> store alone (33 us per
+// launch, six launches: a quarter of a B = 20 call).  Here an utterance is cut into S frame slices: rn_tail_part (grid S x B) writes the
+// slices' column sums of the pooled (+ residual) activation, rn_afms_gate (rn_block128.hip) turns them into the gate, rn_tail_apply
+// (grid S x B) forms the same values again and writes (v + alpha) * gate and the next pre-activation.  Same arithmetic per element as
+// rn_tail_kernel; the column mean is summed in a different order (fp32 round-off; a batch takes ONE of the two forms, by its size alone).
+constexpr int TAILS_THREADS = 256, TAILS_MAX_S = 16;
+
+template <typename T, bool POOL, bool RES>
+__device__ __forceinline__ Vec16<T> tail_value(const T* xb, const T* rb, int t, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    Vec16<T> v;
+    if (POOL) {
+        const T* q = xb + (int64_t)(3 * t) * C;
+        const Vec16<T> a = ld_nt<T>(q), bb = ld_nt<T>(q + C), d = ld_nt<T>(q + 2 * C);
+        if (RES) {
+            const T* r = rb + (int64_t)(3 * t) * C;
+            const Vec16<T> ra = ld_nt<T>(r), rbb = ld_nt<T>(r + C), rd = ld_nt<T>(r + 2 * C);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, fmaxf(fmaxf(a.get(j) + ra.get(j), bb.get(j) + rbb.get(j)), d.get(j) + rd.get(j)));
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, fmaxf(fmaxf(a.get(j), bb.get(j)), d.get(j)));
+        }
+    } else {
+        v = ld_nt<T>(xb + (int64_t)t * C);
+        if (RES) {
+            const Vec16<T> r = ld_nt<T>(rb + (int64_t)t * C);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + r.get(j));
+        }
+    }
+    return v;
+}
+
+// part[(b * S + s) * C + c] = sum over the frames of slice s of utterance b
+template <typename T, bool POOL, bool RES>
+__global__ __launch_bounds__(TAILS_THREADS) void rn_tail_part_kernel(const T* __restrict__ x, const T* __restrict__ res, float* __restrict__ part,
+                                                                     int Tin, int Tn, int C, int per) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float red[TAILS_THREADS / 32][512];     // [row group][channel]: cpr >= 32 (C >= 256 at VEC 8, >= 128 at VEC 4) -> <= 8 row groups
+    const int tid = threadIdx.x, s = blockIdx.x, S = gridDim.x;
+    const int64_t b = blockIdx.y;
+    const int cpr = C / VEC, rstep = TAILS_THREADS / cpr;
+    const int cc = tid % cpr, r0 = tid / cpr, c = cc * VEC;
+    const T* xb = x + b * Tin * (int64_t)C + c;
+    const T* rb = RES ? res + b * Tin * (int64_t)C + c : nullptr;
+    const int t0 = s * per, t1 = min(Tn, t0 + per);
+    float sum[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+#pragma unroll 4
+    for (int t = t0 + r0; t < t1; t += rstep) {
+        const Vec16<T> v = tail_value<T, POOL, RES>(xb, rb, t, C);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum[j] += v.get(j);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[r0][c + j] = sum[j];
+    __syncthreads();
+    for (int n = tid; n < C; n += TAILS_THREADS) {
+        float a = 0.0f;
+        for (int r = 0; r < rstep; ++r) a += red[r][n];
+        part[(b * S + s) * C + n] = a;
+    }
+}
+
+template <typename T, bool POOL, bool RES>
+__global__ __launch_bounds__(TAILS_THREADS) void rn_tail_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, T* __restrict__ pre,
+                                                                      const float* __restrict__ alpha, const float* __restrict__ gate,
+                                                                      const float* __restrict__ nscale, const float* __restrict__ nshift,
+                                                                      int Tin, int Tn, int C, int per, float slope) {
+    constexpr int VEC = Vec16<T>::N;
+    const int tid = threadIdx.x, s = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int cpr = C / VEC, rstep = TAILS_THREADS / cpr;
+    const int cc = tid % cpr, r0 = tid / cpr, c = cc * VEC;
+    const T* xb = x + b * Tin * (int64_t)C + c;
+    const T* rb = RES ? res + b * Tin * (int64_t)C + c : nullptr;
+    float al[VEC], g[VEC], ns[VEC], nh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        al[j] = alpha[c + j]; g[j] = gate[b * C + c + j];
+        ns[j] = pre ? nscale[c + j] : 0.0f; nh[j] = pre ? nshift[c + j] : 0.0f;
+    }
+    T* yb = y ? y + b * Tn * (int64_t)C + c : nullptr;
+    T* pb = pre ? pre + b * Tn * (int64_t)C + c : nullptr;
+    const int t0 = s * per, t1 = min(Tn, t0 + per);
+#pragma unroll 4
+    for (int t = t0 + r0; t < t1; t += rstep) {
+        const Vec16<T> v = tail_value<T, POOL, RES>(xb, rb, t, C);
+        Vec16<T> o, q;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.set(j, (v.get(j) + al[j]) * g[j]);
+        if (yb) *reinterpret_cast<Vec16<T>*>(yb + (int64_t)t * C) = o;
+        if (pb) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float w = fmaf(o.get(j), ns[j], nh[j]);
+                q.set(j, w > 0.0f ? w : slope * w);
+            }
+            *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+        }
+    }
+}
+
 inline int grid_for(int64_t items) {
     int64_t g = (items + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -643,12 +749,45 @@ bool rn_tail_supported(int dt, int Tn, int C) {
     return (int64_t)Tn * cpr <= (int64_t)TAIL_NCH * TAIL_THREADS;                                // the utterance fits the registers
 }
 
+// slices per utterance of the small-batch form (0: one workgroup per utterance, rn_tail_kernel)
+int rn_tail_slices(int dt, int B, int Tn, int C, int num_cu) {
+    const int vec = dt != DT_F32 ? 8 : 4;
+    if (B * 4 > num_cu || C % vec || C > 512 || C / vec < 32 || TAILS_THREADS % (C / vec)) return 0;
+    // the slice count depends on the utterance alone (about 48 frames per slice), never on the batch: an utterance's column mean is
+    // summed in the same order whatever batch (or batch slice: option lanes) it rides in
+    int S = (Tn + 47) / 48;
+    if (S > TAILS_MAX_S) S = TAILS_MAX_S;
+    return S >= 2 ? S : 0;
+}
+
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
-                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream, const void* res) {
+                          const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream, const void* res,
+                          float* part, float* gate, int num_cu) {
     const int Tn = pool ? Tin / 3 : Tin;
     if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(dt, Tn, C) || (pre && (!next_scale || !next_shift)))
         return hipErrorInvalidValue;
     if (res && dt == DT_F32) return hipErrorInvalidValue;       // (the residual form exists for the 16-bit handles, whose conv2 may run without one)
+    const int S = (part && gate) ? rn_tail_slices(dt, B, Tn, C, num_cu) : 0;
+    if (S > 0) {        // small batch: slice sums -> gate -> apply (part: B x S x C floats, gate: B x C floats)
+        const int per = (Tn + S - 1) / S;
+        const dim3 grid(S, B), block(TAILS_THREADS);
+#define SV_PART(TT, P, R) hipLaunchKernelGGL((rn_tail_part_kernel<TT, P, R>), grid, block, 0, stream, (const TT*)x, (const TT*)res, part, Tin, Tn, C, per)
+#define SV_APPLY(TT, P, R) hipLaunchKernelGGL((rn_tail_apply_kernel<TT, P, R>), grid, block, 0, stream, (const TT*)x, (const TT*)res, (TT*)y, (TT*)pre, \
+                                              alpha, gate, next_scale, next_shift, Tin, Tn, C, per, slope)
+#define SV_BOTH16(WHAT, TT) { if (res) { if (pool) WHAT(TT, true, true); else WHAT(TT, false, true); } else { if (pool) WHAT(TT, true, false); else WHAT(TT, false, false); } }
+        if (dt == DT_F16) SV_BOTH16(SV_PART, f16_t)
+        else if (dt == DT_BF16) SV_BOTH16(SV_PART, bf16_t)
+        else { if (pool) SV_PART(float, true, false); else SV_PART(float, false, false); }
+        if (hipError_t e = hipGetLastError()) return e;
+        if (hipError_t e = launch_rn_afms_gate(part, S, B, C, Tn, WT, bias, gate, stream)) return e;
+        if (dt == DT_F16) SV_BOTH16(SV_APPLY, f16_t)
+        else if (dt == DT_BF16) SV_BOTH16(SV_APPLY, bf16_t)
+        else { if (pool) SV_APPLY(float, true, false); else SV_APPLY(float, false, false); }
+#undef SV_BOTH16
+#undef SV_APPLY
+#undef SV_PART
+        return hipGetLastError();
+    }
 #define SV_TAIL(TT, P, R) hipLaunchKernelGGL((rn_tail_kernel<TT, P, R>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
                                              alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope, (const TT*)res)
 #define SV_TAIL16(TT) { if (res) { if (pool) SV_TAIL(TT, true, true); else SV_TAIL(TT, false, true); } else { if (pool) SV_TAIL(TT, true, false); else SV_TAIL(TT, false, false); } }

@@ -418,7 +418,10 @@ __global__ __launch_bounds__(512, 2) void rn_block128_kernel(RnBlock128Params p)
 // bound by re-reading the weight matrix per utterance (40 us).  Workgroup = 16 outputs x 16 utterances: both operand slices are
 // staged in LDS with every load in flight at once (WT = the fc weight transposed, so a slice is 64-byte row pieces), then
 // thread = (output, utterance) runs the dot product out of LDS.
-constexpr int GATE_N = 16, GATE_U = 16;
+// (GATE_U = 4 for small batches: four times the workgroups, and a thread sums the partial rows of 2 (c, utterance) pairs instead of 8 —
+//  at B = 20 the fused blocks hand over 56 partial rows per utterance and the kernel took 29 us)
+constexpr int GATE_N = 16;
+template <int GATE_U>
 __global__ __launch_bounds__(256) void rn_afms_gate_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_T,
                                                            const float* __restrict__ WT, const float* __restrict__ bias,
                                                            float* __restrict__ s) {
@@ -454,6 +457,7 @@ __global__ __launch_bounds__(256) void rn_afms_gate_kernel(const float* __restri
     }
     __syncthreads();
     const int n = tid & 15, u = tid >> 4;
+    if (u >= GATE_U) return;
     float acc = 0.0f;
 #pragma unroll 8
     for (int c = 0; c < C; ++c) acc = fmaf(wl[c * GATE_N + n], mt[c * GATE_U + u], acc);
@@ -506,9 +510,13 @@ hipError_t launch_rn_block128(const RnBlock128Params& p_in, int num_cu, hipStrea
 hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* WT, const float* bias, float* s,
                                hipStream_t stream) {
     if (!part || !WT || !bias || !s || C > 512 || C % 64 != 0 || nparts <= 0 || Tn <= 0 || B <= 0) return hipErrorInvalidValue;
-    const size_t lds = (size_t)C * (GATE_N + GATE_U) * sizeof(float);       // <= 64 KiB
-    hipLaunchKernelGGL(rn_afms_gate_kernel, dim3(C / GATE_N, (B + GATE_U - 1) / GATE_U), dim3(256), lds, stream, part, nparts, B, C,
-                       1.0f / (float)Tn, WT, bias, s);
+    if (B <= 64) {
+        const size_t lds = (size_t)C * (GATE_N + 4) * sizeof(float);
+        hipLaunchKernelGGL(rn_afms_gate_kernel<4>, dim3(C / GATE_N, (B + 3) / 4), dim3(256), lds, stream, part, nparts, B, C, 1.0f / (float)Tn, WT, bias, s);
+    } else {
+        const size_t lds = (size_t)C * (GATE_N + 16) * sizeof(float);       // <= 64 KiB
+        hipLaunchKernelGGL(rn_afms_gate_kernel<16>, dim3(C / GATE_N, (B + 15) / 16), dim3(256), lds, stream, part, nparts, B, C, 1.0f / (float)Tn, WT, bias, s);
+    }
     return hipGetLastError();
 }
 

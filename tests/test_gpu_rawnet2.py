@@ -160,6 +160,37 @@ def test_fused_tail_fp32_matches_separate_passes(L, B, monkeypatch):
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("compute,L,B", [("f32", 32000, 5), ("f16", 32000, 20), ("bf16", 20000, 3), ("f16", 32000, 64)])
+def test_small_batch_tail_in_slices_matches_the_one_workgroup_tail(compute, L, B):
+    """Round 4: at B * 4 <= CUs the block tail (max-pool + AFMS + next pre-activation) runs as slice sums -> rn_afms_gate -> apply over
+    up to 16 workgroups per utterance instead of one (csrc/rawnet2.hip: rn_tail_part / rn_tail_apply; 33 -> ~13 us per tail at B = 20).
+    Same arithmetic per element; the column mean is summed in another order.  Option rn_tail_big keeps the one-workgroup kernel."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=7)
+    wav = synth.synth_waveforms(B, L, seed=14)
+    eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    outs = {}
+    for big in (1, 0):
+        eng.set_option("rn_tail_big", big)
+        outs[big] = eng.embed_wave(wav).reshape(B, -1).copy()
+        if not big:
+            assert np.array_equal(eng.embed_wave(wav).reshape(B, -1), outs[big])       # deterministic
+    eng.close()
+    a, b = outs[1], outs[0]
+    assert np.isfinite(b).all()
+    scale = float(np.abs(a).max())
+    diff = float(np.abs(a - b).max()) / scale
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    print(f"{compute} L={L} B={B}: sliced vs one-workgroup tail: max diff / scale {diff:.2e}, min cos {cos.min():.7f}")
+    if compute == "f32":
+        assert diff <= 2e-5
+    elif compute == "f16":
+        assert cos.min() >= 0.99999 and diff <= 2e-3
+    else:       # bf16 RawNet2 (the range-safe fallback): a gate that moves by fp32 round-off moves 8-bit-mantissa block outputs across rounding boundaries
+        assert cos.min() >= 0.999 and diff <= 2e-2
+
+
 @pytest.mark.parametrize("half", ["bf16", "f16"])
 @pytest.mark.parametrize("L", [16001, 20003])
 def test_bf16_sample_counts_that_are_not_a_multiple_of_8(L, half):
@@ -259,7 +290,9 @@ def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, la
     else:
         a, b = outs[1], outs[lanes]
         cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-        assert cos.min() >= 0.9999, cos.min()
+        # (bf16 RawNet2, the range-safe fallback mode: an AFMS gate that moves by fp32 round-off moves 8-bit-mantissa block outputs across
+        #  rounding boundaries, eight blocks deep — 0.99989 - 0.99993 by summation order; fp16, RawNet2's 16-bit mode, sits at 0.9999997)
+        assert cos.min() >= (0.9995 if (model, compute) == ("rawnet2", "bf16") else 0.9999), cos.min()
         assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()
 
 
