@@ -73,6 +73,7 @@ struct svhip_handle {
         int asnorm_slab = 0;      // AS-norm statistics on the slab path
         int asnorm_f32mfma = 0;   // AS-norm fused kernel on the exact fp32 MFMA instead of a split form
         int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
+        int asnorm_w32 = 0;       // AS-norm two-half-plane kernel on the 32-wide MFMA (round 4's first form) instead of 16x16x32
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
@@ -1487,7 +1488,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         svhip_handle::DevOpts& o = h->opt;
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
-        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
+        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
         o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG");
     }
     h->esz = h->bf16 ? 2 : 4;
@@ -2009,7 +2010,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         const int64_t chunk = std::min<int64_t>(N, 131072);
         void *mb, *cand, *cnt, *flag;
         const size_t mb_bytes = (size_t)(D + 32) * D * 4;          // [MB | slice partials of its computation]
-        const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 2;
+        const size_t cand_elems = (size_t)chunk * 2 * ASNORM_CAND_PER_LANE, cnt_elems = (size_t)chunk * 4;      // (2 or 4 candidate lists per embedding)
         // (the exact default is the six-bf16-MFMA form where it is built: scores to fp32 rounding at 2.7 x the fp32 matrix rate)
         // (the exact default is a split form where it is built: scores to fp32 rounding at several times the fp32 matrix rate — two half
         //  planes / three fp16 MFMAs (D = 192, 256); option asnorm_x6: three bf16 planes / six bf16 MFMAs, round 3's form, D = 192)
@@ -2036,6 +2037,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             void* planes = (char*)mb + mb_bytes + mom_bytes;
             if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream, nplanes); }))) return rc;
             fp.planes = planes; fp.nplanes = nplanes;
+            fp.nlists = (nplanes == 2 && !h->opt.asnorm_w32) ? 4 : 2;       // the 16-wide-MFMA kernel: four lists per embedding
         }
         int c = 0;
         for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
@@ -2056,7 +2058,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             }
             h->cur = st2;
             rc = run(h, "asnorm_cand_stats", 0, [&]() {
-                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2);
+                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2, fp.nlists);
             });
             h->cur = h->stream;
             if (rc) {           // leave no aux-stream work pending behind a failed call
@@ -2261,7 +2263,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

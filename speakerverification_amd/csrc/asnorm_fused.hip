@@ -341,6 +341,182 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
     if (valid) p.cnt[row * 2 + h] = cnt;
 }
 
+// ---- the two-half-plane form on v_mfma_f32_16x16x32_f16 ("h3w", round 4, the default) -------------------------------------------------
+// Same arithmetic as asnorm_fused6_kernel<D, 2> (hi.hi + hi.lo + lo.hi on IEEE-half planes, fp32 accumulate), on the 16-wide MFMA: on random
+// data the chip holds a higher clock under the 16x16x32 instruction than under 32x32x16 (bare loops: 1.87 against 1.63 PFLOP/s,
+// tools/mfma_rate.hip; MI355X_MICROARCH.md, DVFS give-back), and this kernel runs at the pace of its MFMAs.  A wave still owns 32 embeddings
+// and walks the cohort in blocks of 32 rows: 2 row groups x 2 embedding groups of 16 per k step of 32.  Accumulator layout: lane (c = lane & 15,
+// q = lane >> 4) holds the scores of cohort rows 16 rg + 4 q + e (e = 0..3) against embedding 16 eg + c — so a lane selects for TWO embeddings,
+// and an embedding's candidates come from FOUR lanes: four candidate lists of ASNORM_CAND_PER_LANE / 2 per embedding (AsnormFusedParams::nlists).
+template <int D>
+__global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = D / 8;                       // 16-byte chunks (8 values) per row of a plane
+    constexpr int PL = 32 * D * 2;                  // one plane of a block of 32 rows
+    constexpr int BLK = 2 * PL;
+    constexpr int NDMA = 2 * 32 * CH / 256;         // DMA instructions per thread per block
+    constexpr int NP = D / 32 + 1;                  // pseudo-cohort blocks: rows of M, then cbar
+    constexpr int NS = D / 32;                      // MFMA k steps (32 wide) per block
+    constexpr int CAPQ = AF_CAPL / 2;               // candidate slots per (embedding, q)
+    static_assert(D % 64 == 0 && (2 * 32 * CH) % 256 == 0 && CH % 8 == 0, "block image: whole DMA rounds, chunk groups of 8");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32 + c;            // embedding of group 0 (group 1: + 16)
+    bool valid[2];
+    uint32_t eoff[2];                                                          // < 2^31 elements per launch (host check)
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg) {
+        const int64_t r = row0 + 16 * eg;
+        valid[eg] = r < p.N;
+        eoff[eg] = (uint32_t)((valid[eg] ? r : p.N - 1) * D);
+    }
+
+    // B operand: embedding (16 eg + c), k = 32 s + 8 q .. + 7, as half hi | lo parts
+    bf16x8 bh[2][NS], bl[2][NS];
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg)
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q + 4);
+            f16x8 a8, b8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const f16_t a = static_cast<f16_t>(v);
+                a8[u] = a;
+                b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
+            }
+            bh[eg][s_] = __builtin_bit_cast(bf16x8, a8);
+            bl[eg][s_] = __builtin_bit_cast(bf16x8, b8);
+        }
+
+    const int rows_total = NP * 32 + p.K;
+    const int nb = (rows_total + 31) / 32;
+    const char* planes = reinterpret_cast<const char*>(p.planes);
+    const int64_t plane_bytes = (int64_t)rows_total * D * 2;
+    // the block image is the one of asnorm_fused6_kernel: lane-linear DMA, the swizzle on the source chunk
+    auto issue = [&](int b, int buf) {
+        const int r0 = b * 32;
+        const int limit = rows_total - 1 - r0;          // the last block clamps its rows
+#pragma unroll
+        for (int qq = 0; qq < NDMA; ++qq) {
+            const int pidx = qq * 256 + tid;
+            const int pl = pidx / (32 * CH), rem = pidx - pl * (32 * CH);
+            const int i = rem / CH, cs = rem - i * CH;
+            const int cc = (cs & ~7) | ((cs ^ (i >> 1)) & 7);
+            const char* src = planes + pl * plane_bytes + ((int64_t)(r0 + min(i, limit)) * D + cc * 8) * 2;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + buf * BLK + (qq * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    // A fragment: cohort row 16 rg + c of the block, k = 32 s + 8 q .. + 7 (chunk 4 s + q of the row).  The 16 lanes of one q read 16 rows at
+    // one logical chunk: 8 keys x even / odd row (row stride 384 B = 1.5 bank periods at D = 192): 16 distinct 16-byte slots, no conflict
+    auto rd = [&](int buf, int pl, int rg, int s_) {
+        const int i = 16 * rg + c, cs = 4 * s_ + q;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BLK + pl * PL + i * (D * 2) + (((cs & ~7) | ((cs ^ (i >> 1)) & 7)) << 4));
+    };
+    typedef f32x4 acc_t[2][2];
+    auto mfma_block = [&](int buf, acc_t& acc) {
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A fragments one k step ahead of their MFMAs, fenced (see asnorm_fused6_kernel)
+        bf16x8 ah[2] = {rd(buf, 0, 0, 0), rd(buf, 0, 1, 0)}, al[2] = {rd(buf, 1, 0, 0), rd(buf, 1, 1, 0)};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            bf16x8 nh[2] = {ah[0], ah[1]}, nl[2] = {al[0], al[1]};
+            if (s_ + 1 < NS) {
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) { nh[rg] = rd(buf, 0, rg, s_ + 1); nl[rg] = rd(buf, 1, rg, s_ + 1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // small terms first; the four accumulators of a term are independent
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(al[rg], bh[eg][s_], acc[rg][eg]);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(ah[rg], bl[eg][s_], acc[rg][eg]);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(ah[rg], bh[eg][s_], acc[rg][eg]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) { ah[rg] = nh[rg]; al[rg] = nl[rg]; }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    float second[2] = {0.0f, 0.0f}, tau[2] = {0.0f, 0.0f};
+    int cnt[2] = {0, 0};
+    uint32_t coff[2];
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg) coff[eg] = (uint32_t)(((valid[eg] ? row0 + 16 * eg : 0) * 4 + q) * CAPQ);
+    auto process = [&](const acc_t& a, int b) {
+        if (b < NP - 1) {               // rows of M: (M e)_i . e_i, i = 32 b + 16 rg + 4 q + e
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(p.E + eoff[eg] + 32 * b + 16 * rg + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) second[eg] = fmaf(a[rg][eg][u], ev[u], second[eg]);
+                }
+        } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of row group 0 of the q = 0 lanes
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg) {
+                const float m = __shfl(a[0][eg][0], c, 64);
+                float sec = second[eg];
+                sec += __shfl_xor(sec, 16, 64);
+                sec += __shfl_xor(sec, 32, 64);
+                tau[eg] = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+            }
+        } else {
+            const int kb = (b - NP) * 32 + 4 * q;
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = kb + 16 * rg + u;
+                        const float v = a[rg][eg][u];
+                        if (i < p.K && v > tau[eg]) {
+                            if (cnt[eg] < CAPQ && valid[eg]) p.cand[coff[eg] + cnt[eg]] = v;
+                            ++cnt[eg];
+                        }
+                    }
+        }
+    };
+
+    issue(0, 0);
+    acc_t accp;
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+        for (int eg = 0; eg < 2; ++eg) accp[rg][eg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // block b has landed (and the candidate stores of one block ago, long since)
+        __syncthreads();                                       // ... for every wave; nobody still reads the other buffer
+        if (b + 1 < nb) issue(b + 1, (b + 1) & 1);
+        if (b > 0) process(accp, b - 1);                       // the selection of the PREVIOUS block first (asnorm_fused6_kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(b & 1, accp);
+    }
+    process(accp, nb - 1);
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg)
+        if (valid[eg]) p.cnt[(row0 + 16 * eg) * 4 + q] = cnt[eg];
+}
+
 // fp32 rows -> three bf16 planes [3][rows_total][D]: rows [0, n0) from A (the pseudo-cohort rows MB), the rest from B (the cohort)
 __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
                                                             bf16_t* __restrict__ planes) {
@@ -369,15 +545,21 @@ __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restr
     }
 }
 
-// one wave per embedding: exact statistics of the top-`top` of its candidates; rows that cannot be decided are flagged
+// one wave per embedding: exact statistics of the top-`top` of its candidates; rows that cannot be decided are flagged.
+// NL candidate lists per embedding (2: one per half-wave lane of the 32-wide kernels; 4: the 16-wide kernel), 2 * AF_CAPL slots in all.
+template <int NL>
 __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cnt, int64_t rows,
                                                                 int top, float* __restrict__ mu, float* __restrict__ sigma,
                                                                 int64_t row_base, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+    constexpr int CAP = 2 * AF_CAPL / NL;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int c0 = cnt[row * 2], c1 = cnt[row * 2 + 1];
-    if (c0 + c1 < top || c0 > AF_CAPL || c1 > AF_CAPL) {
+    int cn[NL], total = 0;
+    bool over = false;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { cn[l] = cnt[row * NL + l]; total += cn[l]; over |= cn[l] > CAP; }
+    if (total < top || over) {
         if (lane == 0) flagged[atomicAdd(nflag, 1)] = (int32_t)(row_base + row);
         return;
     }
@@ -385,11 +567,14 @@ __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __r
     uint32_t ck[2 * AF_CAPL / 64];
 #pragma unroll
     for (int q = 0; q < 2 * AF_CAPL / 64; ++q) {
-        const int idx = lane + 64 * q;
+        int idx = lane + 64 * q;            // position in the concatenation of the lists
         float v = 0.0f;
         bool in = false;
-        if (idx < c0) { v = c[idx]; in = true; }
-        else if (idx - c0 < c1) { v = c[AF_CAPL + idx - c0]; in = true; }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (!in && idx >= 0 && idx < cn[l]) { v = c[l * CAP + idx]; in = true; }
+            idx -= cn[l];
+        }
         ck[q] = in ? fkey(v) : 0u;
     }
     float m, sd;
@@ -497,6 +682,7 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
     if (p.N <= 0) return hipSuccess;
     if (!asnorm_fused_supported(D, p.K, 1) || !p.E || !p.cohort || !p.MB || !p.cand || !p.cnt) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(p.E) | reinterpret_cast<uintptr_t>(p.cohort) | reinterpret_cast<uintptr_t>(p.MB)) & 15) return hipErrorInvalidValue;
+    if (p.nlists != 2 && !(p.nlists == 4 && p.planes && p.nplanes == 2)) return hipErrorInvalidValue;      // (four lists: the 16-wide half-plane kernel only)
     if (p.planes) {                                       // the split forms: three fp16 MFMAs on two half planes / six bf16 MFMAs on three
         if (!asnorm_fused6_supported(D, p.nplanes) || (reinterpret_cast<uintptr_t>(p.planes) & 15) || p.N > (int64_t)1 << 21) return hipErrorInvalidValue;      // (32-bit lane offsets)
         const dim3 grid((unsigned)((p.N + 127) / 128));
@@ -509,6 +695,19 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
             return hipGetLastError();                                                                                       \
         }
         if (p.nplanes == 3) SV_AF6(192, 3)
+        if (p.nlists == 4) {            // two half planes on the 16-wide MFMA (the default)
+#define SV_H3W(DD)                                                                                                          \
+            {                                                                                                               \
+                static DeviceOnce attrw;                                                                                    \
+                constexpr int ldsw = 2 * 2 * 32 * DD * 2;                                                                   \
+                if (hipError_t e = set_max_dynamic_lds(attrw, reinterpret_cast<const void*>(asnorm_h3w_kernel<DD>), ldsw)) return e; \
+                hipLaunchKernelGGL((asnorm_h3w_kernel<DD>), grid, dim3(256), ldsw, stream, p);                              \
+                return hipGetLastError();                                                                                   \
+            }
+            if (D == 192) SV_H3W(192)
+            SV_H3W(256)
+#undef SV_H3W
+        }
         if (D == 192) SV_AF6(192, 2)
         SV_AF6(256, 2)
 #undef SV_AF6
@@ -521,10 +720,15 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
 }
 
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
-                                    int32_t* flagged, int32_t* nflag, hipStream_t stream) {
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(asnorm_cand_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
-                       flagged, nflag);
+    if (nlists == 4)
+        hipLaunchKernelGGL(asnorm_cand_stats_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
+                           flagged, nflag);
+    else if (nlists == 2)
+        hipLaunchKernelGGL(asnorm_cand_stats_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
+                           flagged, nflag);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

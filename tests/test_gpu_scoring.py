@@ -322,4 +322,13 @@ def test_asnorm_six_bf16_mfma_form_agrees_with_the_fp32_mfma_form(monkeypatch):
           "| h3 vs fp32 MFMA: mu", float(np.abs(mu3 - mu1).max()))
     assert float(np.abs(mu3 - rmu).max()) <= 1e-6 and float((np.abs(sd3 - rsd) / rsd).max()) <= 1e-4
     assert float(np.abs(mu3 - mu1).max()) <= 5e-7 and float(np.abs(sd3 - sd1).max()) <= 5e-7
+    # round 4 (late): the default runs on v_mfma_f32_16x16x32_f16 (four candidate lists per embedding); option asnorm_w32 keeps the 32-wide
+    # form (two lists).  Same three products per block in the same order within a k step; the k steps are 32 wide instead of 16
+    eng.set_option("asnorm_w32", 1)
+    muw, sdw = eng.asnorm_stats(E, cohort, top)
+    eng.set_option("asnorm_w32", 0)
+    assert eng.asnorm_last_fallback == 0
+    print("16-wide vs 32-wide half-plane kernel: mu", float(np.abs(mu3 - muw).max()), "sd", float(np.abs(sd3 - sdw).max()))
+    assert float(np.abs(mu3 - muw).max()) <= 2e-7 and float(np.abs(sd3 - sdw).max()) <= 2e-7
+    assert float(np.abs(muw - rmu).max()) <= 1e-6
     eng.close()
