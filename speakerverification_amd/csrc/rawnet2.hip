@@ -9,8 +9,8 @@
 //                   (hop 1 => rows overlap in all but one sample).  MFMA tile (g, j) holds conv positions
 //                   3*(32g + r) + j, so the three max-pool partners of a pooled frame sit in the same
 //                   lane / register of three accumulators and the pool is an elementwise max.
-//                   bf16: v_mfma_f32_32x32x16_bf16, operand fetched as aligned 16-byte reads from 8
-//                   sample-shifted LDS copies;  fp32: v_mfma_f32_32x32x2_f32 with 4-byte reads.
+//                   16-bit: v_mfma_f32_16x16x32 (round 4; 32x32x16 before: 477 -> 460 us), operand fetched as aligned 16-byte
+//                   reads from 8 sample-shifted LDS copies;  fp32: v_mfma_f32_32x32x2_f32 with 4-byte reads.
 //   rn_bn_act     : y = LeakyReLU(x*scale + shift)                       (pre-activation of the blocks)
 //   rn_maxpool3   : max_pool1d(3) along frames
 //   rn_afms_apply : (x + alpha) * s[b, c]                                (AFMS, RawNet_baseline.py:66-67)
@@ -106,8 +106,11 @@ struct SincCfg16 {
     // ds_read_b128 lane groups of the fragment pattern (positions 3 * frame + j: stride-3 rows across the 8 copies) spread over
     // the banks.  A uniform stride of 960 bytes cost one extra LDS cycle per lane group on average (PMC: bank-conflict cycles
     // = 28 % of the kernel's CU cycles); this assignment a third of that — no assignment of 8 offsets is conflict-free.
+    // (round 4: the fragment pattern is that of v_mfma_f32_16x16x32 — 16 lanes = 16 pooled frames at one k chunk, conv positions 3 frame + j —
+    //  and the offsets were searched again for it: exhaustively, no assignment is conflict-free; this one has one 2-way pair in two of the
+    //  three pool-partner patterns)
     static constexpr int COPY_BYTES = 1280;                    // 928 bytes of samples + up to 240 of skew, 256-byte multiple
-    static constexpr unsigned COPY_SKEW = 0xEC924960u;         // offsets 0, 6, 9, 4, 2, 9, 12, 14 (x 16 bytes) for copies 0..7
+    static constexpr unsigned COPY_SKEW = 0x7E49C210u;         // offsets 0, 1, 2, 12, 9, 4, 14, 7 (x 16 bytes) for copies 0..7
     static constexpr int XLDS = 8 * COPY_BYTES;                // one operand buffer: 8 sample-shifted copies of the tile
     static constexpr int OUT_OFF = (2 * XLDS + 255) & ~255;    // two operand buffers, then two output images
     static constexpr int OUT_BYTES = SINC_PT * 256;            // output tile: SINC_PT pooled frames x 128 filters, bf16
@@ -152,17 +155,20 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
     // 64 filters x 32 pooled positions, so every operand fragment read from LDS feeds TWO MFMAs — with one filter block per
     // wave the kernel sat on the LDS read port (1 KiB per MFMA from 8 waves = 256 B/clk per CU): 0.91 ms -> see DESIGN.md
     const int nf = wave & 1, gw = wave >> 1;
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = lane & 31, fh = lane >> 5;          // fp32 path: 32x32x2 fragment coordinates
+    const int r16 = lane & 15, q4 = lane >> 4;         // 16-bit path: 16x16x32 fragment coordinates
 
-    // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand)
-    bf16x8 wfb[BF ? 2 : 1][BF ? 16 : 1];
+    // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand).  16-bit path (round 4):
+    // v_mfma_f32_16x16x32 — four blocks of 16 filters x eight k steps of 32 (the chip holds a higher clock under this instruction than under
+    // 32x32x16: tools/mfma_rate.hip); a lane owns filters 4 q4 .. + 3 of a block for pooled frame r16 of a 16-frame group
+    bf16x8 wfb[BF ? 4 : 1][BF ? 8 : 1];
     float wff[BF ? 1 : 126];
     if (BF) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(nf * 64 + blk * 32 + fr) * 256 * 2 + fh * 16;
+        for (int fb = 0; fb < 4; ++fb) {
+            const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(nf * 64 + fb * 16 + r16) * 256 * 2 + q4 * 16;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) wfb[blk][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 32);
+            for (int kk = 0; kk < 8; ++kk) wfb[fb][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 64);
         }
     } else {
         const float* w = reinterpret_cast<const float*>(filt) + (int64_t)(wave * 32 + fr) * 252 + fh;
@@ -256,32 +262,23 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
             __syncthreads();
         }
         // acc[a][j]: fp32: a = position group g (filters of this wave); bf16: a = filter block of this wave's half (position group gw)
-        f32x16 acc[2][3];
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+        f32x16 acc[BF ? 1 : 2][BF ? 1 : 3];           // fp32 path: [position group][pool partner]
+        // 16-bit path: the wave's 32 pooled frames are two groups of 16, multiplied and finished ONE AFTER THE OTHER (12 accumulators of
+        // 16 x 16 live at a time: with all 24 the kernel needs 270 registers and spills its filter fragments into the tile loop)
+        const char* base[3] = {nullptr, nullptr, nullptr};
         if (BF) {
-            const char* base[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int s = 3 * (32 * gw + fr) + j;                         // conv position inside the tile
-                base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + fh) * 16;
-            }
-            // K step outermost: six independent accumulators in flight (with the pool partner j outermost, consecutive MFMAs on the
-            // same accumulator were two issues apart — a dependent 32x32x16 needs the previous result)
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base[j] + kk * 32);
-                    acc[0][j] = Half16<H>::mfma32(wfb[0][kk], xf, acc[0][j]);
-                    acc[1][j] = Half16<H>::mfma32(wfb[1][kk], xf, acc[1][j]);
-                }
+                const int s = 3 * (32 * gw + r16) + j;                           // conv position inside the tile (frame group 0; group 1: + 48)
+                base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + q4) * 16;
             }
         } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -292,22 +289,46 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                         acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wff[kk], base[2 * kk], acc[g][j], 0, 0, 0);
                 }
         }
-        // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 filters per group
-        int fr_e = fr, fh_e = fh;
+        // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 consecutive filters per accumulator
+        int fr_e = BF ? r16 : fr, fh_e = BF ? q4 : fh;
         asm volatile("" : "+v"(fr_e), "+v"(fh_e));
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int tp = tp0 + 32 * (BF ? gw : g) + fr_e;
+            // 16-bit path: g = 16-frame group of this wave's 32 pooled frames, q = filter block; fp32 path: g = position group, q = 8-filter group
+            f32x4 acc16[BF ? 4 : 1][BF ? 3 : 1];              // [filter block][pool partner]
+            if (BF) {
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc16[fb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // K step outermost: 12 independent accumulators; an operand fragment (one ds_read_b128) feeds the four filter blocks.  The
+                // 24 fragment reads are issued two ahead of their MFMAs through a ring of three, fenced (the compiler otherwise hoists them
+                // in bulk); frame group 1 starts 48 conv positions = 6 chunks of the SAME copy further on (+ 96 bytes)
+                auto xread = [&](int idx) { return *reinterpret_cast<const bf16x8*>(base[idx % 3] + g * 96 + (idx / 3) * 64); };
+                bf16x8 ring[3];
+                ring[0] = xread(0);
+                ring[1] = xread(1);
+#pragma unroll
+                for (int idx = 0; idx < 24; ++idx) {
+                    if (idx + 2 < 24) ring[(idx + 2) % 3] = xread(idx + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int fb = 0; fb < 4; ++fb) acc16[fb][idx % 3] = Half16<H>::mfma16(wfb[fb][idx / 3], ring[idx % 3], acc16[fb][idx % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int tp = tp0 + (BF ? 32 * gw + 16 * g : 32 * g) + fr_e;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f = (BF ? nf * 64 + g * 32 : wave * 32) + 8 * q + 4 * fh_e;
+                const int f = BF ? nf * 64 + q * 16 + 4 * fh_e : wave * 32 + 8 * q + 4 * fh_e;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(bnl + f);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(bnl + 128 + f);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * q + e;
-                    const float m = fmaxf(fmaxf(fabsf(acc[g][0][r]), fabsf(acc[g][1][r])), fabsf(acc[g][2][r]));
+                    float m;
+                    if (BF) m = fmaxf(fmaxf(fabsf(acc16[q][0][e]), fabsf(acc16[q][1][e])), fabsf(acc16[q][2][e]));
+                    else { const int r = 4 * q + e; m = fmaxf(fmaxf(fabsf(acc[g][0][r]), fabsf(acc[g][1][r])), fabsf(acc[g][2][r])); }
                     const float y = fmaf(m, sc[e], sh[e]);
                     v[e] = y > 0.0f ? y : 0.3f * y;
                 }
@@ -319,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                     if (BF) {
                         typedef H bf16x4 __attribute__((ext_vector_type(4)));
                         bf16x4 pk = {static_cast<H>(v[0]), static_cast<H>(v[1]), static_cast<H>(v[2]), static_cast<H>(v[3])};
-                        {   // 8-byte chunk c8 of row `row` lives at chunk c8 ^ (row & 31): the 32 rows of one store land on 32 banks
-                            const int row = 32 * gw + fr_e, c8 = f >> 2;
+                        {   // 8-byte chunk c8 of row `row` lives at chunk c8 ^ (row & 31): the 16 rows x 4 chunks of one store land on 64 banks
+                            const int row = 32 * gw + 16 * g + fr_e, c8 = f >> 2;
                             *reinterpret_cast<bf16x4*>(otile + row * 256 + ((c8 ^ (row & 31)) << 3)) = pk;
                         }
                         if (pre) {
