@@ -73,6 +73,7 @@ struct svhip_handle {
         int asnorm_slab = 0;      // AS-norm statistics on the slab path
         int asnorm_f32mfma = 0;   // AS-norm fused kernel on the exact fp32 MFMA instead of a split form
         int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
+        int score_tiled = 0;      // dense score GEMMs on the tiled split kernel (gemm_pw) instead of the row-streaming one (score_h3w)
         int asnorm_w32 = 0;       // AS-norm two-half-plane kernel on the 32-wide MFMA (round 4's first form) instead of 16x16x32
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
@@ -1488,7 +1489,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         svhip_handle::DevOpts& o = h->opt;
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
-        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
+        o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
         o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG");
     }
     h->esz = h->bf16 ? 2 : 4;
@@ -1927,6 +1928,11 @@ static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64
                       const void* dBsplit = nullptr) {
     if (D % 32 != 0) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embedding dim %d must be a multiple of 32", D);
     if (Na > (1 << 30) / 1 || Nb > (1 << 30)) SV_FAIL(h, SVHIP_ERR_INVALID, "matrix too large");
+    // D = 192 / 256 (what the models produce): rows of A in registers, B streamed past them as half planes (asnorm_fused.hip: score_h3w)
+    if (dBsplit && !h->opt.score_tiled && score_h3w_supported(D, Na, Nb) && ((reinterpret_cast<uintptr_t>(dA) | reinterpret_cast<uintptr_t>(dB)) & 15) == 0) {
+        hipStream_t st = h->stream;
+        return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_score_h3w(dA, Na, dB, Nb, D, dO, ldo, const_cast<void*>(dBsplit), h->num_cu, st); });
+    }
     GemmParams p;
     p.A = dA; p.W = dB; p.Y = dO;
     p.M = (int)Na; p.N = (int)Nb; p.K = D; p.Kp = D; p.Wrows = (int)Nb;
@@ -1943,6 +1949,8 @@ static int split_b(svhip_handle* h, const float* dB, int64_t Nb, int D, void** o
     *out = nullptr;
     if (h->opt.score_f32mfma && !h->x3) return SVHIP_OK;
     if (int rc = scratch(h, svhip_handle::SCR_SPLIT, (size_t)Nb * D * 4, out)) return rc;
+    // (the row-streaming kernel fills the same scratch with its own half planes: [2][Nb][D] halves are the same Nb * D * 4 bytes)
+    if (!h->opt.score_tiled && score_h3w_supported(D, 1, Nb) && (reinterpret_cast<uintptr_t>(dB) & 15) == 0) return SVHIP_OK;
     return run(h, "split_words", 0, [&]() { return launch_split_words(dB, *out, Nb * D, h->stream); });
 }
 
@@ -2263,7 +2271,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

@@ -517,6 +517,139 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
         if (valid[eg]) p.cnt[(row0 + 16 * eg) * 4 + q] = cnt[eg];
 }
 
+// ---- dense score matrix on the same machinery: out[i][j] = A_i . B_j (svhip_score_matrix, the slab path's cohort GEMM) --------------------
+// K = D = 192 / 256 is six / eight k steps: as a tiled GEMM (gemm_pw's split form, 256 x 128 tiles) the kernel spent its time fetching fp32
+// operands (43 FLOP per byte) — 152 TFLOP/s, 0.68 ms for 16 384 x 16 384.  Here a wave keeps 32 rows of A in registers as half hi | lo parts
+// and streams B (pre-split half planes, blocks of 32 rows through the LDS image of the AS-norm kernel) past them: three fp16 MFMAs per
+// product block on v_mfma_f32_16x16x32_f16, scores stored straight from the accumulators (lane = 4 consecutive columns of one row: 16-byte
+// stores, a 128-byte line per row per block).  Grid (row panels of 128, column slices): every workgroup walks `per` blocks of B.
+template <int D>
+__global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = D / 8;
+    constexpr int PL = 32 * D * 2;
+    constexpr int BLK = 2 * PL;
+    constexpr int NDMA = 2 * 32 * CH / 256;
+    constexpr int NS = D / 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32 + c;
+    bool valid[2];
+    int64_t arow[2];
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg) {
+        arow[eg] = row0 + 16 * eg;
+        valid[eg] = arow[eg] < p.Na;
+    }
+    bf16x8 bh[2][NS], bl[2][NS];
+#pragma unroll
+    for (int eg = 0; eg < 2; ++eg) {
+        const float* src = p.A + (valid[eg] ? arow[eg] : p.Na - 1) * D;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 32 * s_ + 8 * q);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 32 * s_ + 8 * q + 4);
+            f16x8 a8, b8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const f16_t a = static_cast<f16_t>(v);
+                a8[u] = a;
+                b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
+            }
+            bh[eg][s_] = __builtin_bit_cast(bf16x8, a8);
+            bl[eg][s_] = __builtin_bit_cast(bf16x8, b8);
+        }
+    }
+    const int nb_all = (p.Nb + 31) / 32;
+    const int b_first = blockIdx.y * p.per, b_last = min(nb_all, b_first + p.per);
+    if (b_first >= b_last) return;                                                  // workgroup-uniform
+    const char* planes = reinterpret_cast<const char*>(p.planes);
+    const int64_t plane_bytes = (int64_t)p.Nb * D * 2;
+    auto issue = [&](int b, int buf) {
+        const int r0 = b * 32;
+        const int limit = p.Nb - 1 - r0;            // the last block clamps its rows
+#pragma unroll
+        for (int qq = 0; qq < NDMA; ++qq) {
+            const int pidx = qq * 256 + tid;
+            const int pl = pidx / (32 * CH), rem = pidx - pl * (32 * CH);
+            const int i = rem / CH, cs = rem - i * CH;
+            const int cc = (cs & ~7) | ((cs ^ (i >> 1)) & 7);
+            const char* src = planes + pl * plane_bytes + ((int64_t)(r0 + min(i, limit)) * D + cc * 8) * 2;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + buf * BLK + (qq * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto rd = [&](int buf, int pl, int rg, int s_) {
+        const int i = 16 * rg + c, cs = 4 * s_ + q;
+        return *reinterpret_cast<const bf16x8*>(smem + buf * BLK + pl * PL + i * (D * 2) + (((cs & ~7) | ((cs ^ (i >> 1)) & 7)) << 4));
+    };
+    const bool vec_ok = (p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+    // a wave whose 32 rows are all inside A issues exactly four 16-byte store instructions per interior block, AFTER the next block's DMAs:
+    // the wait for block b may then leave those four (the newest entries of the in-order counter) in flight instead of draining them
+    const bool rows_full = vec_ok && ((int64_t)blockIdx.x * 128 + wave * 32 + 32 <= p.Na);      // wave-uniform
+    bool four_stores_behind = false;
+    issue(b_first, 0);
+    for (int b = b_first; b < b_last; ++b) {
+        const int buf = (b - b_first) & 1;
+        if (four_stores_behind) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // block b has landed; the previous block's stores may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        four_stores_behind = rows_full && (32 * b + 32 <= p.Nb);
+        __syncthreads();
+        if (b + 1 < b_last) issue(b + 1, buf ^ 1);
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 ah[2] = {rd(buf, 0, 0, 0), rd(buf, 0, 1, 0)}, al[2] = {rd(buf, 1, 0, 0), rd(buf, 1, 1, 0)};
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            bf16x8 nh[2] = {ah[0], ah[1]}, nl[2] = {al[0], al[1]};
+            if (s_ + 1 < NS) {
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) { nh[rg] = rd(buf, 0, rg, s_ + 1); nl[rg] = rd(buf, 1, rg, s_ + 1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(al[rg], bh[eg][s_], acc[rg][eg]);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(ah[rg], bl[eg][s_], acc[rg][eg]);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int eg = 0; eg < 2; ++eg) acc[rg][eg] = Half16<f16_t>::mfma16(ah[rg], bh[eg][s_], acc[rg][eg]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) { ah[rg] = nh[rg]; al[rg] = nl[rg]; }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // acc[rg][eg][e] = A row (16 eg + c of the wave) . B row 32 b + 16 rg + 4 q + e
+#pragma unroll
+        for (int eg = 0; eg < 2; ++eg) {
+            if (!valid[eg]) continue;
+            float* orow = p.out + arow[eg] * p.ldo;
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                const int j0 = 32 * b + 16 * rg + 4 * q;
+                if (vec_ok && j0 + 4 <= p.Nb) {
+                    __builtin_nontemporal_store(acc[rg][eg], reinterpret_cast<f32x4*>(orow + j0));      // (written once, read by a later kernel at best)
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + e < p.Nb) orow[j0 + e] = acc[rg][eg][e];
+                }
+            }
+        }
+    }
+}
+
 // fp32 rows -> three bf16 planes [3][rows_total][D]: rows [0, n0) from A (the pseudo-cohort rows MB), the rest from B (the cohort)
 __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
                                                             bf16_t* __restrict__ planes) {
@@ -742,6 +875,41 @@ hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* i
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, m, s, ids, n, mu, sigma);
     return hipGetLastError();
+}
+
+bool score_h3w_supported(int D, int64_t Na, int64_t Nb) { return (D == 192 || D == 256) && Na > 0 && Nb > 0 && Nb < ((int64_t)1 << 30) && Na < ((int64_t)1 << 31); }
+size_t score_h3w_planes_bytes(int D, int64_t Nb) { return (size_t)2 * Nb * D * 2; }
+
+// out (Na, ldo) = A (Na, D) . B (Nb, D)^T; `planes` = score_h3w_planes_bytes of scratch (filled here with the half parts of B)
+hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t Nb, int D, float* out, int64_t ldo, void* planes, int num_cu,
+                            hipStream_t stream) {
+    if (!score_h3w_supported(D, Na, Nb) || !A || !B || !out || !planes || ldo < Nb) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(planes)) & 15) return hipErrorInvalidValue;
+    const int64_t n = Nb * D;
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, B, 0, B, (int)Nb, D, reinterpret_cast<f16_t*>(planes));
+    ScoreH3Params p;
+    p.A = A; p.Na = Na; p.planes = planes; p.Nb = (int)Nb; p.out = out; p.ldo = ldo;
+    const int panels = (int)((Na + 127) / 128), nb_all = (int)((Nb + 31) / 32);
+    // column slices: enough workgroups for ~4 per CU, at least 8 blocks per slice
+    int slices = (4 * (num_cu > 0 ? num_cu : 256) + panels - 1) / panels;
+    if (slices > (nb_all + 7) / 8) slices = (nb_all + 7) / 8;
+    if (slices < 1) slices = 1;
+    if (slices > 65535) slices = 65535;
+    p.per = (nb_all + slices - 1) / slices;
+    slices = (nb_all + p.per - 1) / p.per;
+    const dim3 grid((unsigned)panels, (unsigned)slices);
+#define SV_SC(DD)                                                                                                           \
+    {                                                                                                                       \
+        static DeviceOnce attr;                                                                                             \
+        constexpr int lds = 2 * 2 * 32 * DD * 2;                                                                            \
+        if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(score_h3w_kernel<DD>), lds)) return e;    \
+        hipLaunchKernelGGL((score_h3w_kernel<DD>), grid, dim3(256), lds, stream, p);                                        \
+        return hipGetLastError();                                                                                           \
+    }
+    if (D == 192) SV_SC(192)
+    SV_SC(256)
+#undef SV_SC
 }
 
 }  // namespace svhip

@@ -374,6 +374,20 @@ struct AsnormFusedParams {
     int nlists = 2;                 // candidate lists per embedding: 2 (cnt (N, 2), lists of ASNORM_CAND_PER_LANE), or 4 with nplanes = 2: the
                                     // 16-wide-MFMA kernel (cnt (N, 4), lists of ASNORM_CAND_PER_LANE / 2)
 };
+// dense score matrix on half planes / 16x16x32 fp16 MFMAs (asnorm_fused.hip): out (Na, ldo) = A (Na, D) . B (Nb, D)^T, D = 192 / 256
+struct ScoreH3Params {
+    const float* A = nullptr;
+    int64_t Na = 0;
+    const void* planes = nullptr;   // [2][Nb][D] half parts of B
+    int Nb = 0;
+    float* out = nullptr;
+    int64_t ldo = 0;
+    int per = 0;                    // blocks of 32 rows of B per workgroup (column slice)
+};
+bool score_h3w_supported(int D, int64_t Na, int64_t Nb);
+size_t score_h3w_planes_bytes(int D, int64_t Nb);
+hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t Nb, int D, float* out, int64_t ldo, void* planes, int num_cu,
+                            hipStream_t stream);
 bool asnorm_fused6_supported(int D, int planes);
 size_t asnorm_planes_bytes(int D, int K);
 hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes = 2);

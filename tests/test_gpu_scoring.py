@@ -118,6 +118,33 @@ def test_score_matrix(eng):
     assert float(np.abs(got - want).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("Na,Nb,D", [(300, 517, 192), (1, 5, 192), (129, 64, 256), (1000, 4096, 192), (260, 33, 256), (70, 130, 64)])
+def test_score_matrix_row_streaming_kernel_against_the_tiled_one(Na, Nb, D):
+    """Round 4: D = 192 / 256 score matrices run on score_h3w (rows of A in registers as half hi | lo parts, B streamed past them as half
+    planes, three fp16 16x16x32 MFMAs per product block, scores stored from the accumulators); option score_tiled keeps the tiled split
+    GEMM.  Both against the float64 product: ragged sizes (single rows, Nb not a multiple of 4 or 32, several column slices), host and
+    device operands; D = 64 takes the tiled kernel either way."""
+    import torch
+    eng = Engine(model="none", max_batch=1)
+    rng = np.random.Generator(np.random.PCG64(Na * 7 + Nb))
+    A = rng.standard_normal((Na, D)).astype(np.float32); A /= np.linalg.norm(A, axis=1, keepdims=True)
+    B = rng.standard_normal((Nb, D)).astype(np.float32); B /= np.linalg.norm(B, axis=1, keepdims=True)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    got = eng.score_matrix(A, B)
+    eng.set_option("score_tiled", 1)
+    tiled = eng.score_matrix(A, B)
+    eng.set_option("score_tiled", 0)
+    assert got.shape == (Na, Nb)
+    print(f"score_matrix {Na} x {Nb} x {D}: row-streaming vs f64 {np.abs(got - want).max():.2e}, tiled vs f64 {np.abs(tiled - want).max():.2e}")
+    assert float(np.abs(got - want).max()) <= 2e-7 and float(np.abs(tiled - want).max()) <= 1e-6
+    Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    out = torch.full((Na, Nb), float("nan"), device="cuda")
+    eng.score_matrix(Ad, Bd, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got)
+    eng.close()
+
+
 def test_large_pair_list_properties():
     """full-size (BASELINE config 4 scale) invariants: symmetry, self-pairs == 1, device pointers."""
     eng = Engine(model="none", max_batch=1)
