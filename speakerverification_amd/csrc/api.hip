@@ -164,6 +164,8 @@ struct svhip_handle {
     void* ATT = nullptr;          // (M, 128)
     float* LOGITS = nullptr;      // (M, 3C) fp32
     float *d_mean = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_gstats = nullptr, *d_ctx = nullptr;
+    float* d_lin_part = nullptr;              // K-slice partials of the small-M linear layers (fc, asp_ctx) at full batches
+    size_t lin_part_per_utt = 0;
     float *d_pool_raw = nullptr, *d_pool_bn = nullptr, *d_emb = nullptr;
     int lastB = 0;
 
@@ -851,6 +853,8 @@ int alloc_workspace(svhip_handle* h) {
         if ((rc = dev_alloc(h, &h->d_s2, B * C))) return rc;
         if ((rc = dev_alloc(h, &h->d_gstats, B * 2 * C3))) return rc;
         if ((rc = dev_alloc(h, &h->d_ctx, B * 128))) return rc;
+        h->lin_part_per_utt = (size_t)((2 * C3 + 383) / 384) * (size_t)std::max(128, c.embed_dim);
+        if ((rc = dev_alloc(h, &h->d_lin_part, B * h->lin_part_per_utt))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_raw, B * 2 * C3))) return rc;
         if ((rc = dev_alloc(h, &h->d_pool_bn, B * 2 * C3))) return rc;
         if (h->x3 && (rc = dev_alloc(h, reinterpret_cast<char**>(&h->s32_buf), M * C3 * 4 + 256))) return rc;
@@ -1121,7 +1125,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         if ((rc = run(h, "asp_gstats", 0, [&]() { return launch_colstats(MFA, bf, C3, B, T, C3, d_gstats, 1e-12f, st); }))) return rc;
     }
     if ((rc = run(h, "asp_ctx", 2.0 * B * 128 * 2 * C3, [&]() {
-             return launch_rowvec_linear(d_gstats, 2 * C3, h->asp_ctx.W, h->asp_ctx.bias, d_ctx, 128, B, 128, 2 * C3, ACT_NONE, st);
+             return launch_rowvec_linear(d_gstats, 2 * C3, h->asp_ctx.W, h->asp_ctx.bias, d_ctx, 128, B, 128, 2 * C3, ACT_NONE, st, h->d_lin_part + (size_t)b0 * h->lin_part_per_utt);
          }))) return rc;
     if ((rc = conv_gemm(h, "gemm_asp_tdnn", h->asp_tdnn, MFA, C3, ATT, 128, M, ACT_RELU, ACT_TANH, nullptr, 0, d_ctx, 128)))
         return rc;
@@ -1153,7 +1157,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
              }))) return rc;
     }
     if ((rc = run(h, "fc", 2.0 * B * h->fc.N * h->fc.K, [&]() {
-             return launch_rowvec_linear(d_pool_bn, 2 * C3, h->fc.W, h->fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 2 * C3, ACT_NONE, st);
+             return launch_rowvec_linear(d_pool_bn, 2 * C3, h->fc.W, h->fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 2 * C3, ACT_NONE, st, h->d_lin_part + (size_t)b0 * h->lin_part_per_utt);
          }))) return rc;
     return SVHIP_OK;
 }

@@ -225,6 +225,64 @@ __global__ __launch_bounds__(1024) void rowvec_linear_small_kernel(const float* 
     }
 }
 
+// Full batches (B > 64, K = 6 144 for ECAPA's fc / asp_ctx): the 8 x 8-output kernel above moves 300 MB from L2 for 11 MB of operands (each
+// workgroup reads 8 rows of both matrices end to end): 36 - 39 us per layer.  Here the product runs on the exact fp32 MFMA
+// (v_mfma_f32_32x32x2: a k-ordered fmaf chain, one rounding per product) with K split over workgroups: a workgroup = a 32 (n) x 32 (b) output
+// tile over a K slice of LIN_KS = 384 — its four waves take 96 k each, a lane's 16-byte load supplies four MFMA steps (the k order inside a
+// dot product is permuted the same way for both operands) — and writes its partial tile to a scratch; a second launch adds the slices in a
+// fixed order, the bias and the activation.  Deterministic; a row's sums do not depend on the batch it rides in.
+constexpr int LIN_KS = 384;
+__global__ __launch_bounds__(256) void rowvec_linear_mfma_part_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ W,
+                                                                      float* __restrict__ part, int B, int N, int K) {
+    __shared__ float red[3][16][64];                   // partial tiles of waves 1 - 3: [wave][register][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, b0 = blockIdx.y * 32, ks = blockIdx.z;
+    const int k0 = ks * LIN_KS + wave * (LIN_KS / 4) + 4 * h;
+    const float* wrow = W + (int64_t)min(n0 + r, N - 1) * K + k0;                 // A operand: row = output channel
+    const float* xrow = in + (int64_t)min(b0 + r, B - 1) * ld_in + k0;            // B operand: column = utterance
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    f32x4 wv[LIN_KS / 32], xv[LIN_KS / 32];
+#pragma unroll
+    for (int j = 0; j < LIN_KS / 32; ++j) {                                       // 12 groups of 8 k: every load of the slice in flight at once
+        wv[j] = *reinterpret_cast<const f32x4*>(wrow + 8 * j);
+        xv[j] = *reinterpret_cast<const f32x4*>(xrow + 8 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < LIN_KS / 32; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][e], xv[j][e], acc, 0, 0, 0);
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // acc[e]: output channel n0 + (e & 3) + 8 (e >> 2) + 4 h, utterance b0 + r
+        const int b = b0 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ((acc[4 * g + u] + red[0][4 * g + u][lane]) + red[1][4 * g + u][lane]) + red[2][4 * g + u][lane];
+            const int n = n0 + 8 * g + 4 * h;
+            if (b < B && n + 4 <= N) *reinterpret_cast<f32x4*>(part + ((int64_t)ks * B + b) * N + n) = v;
+            else if (b < B) for (int u = 0; u < 4; ++u) if (n + u < N) part[((int64_t)ks * B + b) * N + n + u] = v[u];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rowvec_linear_mfma_sum_kernel(const float* __restrict__ part, int nslices, const float* __restrict__ bias,
+                                                                     float* __restrict__ out, int ld_out, int B, int N, int act) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, n = i - b * N;
+    float s = 0.0f;
+    for (int k = 0; k < nslices; ++k) s += part[(int64_t)k * B * N + i];
+    out[(int64_t)b * ld_out + n] = apply_act(s + (bias ? bias[n] : 0.0f), act);
+}
+
 // ---- finalize the column-sum partials written by the pw2 GEMM epilogue --------------------------------------
 // part[((tm*RG + rg)*2 + seg)*C + c]: utterance b owns segment seg = b - (tm*256)/T of tile tm; RG row groups per tile
 // (8 x 32 rows from gemm_pw2's LDS image, 2 x 128 rows from gemm_pw3's accumulators).
@@ -578,10 +636,18 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
     return hipGetLastError();
 }
 
+size_t rowvec_linear_scratch_bytes(int B, int N, int K) { return (K % LIN_KS == 0 && K >= 8 * LIN_KS) ? (size_t)(K / LIN_KS) * B * N * sizeof(float) : 0; }
+
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
-                                int B, int N, int K, int act, hipStream_t stream) {
+                                int B, int N, int K, int act, hipStream_t stream, float* part) {
     if (K <= 0 || N <= 0 || B <= 0 || K % 4 != 0 || ld_in % 4 != 0) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
+    if (part && B > 64 && N % 4 == 0 && rowvec_linear_scratch_bytes(B, N, K) > 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+        const int ns = K / LIN_KS;
+        hipLaunchKernelGGL(rowvec_linear_mfma_part_kernel, dim3((N + 31) / 32, (B + 31) / 32, ns), dim3(256), 0, stream, in, ld_in, W, part, B, N, K);
+        hipLaunchKernelGGL(rowvec_linear_mfma_sum_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, part, ns, bias, out, ld_out, B, N, act);
+        return hipGetLastError();
+    }
     if (B <= 64 && K >= 2048) {
         hipLaunchKernelGGL(rowvec_linear_small_kernel, dim3((N + 7) / 8, (B + 3) / 4), dim3(1024), 0, stream, in, ld_in, W, bias, out, ld_out, B, N, K, act);
         return hipGetLastError();

@@ -220,8 +220,11 @@ hipError_t launch_colmean(const void* X, int dt, int ldx, int B, int T, int C, f
 // mean and population std over T (two pass, clamp 1e-12 as ECAPA_TDNN.py:222-227): -> stats (B, 2C) = [mean | std]
 hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int C, float* stats, float eps, hipStream_t stream);
 // out[b, n] = act( bias[n] + sum_k W[n, k] * in[b, k] ), all fp32 (small-M linear layers)
+// `part` (optional, rowvec_linear_scratch_bytes(B, N, K) > 0 bytes): full batches (B > 64) of long rows (K a multiple of 384, >= 3 072) run on the
+// exact fp32 MFMA with K split over workgroups and the slices added in a fixed order
+size_t rowvec_linear_scratch_bytes(int B, int N, int K);
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
-                                int B, int N, int K, int act, hipStream_t stream);
+                                int B, int N, int K, int act, hipStream_t stream, float* part = nullptr);
 // s[b, :] = sigmoid(W2 relu(W1 mean[b, :] + b1) + b2); W1 [H][C], W2T = W2 transposed [H][C]
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
                          const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream, int row_groups = 8);
