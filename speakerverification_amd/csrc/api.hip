@@ -80,6 +80,7 @@ struct svhip_handle {
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
+        int rn_sinc_f32 = 0;      // F32X3 handles: the sinc front-end on the exact fp32 MFMA (tests) instead of three fp16 MFMAs per product
         int rn_tail_big = 0;      // RawNet2 block tail: one workgroup per utterance at every batch size (tests)
         int r2_slices = -1;       // bf16 Res2Net chain: time slices per utterance (-1: by batch size, 0 / 1: whole utterances, n: forced)
     } opt;
@@ -121,6 +122,7 @@ struct svhip_handle {
     RnBlock rn_blocks[8];
     float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
     void* rn_filt = nullptr;
+    void* rn_filt_x3 = nullptr;               // F32X3 handles: [2][128][256] half hi | lo parts of the sinc filters
     float *rn_agg_scale = nullptr, *rn_agg_shift = nullptr;
     ConvLayer rn_att0, rn_att3;
     LinearLayer rn_fc;
@@ -729,6 +731,18 @@ int bake_sinc(svhip_handle* h) {
         float* d;
         if ((rc = dev_upload(h, &d, pk))) return rc;
         h->rn_filt = d;
+        if (h->x3) {        // the split front-end (rn_sinc_x3): hi and lo half planes, k contiguous, zero beyond the 251 taps
+            std::vector<uint16_t> pl((size_t)2 * NF * 256, 0);
+            for (int f = 0; f < NF; ++f)
+                for (int k = 0; k < KS; ++k) {
+                    const uint32_t w = x3_split_word(filt[(size_t)f * KS + k]);
+                    pl[(size_t)f * 256 + k] = (uint16_t)(w >> 16);
+                    pl[(size_t)(NF + f) * 256 + k] = (uint16_t)(w & 0xffffu);
+                }
+            uint16_t* dx;
+            if ((rc = dev_upload(h, &dx, pl))) return rc;
+            h->rn_filt_x3 = dx;
+        }
     }
     return SVHIP_OK;
 }
@@ -816,10 +830,10 @@ int alloc_workspace(svhip_handle* h) {
             SV_HIP(h, hipMemset(q + h->rn_buf_bytes, 0, 256));          // the zero tail (no kernel writes past the payload)
         }
         if ((rc = dev_alloc(h, &h->rn_stats, B * 2))) return rc;
-        if (h->bf16) {                                           // LayerNorm output as bf16, zero-tailed rows (operand of the bf16 sinc kernel)
+        if (h->bf16 || h->x3) {                                  // LayerNorm output in 16 bits, zero-tailed rows (operand of the 16-bit / split sinc kernels)
             h->rn_Lp = (int)round_up(c.samples + RN_XN_TAIL, 64);
             uint16_t* q;
-            if ((rc = dev_alloc(h, &q, 2 * B * (size_t)h->rn_Lp))) return rc;
+            if ((rc = dev_alloc(h, &q, (h->x3 ? 4 : 2) * B * (size_t)h->rn_Lp))) return rc;      // (F32X3: hi and lo parts of both copies)
             h->rn_xn = q;
         }
         if ((rc = dev_alloc(h, &h->rn_part, B * (size_t)(rn_block128_ntiles(h->rn_T1) + 1) * 4 * 128))) return rc;
@@ -1231,9 +1245,10 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     float* rn_pooled = h->rn_pooled + (size_t)b0 * 1024;
     float* d_emb = h->d_emb + (size_t)b0 * c.embed_dim;
     int rc;
-    void* rn_xn = bf ? static_cast<char*>(h->rn_xn) + (size_t)b0 * 2 * h->rn_Lp * 2 : nullptr;
+    const bool sinc_x3 = h->x3 && h->rn_filt_x3 && !h->opt.rn_sinc_f32;            // F32X3: the front-end on three fp16 MFMAs per product
+    void* rn_xn = bf ? static_cast<char*>(h->rn_xn) + (size_t)b0 * 2 * h->rn_Lp * 2 : sinc_x3 ? static_cast<char*>(h->rn_xn) + (size_t)b0 * 4 * h->rn_Lp * 2 : nullptr;
     const int dt = h->dt;
-    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st, rn_xn, h->rn_Lp, h->rn_gamma, h->rn_beta, dt); }))) return rc;
+    if ((rc = run(h, "rn_ln_stats", 0, [&]() { return launch_rn_ln_stats(d_wav, B, L, rn_stats, st, rn_xn, h->rn_Lp, h->rn_gamma, h->rn_beta, dt, sinc_x3); }))) return rc;
     int T = h->rn_T1;
     void *x = off(h->rn_buf[0], b0 * per_utt, e), *pre = off(h->rn_buf[1], b0 * per_utt, e), *hb = off(h->rn_buf[2], b0 * per_utt, e),
          *o = off(h->rn_buf[3], b0 * per_utt, e), *sc = off(h->rn_buf[4], b0 * per_utt, e), *xn = off(h->rn_buf[5], b0 * per_utt, e);
@@ -1258,6 +1273,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
+             if (sinc_x3) return launch_rn_sinc_x3(h->rn_filt_x3, h->rn_fbn_scale, h->rn_fbn_shift, reinterpret_cast<float*>(x), B, L, T, rn_xn, h->rn_Lp, h->num_cu, st);
              return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, dt, B, L, T, st,
                                    nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu);
          }))) return rc;
@@ -1494,7 +1510,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2276,7 +2292,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
         {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
-        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"n128_off", &o.n128_off}};
+        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

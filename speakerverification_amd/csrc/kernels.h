@@ -290,8 +290,12 @@ hipError_t launch_asp_x3(const AspX3Params& p, int B, hipStream_t stream);
 //  == 0): sample j at index j, then sample j + 1 at index j — the operand of the bf16 sinc kernel, which reads up to 470 samples
 //  past its last tile's first sample)
 constexpr int RN_XN_TAIL = 512;
+// (xn_lo: the split form of F32X3 handles — FOUR rows of Lp halves per utterance: hi parts of the two copies, then their lo parts)
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn = nullptr, int Lp = 0,
-                              const float* gamma = nullptr, const float* beta = nullptr, int xn_dt = DT_BF16);
+                              const float* gamma = nullptr, const float* beta = nullptr, int xn_dt = DT_BF16, bool xn_lo = false);
+// the sinc front-end on three fp16 MFMAs per product (F32X3 handles): filt_planes = [2][128][256] halves (hi | lo), fp32 out
+hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, const float* bn_shift, float* out, int B, int L, int T1,
+                             const void* xn, int Lp, int num_cu, hipStream_t stream);
 // LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,

@@ -26,7 +26,8 @@ namespace {
 
 // With `xn` the kernel also writes the LayerNorm output gamma * (x - mean) * inv + beta (RawNet_baseline.py:24) as bf16 into a
 // zero-tailed row of Lp samples: the bf16 sinc kernel stages its operand from it with LDS-DMA (no arithmetic in its tile loop).
-template <typename H>
+// LO (the split front-end of F32X3 handles): four rows per utterance — hi parts of the two copies, then their lo parts (lo = H(v - hi))
+template <typename H, bool LO = false>
 __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restrict__ x, int L, float* __restrict__ stats,
                                                           H* __restrict__ xn, int Lp, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
     if (xn) {
         // copy 0: sample j at index j; copy 1: sample j + 1 at index j — so that every 2-sample LDS-DMA of the sinc kernel, for an
         // even or an odd shift, starts on a 4-byte boundary
-        H* __restrict__ o0 = xn + (int64_t)b * 2 * Lp;
+        H* __restrict__ o0 = xn + (int64_t)b * (LO ? 4 : 2) * Lp;
         H* __restrict__ o1 = o0 + Lp;
         const bool vec = (L % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
         for (int j0 = threadIdx.x * 8; j0 < Lp; j0 += 256 * 8) {
@@ -93,6 +94,13 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
             for (int e = 0; e < 8; ++e) { a.set(e, v[e]); c.set(e, v[e + 1]); }
             *reinterpret_cast<Vec16<H>*>(o0 + j0) = a;
             *reinterpret_cast<Vec16<H>*>(o1 + j0) = c;
+            if (LO) {
+                Vec16<H> al, cl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { al.set(e, v[e] - a.get(e)); cl.set(e, v[e + 1] - c.get(e)); }
+                *reinterpret_cast<Vec16<H>*>(o0 + 2 * Lp + j0) = al;
+                *reinterpret_cast<Vec16<H>*>(o1 + 2 * Lp + j0) = cl;
+            }
         }
     }
 }
@@ -365,6 +373,146 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         tp_prev = tp0; b_prev = b;
     }
     if (BF && tp_prev >= 0) {
+        __syncthreads();
+        flush(b_prev, tp_prev, smem + CF::OUT_OFF + ((item1 - 1 - item0) & 1) * CF::OUT_BYTES);
+    }
+}
+
+// ---- the sinc front-end of F32X3 handles: fp32 in / out, products as three fp16 MFMAs on half hi | lo parts (round 4) ----------------------
+// Same structure as the 16-bit path of rn_sinc_kernel (LayerNorm output staged by 4-byte LDS-DMA into eight sample-shifted copies, filter
+// fragments in registers, v_mfma_f32_16x16x32_f16, pooled tile through an LDS image), with a second plane for everything: the lo parts of the
+// waveform (rn_ln_stats<LO>) and of the filters.  A wave owns 32 filters (hi and lo fragments: 128 VGPRs), all four waves the same 32 pooled
+// frames of a tile; per (k step, pool partner) two fragment reads feed six MFMAs (lo.hi + hi.lo + hi.hi for two filter blocks).  fp32 output.
+// The exact-fp32-MFMA instance of rn_sinc_kernel it replaces on these handles ran at the fp32 matrix peak: 3.7 ms per 256 utterances.
+constexpr int SX_PT = 32;                   // pooled frames per tile
+constexpr int SX_SAMPLES = 360;             // >= 3 * SX_PT conv positions + 255 + 8, multiple of 8
+struct SincX3Cfg {
+    static constexpr int COPY_BYTES = 1024;                    // 720 bytes of samples + up to 240 of skew
+    static constexpr unsigned COPY_SKEW = 0x7E49C210u;         // (the fragment pattern of the 16-bit kernel: SincCfg16)
+    static constexpr int PLANE = 8 * COPY_BYTES;
+    static constexpr int XLDS = 2 * PLANE;                     // hi | lo planes of one operand buffer
+    static constexpr int OUT_OFF = 2 * XLDS;                   // two operand buffers, then two output images
+    static constexpr int OUT_BYTES = SX_PT * 512;              // 32 pooled frames x 128 filters fp32
+    static constexpr int BN_OFF = OUT_OFF + 2 * OUT_BYTES;
+    static constexpr int LDS = BN_OFF + 1024;                  // 65 KiB: two workgroups per CU
+};
+
+// filt: [2][128][256] half (hi plane, lo plane; k contiguous, zero beyond 251); xn: per utterance four rows of Lp halves (rn_ln_stats<LO>)
+__global__ __launch_bounds__(256, 2) void rn_sinc_x3_kernel(const f16_t* __restrict__ filt, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                            float* __restrict__ out, int T1, int B, const uint16_t* __restrict__ xn, int Lp) {
+    typedef SincX3Cfg CF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_u = (T1 + SX_PT - 1) / SX_PT;
+    const int items = B * tiles_u;
+    const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item0 = (int)blockIdx.x * per, item1 = item0 + per < items ? item0 + per : items;
+    if (item0 >= items) return;                                  // workgroup-uniform
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = filter quarter: filters 32 wave .. + 31
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    bf16x8 whi[2][8], wlo[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(wave * 32 + blk * 16 + r16) * 256 * 2 + q4 * 16;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            whi[blk][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 64);
+            wlo[blk][kk] = *reinterpret_cast<const bf16x8*>(w + 128 * 256 * 2 + kk * 64);
+        }
+    }
+    auto flush = [&](int b, int tpf, const char* img) {              // 32 rows x 32 chunks of 16 bytes, 4 per thread
+        int tid_f = tid;
+        asm volatile("" : "+v"(tid_f));
+#pragma unroll
+        for (int e = 0; e < SX_PT * 32 / 256; ++e) {
+            const int idx = e * 256 + tid_f;
+            const int row = idx >> 5, c16 = idx & 31;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(img + row * 512 + ((c16 ^ (row & 31)) << 4));
+            if (tpf + row < T1) *reinterpret_cast<f32x4*>(out + ((int64_t)b * T1 + tpf + row) * 128 + c16 * 4) = t;
+        }
+    };
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef __attribute__((address_space(1))) const void gbl_void_t;
+    auto dma = [&](int item, int buf) {                          // plane pl, copy pc, index i <- part pl of sample 3 * tpn + i + pc of utterance b
+        const int b = item / tiles_u, tpn = (item - b * tiles_u) * SX_PT;
+        const uint16_t* src0 = xn + (int64_t)b * 4 * Lp + 3 * tpn + 2 * lane;
+        char* dst = smem + buf * CF::XLDS;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {                               // 2 planes x 8 copies x 3 segments of 128 samples = 48 wave-instructions, 12 per wave
+            const int idx = wave + 4 * e, pl = idx / 24, rem = idx - pl * 24, pc = rem / 3, q = rem - pc * 3;
+            const uint16_t* src = src0 + pl * 2 * Lp + (pc & 1) * Lp + (pc & ~1) + q * 128;
+            if (q * 128 + 2 * lane < SX_SAMPLES)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + pl * CF::PLANE + pc * CF::COPY_BYTES + ((CF::COPY_SKEW >> (4 * pc)) & 15) * 16 + q * 256), 4, 0, 0);
+        }
+    };
+    float* const bnl = reinterpret_cast<float*>(smem + CF::BN_OFF);
+    bnl[tid] = tid < 128 ? bn_scale[tid] : bn_shift[tid - 128];
+    dma(item0, 0);
+    int tp_prev = -1, b_prev = 0;
+    for (int item = item0; item < item1; ++item) {
+        const int it = item - item0;
+        const int b = item / tiles_u;
+        const int tp0 = (item - b * tiles_u) * SX_PT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* const xbuf = smem + (it & 1) * CF::XLDS;
+        char* const otile = smem + CF::OUT_OFF + (it & 1) * CF::OUT_BYTES;
+        if (item + 1 < item1) dma(item + 1, (it + 1) & 1);
+        if (tp_prev >= 0) flush(b_prev, tp_prev, smem + CF::OUT_OFF + ((it - 1) & 1) * CF::OUT_BYTES);
+        const char* base[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int s = 3 * r16 + j;                                   // conv position inside the tile (frame group 0; group 1: + 48)
+            base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + q4) * 16;
+        }
+        int r16_e = r16, q4_e = q4;
+        asm volatile("" : "+v"(r16_e), "+v"(q4_e));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[blk][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // 24 (k step, pool partner) pairs; the hi and lo fragments of a pair are read two pairs ahead of their six MFMAs, fenced
+            auto xread = [&](int idx, int pl) { return *reinterpret_cast<const bf16x8*>(base[idx % 3] + pl * CF::PLANE + g * 96 + (idx / 3) * 64); };
+            bf16x8 rh[3], rl[3];
+            rh[0] = xread(0, 0); rl[0] = xread(0, 1);
+            rh[1] = xread(1, 0); rl[1] = xread(1, 1);
+#pragma unroll
+            for (int idx = 0; idx < 24; ++idx) {
+                if (idx + 2 < 24) { rh[(idx + 2) % 3] = xread(idx + 2, 0); rl[(idx + 2) % 3] = xread(idx + 2, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                const int kk = idx / 3, j = idx % 3;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) acc[blk][j] = Half16<f16_t>::mfma16(wlo[blk][kk], rh[idx % 3], acc[blk][j]);      // small terms first
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) acc[blk][j] = Half16<f16_t>::mfma16(whi[blk][kk], rl[idx % 3], acc[blk][j]);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) acc[blk][j] = Half16<f16_t>::mfma16(whi[blk][kk], rh[idx % 3], acc[blk][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3): lane = pooled frame 16 g + r16, filters 32 wave + 16 blk + 4 q4 .. + 3
+            const int row = 16 * g + r16_e;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int f = wave * 32 + blk * 16 + 4 * q4_e;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnl + f);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(bnl + 128 + f);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float m = fmaxf(fmaxf(fabsf(acc[blk][0][e]), fabsf(acc[blk][1][e])), fabsf(acc[blk][2][e]));
+                    const float y = fmaf(m, sc[e], sh[e]);
+                    v[e] = y > 0.0f ? y : 0.3f * y;
+                }
+                *reinterpret_cast<f32x4*>(otile + row * 512 + (((f >> 2) ^ (row & 31)) << 4)) = v;
+            }
+        }
+        tp_prev = tp0; b_prev = b;
+    }
+    if (tp_prev >= 0) {
         __syncthreads();
         flush(b_prev, tp_prev, smem + CF::OUT_OFF + ((item1 - 1 - item0) & 1) * CF::OUT_BYTES);
     }
@@ -692,9 +840,10 @@ inline int grid_for(int64_t items) {
 }  // namespace
 
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn, int Lp, const float* gamma,
-                              const float* beta, int xn_dt) {
+                              const float* beta, int xn_dt, bool xn_lo) {
     if (xn && (Lp < L + RN_XN_TAIL || Lp % 64 != 0 || !gamma || !beta)) return hipErrorInvalidValue;
-    if (xn_dt == DT_F16) hipLaunchKernelGGL(rn_ln_stats_kernel<f16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
+    if (xn_lo) hipLaunchKernelGGL((rn_ln_stats_kernel<f16_t, true>), dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
+    else if (xn_dt == DT_F16) hipLaunchKernelGGL(rn_ln_stats_kernel<f16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
     else hipLaunchKernelGGL(rn_ln_stats_kernel<bf16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<bf16_t*>(xn), Lp, gamma, beta);
     return hipGetLastError();
 }
@@ -722,6 +871,22 @@ hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gam
         hipLaunchKernelGGL(rn_sinc_kernel<float>, grid, block, SincCfg<float>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
                            bn_shift, reinterpret_cast<float*>(out), reinterpret_cast<float*>(pre), next_scale, next_shift, L, T1, B,
                            static_cast<const uint16_t*>(nullptr), 0);
+    return hipGetLastError();
+}
+
+// F32X3 handles: out (B, T1, 128) fp32 from the split LayerNorm output (rn_ln_stats with xn_lo: four rows of Lp halves per utterance)
+hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, const float* bn_shift, float* out, int B, int L, int T1,
+                             const void* xn, int Lp, int num_cu, hipStream_t stream) {
+    if (B <= 0 || !filt_planes || !bn_scale || !bn_shift || !out || !xn) return hipErrorInvalidValue;
+    if (T1 != (L - 250) / 3 || L < 251 + 3 || Lp < L + RN_XN_TAIL || Lp % 64 != 0) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(filt_planes) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(xn)) & 15) return hipErrorInvalidValue;
+    const int64_t items = (int64_t)B * ((T1 + SX_PT - 1) / SX_PT);
+    if (items >= (1ll << 31)) return hipErrorInvalidValue;
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(rn_sinc_x3_kernel), SincX3Cfg::LDS)) return e;
+    const int slots = 2 * (num_cu > 0 ? num_cu : 256);
+    hipLaunchKernelGGL(rn_sinc_x3_kernel, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SincX3Cfg::LDS, stream,
+                       reinterpret_cast<const f16_t*>(filt_planes), bn_scale, bn_shift, out, T1, B, reinterpret_cast<const uint16_t*>(xn), Lp);
     return hipGetLastError();
 }
 

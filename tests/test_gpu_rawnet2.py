@@ -160,6 +160,37 @@ def test_fused_tail_fp32_matches_separate_passes(L, B, monkeypatch):
     assert float(np.abs(outs[0] - outs[1]).max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("L,B", [(32000, 3), (16001, 2), (20003, 5), (4000, 1)])
+def test_f32x3_sinc_front_end_on_split_halves_matches_the_exact_fp32_mfma(L, B):
+    """Round 4: on F32X3 handles the sinc front-end runs as three fp16 MFMAs per product on half hi | lo parts of the LayerNorm output and
+    of the filters (csrc/rawnet2.hip: rn_sinc_x3_kernel; 22 + 22 significant bits); option rn_sinc_f32 keeps the exact-fp32-MFMA instance.
+    Front-end outputs (option rn_stop = 0) and embeddings against each other, sample counts that are not a multiple of 8 or of a tile."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=9)
+    wav = synth.synth_waveforms(B, L, seed=17)
+    eng = Engine(model="rawnet2", compute="f32x3", embed_dim=320, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    res = {}
+    for exact in (1, 0):
+        eng.set_option("rn_sinc_f32", exact)
+        eng.set_option("rn_stop", 0)
+        eng.embed_wave(wav)
+        front = eng.get_stage("rn_x").copy()
+        eng.set_option("rn_stop", -1)
+        eng.profile(True)
+        emb = eng.embed_wave(wav).reshape(B, -1).copy()
+        labels = set(eng.profile_results())
+        eng.profile(False)
+        res[exact] = (front, emb)
+    eng.close()
+    f1, f0 = res[1][0], res[0][0]
+    assert f1.shape == f0.shape and np.isfinite(f0).all() and np.abs(f1).max() > 0
+    dfront = float(np.abs(f1 - f0).max() / np.abs(f1).max())
+    demb = float(np.abs(res[1][1] - res[0][1]).max() / np.abs(res[1][1]).max())
+    print(f"L={L} B={B}: split-half sinc vs exact fp32 MFMA: front-end {dfront:.2e} of its scale, embeddings {demb:.2e} of theirs")
+    assert dfront <= 2e-6 and demb <= 1e-4          # (embeddings: the mode's own bar — the blocks behind the front-end are split products too)
+
+
 @pytest.mark.parametrize("compute,L,B", [("f32", 32000, 5), ("f16", 32000, 20), ("bf16", 20000, 3), ("f16", 32000, 64)])
 def test_small_batch_tail_in_slices_matches_the_one_workgroup_tail(compute, L, B):
     """Round 4: at B * 4 <= CUs the block tail (max-pool + AFMS + next pre-activation) runs as slice sums -> rn_afms_gate -> apply over
