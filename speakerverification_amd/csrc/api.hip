@@ -80,6 +80,7 @@ struct svhip_handle {
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
+        int rn_step_off = 0;      // F32X3 handles: the 128 -> 128 blocks' convolutions on the tiled in-register-split kernel (tests)
         int rn_sinc_f32 = 0;      // F32X3 handles: the sinc front-end on the exact fp32 MFMA (tests) instead of three fp16 MFMAs per product
         int rn_tail_big = 0;      // RawNet2 block tail: one workgroup per utterance at every batch size (tests)
         int r2_slices = -1;       // bf16 Res2Net chain: time slices per utterance (-1: by batch size, 0 / 1: whole utterances, n: forced)
@@ -1270,10 +1271,22 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         h->rn_snap_T = Tn; h->rn_snap_C = Cn;
         return SVHIP_OK;
     };
+    // F32X3: will block `bn` (entered with Tn frames) run its convolutions on the 128 x 128 split kernel (r2_step.hip modes 1 / 2)?  Its
+    // producer then writes lrelu(bn1(x)) straight in the S32 layout (pre_is_s32) instead of fp32
+    auto x3_step_block = [&](int bn, int Tn) {
+        if (bn > 7 || !h->x3 || h->opt.rn_step_off || stop_after >= 0 || snap_at >= 0) return false;
+        const svhip_handle::RnBlock& Kn = h->rn_blocks[bn];
+        return Kn.cin == 128 && Kn.cout == 128 && !Kn.has_shortcut && Kn.conv1.Ws32 && Kn.conv2.Ws32 && Tn >= 2;
+    };
+    bool pre_is_s32 = false;
+    // (the split front-end writes block 0's pre-activation itself, in the S32 layout, when block 0 runs on the split convolution kernel)
+    const bool sinc_pre = sinc_x3 && x3_step_block(0, T);
+    if (sinc_pre) pre_is_s32 = true;
     if ((rc = run(h, "rn_sinc", 2.0 * B * 128.0 * 251.0 * (L - 250), [&]() {
              // (the kernel can also write block 0's pre-activation, but its 8-byte scattered stores make that as dear as the
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
-             if (sinc_x3) return launch_rn_sinc_x3(h->rn_filt_x3, h->rn_fbn_scale, h->rn_fbn_shift, reinterpret_cast<float*>(x), B, L, T, rn_xn, h->rn_Lp, h->num_cu, st);
+             if (sinc_x3) return launch_rn_sinc_x3(h->rn_filt_x3, h->rn_fbn_scale, h->rn_fbn_shift, reinterpret_cast<float*>(x), B, L, T, rn_xn, h->rn_Lp, h->num_cu, st,
+                                                   sinc_pre ? pre : nullptr, h->rn_blocks[0].bn1_scale, h->rn_blocks[0].bn1_shift);
              return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, dt, B, L, T, st,
                                    nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu);
          }))) return rc;
@@ -1325,8 +1338,9 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         const int M = B * T;
         // out = lrelu(bn1(x))                                                         RawNet_baseline.py:222
         // (blocks 1..7 get it from the previous block's AFMS pass, which writes x and lrelu(bn1(x)) together)
-        if ((bi == 0 && first == 0) || stop_after >= 0) {
-            if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, dt, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st); }))) return rc;
+        if (((bi == 0 && first == 0) || stop_after >= 0) && !(bi == 0 && sinc_pre)) {
+            pre_is_s32 = x3_step_block(bi, T);
+            if ((rc = run(h, "rn_bn_act", 0, [&]() { return launch_rn_bn_act(x, pre, dt, K.bn1_scale, K.bn1_shift, M, K.cin, 0.3f, st, pre_is_s32); }))) return rc;
         }
         // conv1 -> bn2 -> lrelu (epilogue), conv2 + shortcut                            :224-226
         // A 1 x 1 shortcut rides in conv2's GEMM as extra K columns when the 256 x 256 kernel takes it (no shortcut tensor in HBM)
@@ -1337,6 +1351,27 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         if (K.has_shortcut && !fold_sc) {
             if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
             resid = sc;
+        }
+        // F32X3, the 128 -> 128 blocks (layer1, layer2: 40 % of the model's FLOPs on its longest time axes): both convolutions on the 128 x 128
+        // split kernel (r2_step.hip, modes 1 / 2) — pre in the S32 layout, conv1's output stays S32 (conv2's operand), conv2 adds the identity
+        // shortcut on the way out.  (Otherwise they run on the tiled kernel that splits its fp32 operands in registers: 186 TFLOP/s.)
+        const bool x3_step = h->x3 && !h->opt.rn_step_off && K.cin == 128 && K.cout == 128 && !K.has_shortcut && K.conv1.Ws32 && K.conv2.Ws32 && T >= 2;
+        if (pre_is_s32 && !x3_step) SV_FAIL(h, SVHIP_ERR_STATE, "RawNet2 block %d: split pre-activation without the split convolution route", bi);
+        if (x3_step) {
+            GemmParams q1;
+            q1.A = pre_is_s32 ? pre : sc; q1.lda = 128; q1.W = K.conv1.Ws32; q1.Wrows = 128; q1.x3 = 2;
+            q1.scale = K.conv1.scale; q1.shift = K.conv1.shift;
+            q1.M = M; q1.N = 128; q1.K = 384; q1.Kp = 384; q1.T = T; q1.taps = 3; q1.dil = 1; q1.cin = 128; q1.pad_mode = PAD_ZERO;
+            q1.zero_page = h->d_zeros; q1.Y = hb; q1.ldy = 128; q1.num_cu = h->num_cu;
+            GemmParams q2 = q1;
+            q2.A = hb; q2.W = K.conv2.Ws32; q2.scale = nullptr; q2.shift = nullptr; q2.Y = o; q2.out_f32 = 1; q2.R = reinterpret_cast<const float*>(x); q2.ldr = 128;
+            if (rn_step_supported(q1, 1) && rn_step_supported(q2, 2)) {
+                if (!pre_is_s32 && (rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(pre), 128, sc, M, 128, st); }))) return rc;
+                if ((rc = run(h, "rn_step", (double)M * K.conv1.flops_per_row, [&]() { return launch_rn_step(q1, 1, st); }))) return rc;
+                if ((rc = run(h, "rn_step", (double)M * K.conv2.flops_per_row, [&]() { return launch_rn_step(q2, 2, st); }))) return rc;
+                goto convs_done;
+            }
+            if (pre_is_s32) SV_FAIL(h, SVHIP_ERR_STATE, "RawNet2 block %d: the split convolution kernel refused a shape its producer was told it takes", bi);
         }
         if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
         if (fold_sc) {
@@ -1351,6 +1386,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
             if (!K.has_shortcut && tail_fused && bf && conv_cv_persistent(h, K.conv2, hb, K.cout, M, T, PAD_ZERO)) { resid_in_tail = x; resid = nullptr; }
             if ((rc = conv_gemm(h, "rn_gemm", K.conv2, hb, K.cout, o, K.cout, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, false, T, PAD_ZERO, resid, resid ? K.cout : 0))) return rc;
         }
+    convs_done:
         // AFMS gate; the same pass writes the next consumer's lrelu(bn(.)): block bi+1's bn1, or the aggregation BN after block 7
         const float* nsc = bi < 7 ? h->rn_blocks[bi + 1].bn1_scale : h->rn_agg_scale;
         const float* nsh = bi < 7 ? h->rn_blocks[bi + 1].bn1_shift : h->rn_agg_shift;
@@ -1368,6 +1404,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
                      return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st,
                                            resid_in_tail, sliced ? rn_scratch : nullptr, sliced ? rn_gate[0] : nullptr, h->num_cu);
                  }))) return rc;
+            pre_is_s32 = false;                                 // (the fused tails write fp32; a split consumer converts it: split_s32)
             T = Tn;
         } else {
             void* y = o;
@@ -1381,7 +1418,10 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
             if ((rc = run(h, "rn_afms_gate", 2.0 * B * K.cout * K.cout, [&]() {
                      return launch_rn_afms_gate(rn_mean, 1, B, K.cout, 1, K.afms_fcT, K.afms_fc.bias, rn_gate[0], st);
                  }))) return rc;
-            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, x_dead ? nullptr : xn, dt, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f); }))) return rc;
+            // (F32X3: when the next block runs on the split convolution kernel its pre-activation is written in the S32 layout right here)
+            const bool next_s32 = npre && x3_step_block(bi + 1, T);
+            if ((rc = run(h, "rn_afms_apply", 0, [&]() { return launch_rn_afms_apply(y, x_dead ? nullptr : xn, dt, K.alpha, rn_gate[0], B, T, K.cout, st, nsc, nsh, npre, 0.3f, next_s32); }))) return rc;
+            pre_is_s32 = next_s32;
         }
         std::swap(x, xn);
         h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = K.cout;
@@ -1510,7 +1550,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2292,7 +2332,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
         {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
-        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"n128_off", &o.n128_off}};
+        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

@@ -142,6 +142,10 @@ bool gemm_pw3x3_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3x3(const GemmParams& p, hipStream_t stream);
 bool r2_step_supported(const GemmParams& p);               // r2_step.hip: the Res2Net step on 128 x 128 tiles, two workgroups per CU (cin = 128)
 hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream);
+// RawNet2's 128 -> 128, k = 3 convolutions on F32X3 handles (r2_step.hip, modes 1 / 2): S32 operands, zero padding (GemmParams::zero_page),
+// mode 1: S32 output of lrelu0.3(BN(.)); mode 2: fp32 output of conv (+ R)
+bool rn_step_supported(const GemmParams& p, int mode);
+hipError_t launch_rn_step(const GemmParams& p, int mode, hipStream_t stream);
 bool gemm_pw3cv_supported(const GemmParams& p);          // conv-gather X3 form (odd taps, reflect): see gemm_pw3.hip
 hipError_t launch_gemm_pw3cv(const GemmParams& p, hipStream_t stream);
 bool gemm_n128_supported(const GemmParams& p);           // gemm_n128.hip
@@ -294,20 +298,23 @@ constexpr int RN_XN_TAIL = 512;
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn = nullptr, int Lp = 0,
                               const float* gamma = nullptr, const float* beta = nullptr, int xn_dt = DT_BF16, bool xn_lo = false);
 // the sinc front-end on three fp16 MFMAs per product (F32X3 handles): filt_planes = [2][128][256] halves (hi | lo), fp32 out
+// (pre_s32: optional second output lrelu0.3(next_scale * out + next_shift) in the S32 split layout, (B * T1, 128))
 hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, const float* bn_shift, float* out, int B, int L, int T1,
-                             const void* xn, int Lp, int num_cu, hipStream_t stream);
+                             const void* xn, int Lp, int num_cu, hipStream_t stream, void* pre_s32 = nullptr, const float* next_scale = nullptr,
+                             const float* next_shift = nullptr);
 // LayerNorm + sinc conv (k=251) + abs + maxpool3 + BN + LeakyReLU(0.3): wav (B, L) -> out (B, T1, 128), T1 = (L-250)/3
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,
                           hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr,
                           const void* xn = nullptr, int Lp = 0, int num_cu = 256);
 // (dt: DT_F32 / DT_BF16 / DT_F16 — the storage type of the activations)
+// (y_s32 / pre_s32, fp32 only: that output in the S32 split layout — the operand of the split convolution kernels — instead of fp32)
 hipError_t launch_rn_bn_act(const void* x, void* y, int dt, const float* scale, const float* shift, int64_t rows, int C,
-                            float slope, hipStream_t stream);
+                            float slope, hipStream_t stream, bool y_s32 = false);
 hipError_t launch_rn_maxpool3(const void* x, void* y, int dt, int B, int Tin, int C, hipStream_t stream);
 hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alpha, const float* s, int B, int T, int C,
                                 hipStream_t stream, const float* next_scale = nullptr, const float* next_shift = nullptr,
-                                void* pre = nullptr, float slope = 0.3f);
+                                void* pre = nullptr, float slope = 0.3f, bool pre_s32 = false);
 // fused block tail (rawnet2.hip): [max_pool1d(3)] + AFMS + the next consumer's lrelu(bn(.)), one workgroup per utterance with the
 // pooled activation held in registers; rn_tail_supported says whether (Tn, C) fits (else the four separate passes run)
 bool rn_tail_supported(int dt, int Tn, int C);

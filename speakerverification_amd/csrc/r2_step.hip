@@ -25,6 +25,10 @@ constexpr int RS_TILE = 128;                       // frames per tile = channels
 constexpr int RS_HT = RS_TILE * 128;               // one operand half-buffer: 128 rows x one 32-k block (128 bytes)
 constexpr int RS_LDS = 4 * RS_HT;                  // {X, W} x two K tiles = 64 KiB = one 128-row image of 512-byte rows
 
+// MODE 0: the Res2Net step above.  MODE 1 / 2 (round 4, late): RawNet2's 128 -> 128 convolutions on F32X3 handles (models/RawNet_baseline.py
+// :224-227) — zero padding (rows outside the utterance read a zero page), no bias; 1 = conv1: BN -> LeakyReLU(0.3), output in the S32 layout
+// (conv2's operand); 2 = conv2: no activation, fp32 output = acc + R (the identity shortcut x, fp32) through the same 64 KiB row image.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -55,8 +59,14 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         const int shift = (tap - 1) * p.dil;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int tt = reflect_idx(xt[q] + shift, p.T);
-            const char* s = Ab + ((int64_t)(xm[q] + tt - xt[q]) * p.lda * 4 + kin * 128 + xc[q]);
+            const char* s;
+            if (MODE == 0) {
+                const int tt = reflect_idx(xt[q] + shift, p.T);
+                s = Ab + ((int64_t)(xm[q] + tt - xt[q]) * p.lda * 4 + kin * 128 + xc[q]);
+            } else {
+                const bool in = (unsigned)(xt[q] + shift) < (unsigned)p.T;
+                s = in ? Ab + ((int64_t)(xm[q] + shift) * p.lda * 4 + kin * 128 + xc[q]) : reinterpret_cast<const char*>(p.zero_page) + xc[q];
+            }
             __builtin_amdgcn_global_load_lds((gbl_void*)s, (lds_void*)(smem + (buf * 2) * RS_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
@@ -75,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
     f32x4 acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + j * 16 + 4 * q4);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0 || p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + j * 16 + 4 * q4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = b4;
     }
@@ -133,6 +144,49 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         *reinterpret_cast<uint2*>(blk + ((kh ^ (ml & 7)) << 4)) = make_uint2(hd[0], hd[1]);
         *reinterpret_cast<uint2*>(blk + (((kh + 4) ^ (ml & 7)) << 4)) = make_uint2(ld[0], ld[1]);
     };
+    if (MODE == 1) {                                // y = lrelu(BN(acc)) in S32 -> Y
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + 4 * q4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + nl);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + nl);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = fmaf(acc[i][j][e], sc[e], sh[e]); v[e] = fmaxf(t, 0.3f * t); }
+                put_s32(v, wm * 64 + i * 16 + r16, nl);
+            }
+        }
+        lds_barrier();
+        copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
+        return;
+    }
+    if (MODE == 2) {                                // out = acc (+ R), fp32, through the row image
+        if (Cn) {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int pidx = q * 256 + tid;
+                const int row = pidx >> 5, pos = pidx & 31;
+                const int cs = (pos & ~7) | ((pos ^ row) & 7);
+                const int m = min(m0 + row, p.M - 1);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wm * 64 + i * 16 + r16, nl = wn * 64 + j * 16 + 4 * q4;
+                f32x4* slot = reinterpret_cast<f32x4*>(smem + ml * 512 + (nl >> 5) * 128 + ((((nl & 31) >> 2) ^ (ml & 7)) << 4));
+                *slot = Cn ? acc[i][j] + *slot : acc[i][j];
+            }
+        lds_barrier();
+        copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
+        return;
+    }
     if (Cn) {
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
@@ -204,8 +258,37 @@ bool r2_step_supported(const GemmParams& p) {
 hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream) {
     if (!r2_step_supported(p)) return hipErrorInvalidValue;
     static DeviceOnce attr;
-    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(r2_step_kernel), RS_LDS)) return e;
-    hipLaunchKernelGGL(r2_step_kernel, dim3((p.M + RS_TILE - 1) / RS_TILE), dim3(256), RS_LDS, stream, p);
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(r2_step_kernel<0>), RS_LDS)) return e;
+    hipLaunchKernelGGL(r2_step_kernel<0>, dim3((p.M + RS_TILE - 1) / RS_TILE), dim3(256), RS_LDS, stream, p);
+    return hipGetLastError();
+}
+
+// RawNet2's 128 -> 128, k = 3 convolutions on F32X3 handles: A (M, lda) and W (128, 384) in the S32 layout, zero padding inside each utterance
+// (zero_page: >= 128 bytes of zeros), no bias.  mode 1: Y = lrelu0.3(BN(conv)) in S32 (row stride ldy elements); mode 2: Y = conv (+ R) in fp32.
+bool rn_step_supported(const GemmParams& p, int mode) {
+    if (!(mode == 1 || mode == 2) || p.x3 != 2 || p.taps != 3 || p.A2 || p.A3 || p.bias_utt || p.colsum || p.bias) return false;
+    if (p.cin != 128 || p.N != 128 || p.K != 384 || p.Kp != 384 || p.Wrows < 128 || p.pad_mode != PAD_ZERO || !p.zero_page) return false;
+    if (mode == 1 && (!p.scale || !p.shift || p.out_f32 || p.R || p.ldy % 32 != 0)) return false;
+    if (mode == 2 && (!p.out_f32 || p.ldy % 4 != 0 || (p.R && p.ldr % 4 != 0))) return false;
+    if (!p.Y || !p.A || !p.W || p.lda < 128 || p.lda % 32 != 0) return false;
+    if (p.T < 2 || p.dil != 1 || p.M <= 0 || p.M % p.T != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.R) |
+         reinterpret_cast<uintptr_t>(p.zero_page) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
+    return true;
+}
+
+hipError_t launch_rn_step(const GemmParams& p, int mode, hipStream_t stream) {
+    if (!rn_step_supported(p, mode)) return hipErrorInvalidValue;
+    const dim3 grid((p.M + RS_TILE - 1) / RS_TILE);
+    if (mode == 1) {
+        static DeviceOnce attr1;
+        if (hipError_t e = set_max_dynamic_lds(attr1, reinterpret_cast<const void*>(r2_step_kernel<1>), RS_LDS)) return e;
+        hipLaunchKernelGGL(r2_step_kernel<1>, grid, dim3(256), RS_LDS, stream, p);
+    } else {
+        static DeviceOnce attr2;
+        if (hipError_t e = set_max_dynamic_lds(attr2, reinterpret_cast<const void*>(r2_step_kernel<2>), RS_LDS)) return e;
+        hipLaunchKernelGGL(r2_step_kernel<2>, grid, dim3(256), RS_LDS, stream, p);
+    }
     return hipGetLastError();
 }
 

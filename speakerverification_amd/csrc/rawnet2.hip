@@ -378,6 +378,21 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
     }
 }
 
+// four consecutive channels c .. c + 3 (c % 4 == 0) of row `row` into the S32 split layout (per row, per 32 channels: 32 hi | 32 lo halves):
+// the operand format of the split convolution kernels (r2_step.hip); C channels per row
+__device__ __forceinline__ void store_s32_chunk(char* base, int64_t row, int C, int c, const float (&v)[4]) {
+    x3x4_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const x3_t hb = x3_hi(v[j]);
+        hi[j] = hb;
+        lo[j] = x3_lo(v[j], hb);
+    }
+    char* q = base + row * (int64_t)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<x3x4_t*>(q) = hi;
+    *reinterpret_cast<x3x4_t*>(q + 64) = lo;
+}
+
 // ---- the sinc front-end of F32X3 handles: fp32 in / out, products as three fp16 MFMAs on half hi | lo parts (round 4) ----------------------
 // Same structure as the 16-bit path of rn_sinc_kernel (LayerNorm output staged by 4-byte LDS-DMA into eight sample-shifted copies, filter
 // fragments in registers, v_mfma_f32_16x16x32_f16, pooled tile through an LDS image), with a second plane for everything: the lo parts of the
@@ -398,8 +413,11 @@ struct SincX3Cfg {
 };
 
 // filt: [2][128][256] half (hi plane, lo plane; k contiguous, zero beyond 251); xn: per utterance four rows of Lp halves (rn_ln_stats<LO>)
+// pre32 (optional): block 0's pre-activation lrelu0.3(bn1(x)) in the S32 split layout, written from the same LDS image (the operand of the
+// split convolution kernel: no separate rn_bn_act pass over the 1.4 GB front-end output)
 __global__ __launch_bounds__(256, 2) void rn_sinc_x3_kernel(const f16_t* __restrict__ filt, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
-                                                            float* __restrict__ out, int T1, int B, const uint16_t* __restrict__ xn, int Lp) {
+                                                            float* __restrict__ out, int T1, int B, const uint16_t* __restrict__ xn, int Lp,
+                                                            char* __restrict__ pre32, const float* __restrict__ nscale, const float* __restrict__ nshift) {
     typedef SincX3Cfg CF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_u = (T1 + SX_PT - 1) / SX_PT;
@@ -421,6 +439,9 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_x3_kernel(const f16_t* __restr
             wlo[blk][kk] = *reinterpret_cast<const bf16x8*>(w + 128 * 256 * 2 + kk * 64);
         }
     }
+    // (a thread's chunk column c16 = tid & 31 is the same in every trip of the flush: its four bn1 constants stay in registers)
+    f32x4 nsc4 = {0.f, 0.f, 0.f, 0.f}, nsh4 = {0.f, 0.f, 0.f, 0.f};
+    if (pre32) { nsc4 = *reinterpret_cast<const f32x4*>(nscale + (tid & 31) * 4); nsh4 = *reinterpret_cast<const f32x4*>(nshift + (tid & 31) * 4); }
     auto flush = [&](int b, int tpf, const char* img) {              // 32 rows x 32 chunks of 16 bytes, 4 per thread
         int tid_f = tid;
         asm volatile("" : "+v"(tid_f));
@@ -429,7 +450,16 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_x3_kernel(const f16_t* __restr
             const int idx = e * 256 + tid_f;
             const int row = idx >> 5, c16 = idx & 31;
             const f32x4 t = *reinterpret_cast<const f32x4*>(img + row * 512 + ((c16 ^ (row & 31)) << 4));
-            if (tpf + row < T1) *reinterpret_cast<f32x4*>(out + ((int64_t)b * T1 + tpf + row) * 128 + c16 * 4) = t;
+            if (tpf + row < T1) {
+                const int64_t grow = (int64_t)b * T1 + tpf + row;
+                *reinterpret_cast<f32x4*>(out + grow * 128 + c16 * 4) = t;
+                if (pre32) {
+                    float pv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const float w = fmaf(t[u], nsc4[u], nsh4[u]); pv[u] = w > 0.0f ? w : 0.3f * w; }
+                    store_s32_chunk(pre32, grow, 128, c16 * 4, pv);
+                }
+            }
         }
     };
     typedef __attribute__((address_space(3))) void lds_void_t;
@@ -518,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_x3_kernel(const f16_t* __restr
     }
 }
 
-template <typename T>
+template <typename T, bool S32 = false>
 __global__ __launch_bounds__(256) void rn_bn_act_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int C, float slope, int64_t chunks) {
     constexpr int VEC = Vec16<T>::N;
@@ -531,6 +561,10 @@ __global__ __launch_bounds__(256) void rn_bn_act_kernel(const T* __restrict__ x,
             const float t = fmaf(v.get(j), scale[c + j], shift[c + j]);
             o.set(j, t > 0.0f ? t : slope * t);
         }
+        if constexpr (S32) {           // (fp32 only: y is the S32 image of the result)
+            const float vv[4] = {o.get(0), o.get(1), o.get(2), o.get(3)};
+            store_s32_chunk(reinterpret_cast<char*>(y), id / cpr, C, c, vv);
+        } else
         *reinterpret_cast<Vec16<T>*>(y + id * VEC) = o;
     }
 }
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(256) void rn_maxpool3_kernel(const T* __restrict__ 
 
 // AFMS gate; with `pre` the next block's pre-activation lrelu(bn1(.)) (or the aggregation BN) is written in the same pass,
 // computed from the value as stored (rounded to T), so the result equals a separate rn_bn_act over y bit for bit.
-template <typename T>
+template <typename T, bool S32 = false>
 __global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ alpha,
                                                             const float* __restrict__ s, int Tn, int C, int64_t chunks,
                                                             const float* __restrict__ nscale, const float* __restrict__ nshift,
@@ -577,6 +611,10 @@ __global__ __launch_bounds__(256) void rn_afms_apply_kernel(const T* __restrict_
                 const float t = fmaf(o.get(j), nscale[c + j], nshift[c + j]);
                 q.set(j, t > 0.0f ? t : slope * t);
             }
+            if constexpr (S32) {       // (fp32 only: pre is the S32 image of the next pre-activation)
+                const float vv[4] = {q.get(0), q.get(1), q.get(2), q.get(3)};
+                store_s32_chunk(reinterpret_cast<char*>(pre), id / cpr, C, c, vv);
+            } else
             *reinterpret_cast<Vec16<T>*>(pre + id * VEC) = q;
         }
     }
@@ -876,7 +914,9 @@ hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gam
 
 // F32X3 handles: out (B, T1, 128) fp32 from the split LayerNorm output (rn_ln_stats with xn_lo: four rows of Lp halves per utterance)
 hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, const float* bn_shift, float* out, int B, int L, int T1,
-                             const void* xn, int Lp, int num_cu, hipStream_t stream) {
+                             const void* xn, int Lp, int num_cu, hipStream_t stream, void* pre_s32, const float* next_scale, const float* next_shift) {
+    if (pre_s32 && (!next_scale || !next_shift || ((reinterpret_cast<uintptr_t>(pre_s32) | reinterpret_cast<uintptr_t>(next_scale) | reinterpret_cast<uintptr_t>(next_shift)) & 15)))
+        return hipErrorInvalidValue;
     if (B <= 0 || !filt_planes || !bn_scale || !bn_shift || !out || !xn) return hipErrorInvalidValue;
     if (T1 != (L - 250) / 3 || L < 251 + 3 || Lp < L + RN_XN_TAIL || Lp % 64 != 0) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(filt_planes) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(xn)) & 15) return hipErrorInvalidValue;
@@ -886,18 +926,21 @@ hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, con
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(rn_sinc_x3_kernel), SincX3Cfg::LDS)) return e;
     const int slots = 2 * (num_cu > 0 ? num_cu : 256);
     hipLaunchKernelGGL(rn_sinc_x3_kernel, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SincX3Cfg::LDS, stream,
-                       reinterpret_cast<const f16_t*>(filt_planes), bn_scale, bn_shift, out, T1, B, reinterpret_cast<const uint16_t*>(xn), Lp);
+                       reinterpret_cast<const f16_t*>(filt_planes), bn_scale, bn_shift, out, T1, B, reinterpret_cast<const uint16_t*>(xn), Lp,
+                       reinterpret_cast<char*>(pre_s32), next_scale, next_shift);
     return hipGetLastError();
 }
 
 hipError_t launch_rn_bn_act(const void* x, void* y, int dt, const float* scale, const float* shift, int64_t rows, int C,
-                            float slope, hipStream_t stream) {
+                            float slope, hipStream_t stream, bool y_s32) {
+    if (y_s32 && (dt != DT_F32 || C % 32 != 0 || (reinterpret_cast<uintptr_t>(y) & 127))) return hipErrorInvalidValue;
     const bool bf16 = dt == DT_BF16;
     const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec) return hipErrorInvalidValue;
     const int64_t chunks = rows * (C / vec);
     if (dt == DT_F16) hipLaunchKernelGGL(rn_bn_act_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, scale, shift, C, slope, chunks);
     else if (bf16) hipLaunchKernelGGL(rn_bn_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, scale, shift, C, slope, chunks);
+    else if (y_s32) hipLaunchKernelGGL((rn_bn_act_kernel<float, true>), dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, scale, shift, C, slope, chunks);
     else hipLaunchKernelGGL(rn_bn_act_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, scale, shift, C, slope, chunks);
     return hipGetLastError();
 }
@@ -915,13 +958,15 @@ hipError_t launch_rn_maxpool3(const void* x, void* y, int dt, int B, int Tin, in
 }
 
 hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alpha, const float* s, int B, int T, int C,
-                                hipStream_t stream, const float* next_scale, const float* next_shift, void* pre, float slope) {
+                                hipStream_t stream, const float* next_scale, const float* next_shift, void* pre, float slope, bool pre_s32) {
+    if (pre_s32 && (dt != DT_F32 || !pre || C % 32 != 0 || (reinterpret_cast<uintptr_t>(pre) & 127))) return hipErrorInvalidValue;
     const bool bf16 = dt == DT_BF16;
     const int vec = dt != DT_F32 ? 8 : 4;
     if (C % vec || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     const int64_t chunks = (int64_t)B * T * (C / vec);
     if (dt == DT_F16) hipLaunchKernelGGL(rn_afms_apply_kernel<f16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (f16_t*)pre, slope);
     else if (bf16) hipLaunchKernelGGL(rn_afms_apply_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, alpha, s, T, C, chunks, next_scale, next_shift, (bf16_t*)pre, slope);
+    else if (pre_s32) hipLaunchKernelGGL((rn_afms_apply_kernel<float, true>), dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks, next_scale, next_shift, (float*)pre, slope);
     else hipLaunchKernelGGL(rn_afms_apply_kernel<float>, dim3(grid_for(chunks)), dim3(256), 0, stream, (const float*)x, (float*)y, alpha, s, T, C, chunks, next_scale, next_shift, (float*)pre, slope);
     return hipGetLastError();
 }
