@@ -191,6 +191,41 @@ def test_f32x3_sinc_front_end_on_split_halves_matches_the_exact_fp32_mfma(L, B):
     assert dfront <= 2e-6 and demb <= 1e-4          # (embeddings: the mode's own bar — the blocks behind the front-end are split products too)
 
 
+@pytest.mark.parametrize("L,B", [(32000, 3), (16001, 2), (20003, 5), (4000, 1), (32000, 33)])
+def test_f32x3_split_convolution_kernel_of_the_128_channel_blocks(L, B):
+    """Round 4: on F32X3 handles layer1 / layer2 (128 -> 128, k = 3, zero padding) run on the 128 x 128 split kernel (csrc/r2_step.hip, modes
+    1 / 2): operands in the S32 layout, conv1 -> BN -> LeakyReLU -> S32, conv2 + identity shortcut -> fp32; the pre-activations are written in
+    the S32 layout by their producers (rn_sinc_x3, rn_afms_apply).  Option rn_step_off keeps the tiled kernel that splits fp32 operands in
+    registers: same three products per element, another summation order."""
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=10)
+    wav = synth.synth_waveforms(B, L, seed=19)
+    eng = Engine(model="rawnet2", compute="f32x3", embed_dim=320, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    res = {}
+    for off in (1, 0):
+        eng.set_option("rn_step_off", off)
+        eng.profile(True)
+        res[off] = eng.embed_wave(wav).reshape(B, -1).copy()
+        labels = eng.profile_results()
+        eng.profile(False)
+        assert ("rn_step" in labels) == (not off), sorted(labels)
+        if not off:
+            assert labels["rn_step"]["launches"] == 4 and "rn_bn_act" not in labels, sorted(labels)
+            # (short utterances: block 0's tail fits the fused rn_tail kernel, which writes fp32 — block 1's operand is then split by a pass)
+            assert ("split_s32" in labels) == (L <= 4000), sorted(labels)
+    eng.close()
+    f32 = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=B, samples=L)
+    f32.load_state_dict(sd)
+    f32.finalize()
+    ref = f32.embed_wave(wav).reshape(B, -1)
+    f32.close()
+    scale = float(np.abs(ref).max())
+    d_on, d_off = float(np.abs(res[0] - ref).max()) / scale, float(np.abs(res[1] - ref).max()) / scale
+    print(f"L={L} B={B}: split convolution kernel {d_on:.2e} of the fp32 scale, tiled kernel {d_off:.2e}")
+    assert np.isfinite(res[0]).all() and d_on <= 1e-4 and d_off <= 1e-4
+
+
 @pytest.mark.parametrize("compute,L,B", [("f32", 32000, 5), ("f16", 32000, 20), ("bf16", 20000, 3), ("f16", 32000, 64)])
 def test_small_batch_tail_in_slices_matches_the_one_workgroup_tail(compute, L, B):
     """Round 4: at B * 4 <= CUs the block tail (max-pool + AFMS + next pre-activation) runs as slice sums -> rn_afms_gate -> apply over
