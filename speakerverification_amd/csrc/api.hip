@@ -561,7 +561,9 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
             L.Wsplit = dsplit;
             // pointwise GELU layers (gemm_pw3's X3 form) and the Res2Net convolutions (its R2 form: N == cin, k = 3)
             if ((taps == 1 && N % 256 == 0 && L.K == L.Kp && L.K % 64 == 0 && L.K >= 128) ||
-                (taps == 3 && N == cin && (cin == 64 || cin == 128) && L.K == L.Kp)) {
+                (taps == 3 && N == cin && (cin == 64 || cin == 128) && L.K == L.Kp) ||
+                // RawNet2's convolutions and projection shortcuts (r2_step.hip, modes 1 / 2)
+                (h->cfg.model == SVHIP_MODEL_RAWNET2 && (taps == 1 || taps == 3) && N % 128 == 0 && cin % 32 == 0 && L.K == L.Kp && L.K == taps * cin)) {
                 std::vector<uint16_t> s32((size_t)N * L.K * 2);
                 for (int n = 0; n < N; ++n)
                     for (int k = 0; k < L.K; ++k) {
@@ -1276,7 +1278,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     auto x3_step_block = [&](int bn, int Tn) {
         if (bn > 7 || !h->x3 || h->opt.rn_step_off || stop_after >= 0 || snap_at >= 0) return false;
         const svhip_handle::RnBlock& Kn = h->rn_blocks[bn];
-        return Kn.cin == 128 && Kn.cout == 128 && !Kn.has_shortcut && Kn.conv1.Ws32 && Kn.conv2.Ws32 && Tn >= 2;
+        return Kn.cin % 32 == 0 && Kn.cout % 128 == 0 && Kn.conv1.Ws32 && Kn.conv2.Ws32 && (!Kn.has_shortcut || Kn.shortcut.Ws32) && Tn >= 2;
     };
     bool pre_is_s32 = false;
     // (the split front-end writes block 0's pre-activation itself, in the S32 layout, when block 0 runs on the split convolution kernel)
@@ -1348,30 +1350,41 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         const void* resid = x;                                                       // identity shortcut takes the pre-BN x (:223)
         const void* resid_in_tail = nullptr;
         const bool tail_fused = !no_tail && rn_tail_supported(dt, K.downsample ? T / 3 : T, K.cout);
-        if (K.has_shortcut && !fold_sc) {
+        // F32X3: the block's convolutions (and its projection shortcut) on the 128 x 128 split kernel (r2_step.hip, modes 1 / 2) — pre in the
+        // S32 layout, conv1's output stays S32 (conv2's operand), conv2 adds the shortcut on the way out.  (Otherwise they run on the tiled
+        // kernel that splits its fp32 operands in registers: 170 - 190 TFLOP/s.)
+        const bool x3_step = h->x3 && !h->opt.rn_step_off && K.cin % 32 == 0 && K.cout % 128 == 0 && K.conv1.Ws32 && K.conv2.Ws32 &&
+                             (!K.has_shortcut || K.shortcut.Ws32) && T >= 2;
+        if (K.has_shortcut && !fold_sc && !x3_step) {
             if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
             resid = sc;
         }
-        // F32X3, the 128 -> 128 blocks (layer1, layer2: 40 % of the model's FLOPs on its longest time axes): both convolutions on the 128 x 128
-        // split kernel (r2_step.hip, modes 1 / 2) — pre in the S32 layout, conv1's output stays S32 (conv2's operand), conv2 adds the identity
-        // shortcut on the way out.  (Otherwise they run on the tiled kernel that splits its fp32 operands in registers: 186 TFLOP/s.)
-        const bool x3_step = h->x3 && !h->opt.rn_step_off && K.cin == 128 && K.cout == 128 && !K.has_shortcut && K.conv1.Ws32 && K.conv2.Ws32 && T >= 2;
         if (pre_is_s32 && !x3_step) SV_FAIL(h, SVHIP_ERR_STATE, "RawNet2 block %d: split pre-activation without the split convolution route", bi);
         if (x3_step) {
-            GemmParams q1;
-            q1.A = pre_is_s32 ? pre : sc; q1.lda = 128; q1.W = K.conv1.Ws32; q1.Wrows = 128; q1.x3 = 2;
+            GemmParams q1;                                   // conv1: pre (S32) -> lrelu(bn2(.)) in S32
+            void* const split_dst = K.has_shortcut ? xn : sc;      // (fp32 pre: its S32 copy goes to a buffer that is free here — the next-x buffer when `sc` holds the projected shortcut)
+            q1.A = pre_is_s32 ? pre : split_dst; q1.lda = K.cin; q1.W = K.conv1.Ws32; q1.Wrows = K.cout; q1.x3 = 2;
             q1.scale = K.conv1.scale; q1.shift = K.conv1.shift;
-            q1.M = M; q1.N = 128; q1.K = 384; q1.Kp = 384; q1.T = T; q1.taps = 3; q1.dil = 1; q1.cin = 128; q1.pad_mode = PAD_ZERO;
-            q1.zero_page = h->d_zeros; q1.Y = hb; q1.ldy = 128; q1.num_cu = h->num_cu;
-            GemmParams q2 = q1;
-            q2.A = hb; q2.W = K.conv2.Ws32; q2.scale = nullptr; q2.shift = nullptr; q2.Y = o; q2.out_f32 = 1; q2.R = reinterpret_cast<const float*>(x); q2.ldr = 128;
-            if (rn_step_supported(q1, 1) && rn_step_supported(q2, 2)) {
-                if (!pre_is_s32 && (rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(pre), 128, sc, M, 128, st); }))) return rc;
+            q1.M = M; q1.N = K.cout; q1.K = 3 * K.cin; q1.Kp = q1.K; q1.T = T; q1.taps = 3; q1.dil = 1; q1.cin = K.cin; q1.pad_mode = PAD_ZERO;
+            q1.zero_page = h->d_zeros; q1.Y = hb; q1.ldy = K.cout; q1.num_cu = h->num_cu;
+            GemmParams q2 = q1;                              // conv2: h (S32) -> fp32, + the shortcut (identity x, or the projected one)
+            q2.A = hb; q2.lda = K.cout; q2.cin = K.cout; q2.K = 3 * K.cout; q2.Kp = q2.K; q2.W = K.conv2.Ws32; q2.scale = nullptr; q2.shift = nullptr;
+            q2.Y = o; q2.out_f32 = 1; q2.R = reinterpret_cast<const float*>(K.has_shortcut ? sc : x); q2.ldr = K.cout;
+            GemmParams q0 = q1;                              // projection shortcut (k = 1) of pre -> fp32, into the spare activation buffer
+            q0.W = K.shortcut.Ws32; q0.taps = 1; q0.K = K.cin; q0.Kp = K.cin; q0.scale = nullptr; q0.shift = nullptr; q0.Y = sc; q0.out_f32 = 1;
+            const bool ok = rn_step_supported(q1, 1) && rn_step_supported(q2, 2) && (!K.has_shortcut || rn_step_supported(q0, 2));
+            if (ok) {
+                if (!pre_is_s32 && (rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(pre), K.cin, split_dst, M, K.cin, st); }))) return rc;
+                if (K.has_shortcut && (rc = run(h, "rn_step", (double)M * K.shortcut.flops_per_row, [&]() { return launch_rn_step(q0, 2, st); }))) return rc;
                 if ((rc = run(h, "rn_step", (double)M * K.conv1.flops_per_row, [&]() { return launch_rn_step(q1, 1, st); }))) return rc;
                 if ((rc = run(h, "rn_step", (double)M * K.conv2.flops_per_row, [&]() { return launch_rn_step(q2, 2, st); }))) return rc;
                 goto convs_done;
             }
             if (pre_is_s32) SV_FAIL(h, SVHIP_ERR_STATE, "RawNet2 block %d: the split convolution kernel refused a shape its producer was told it takes", bi);
+            if (K.has_shortcut && !fold_sc) {               // (the tiled route after all: its projection shortcut)
+                if ((rc = conv_gemm(h, "rn_gemm", K.shortcut, pre, K.cin, sc, K.cout, M, ACT_NONE))) return rc;
+                resid = sc;
+            }
         }
         if ((rc = conv_gemm(h, "rn_gemm", K.conv1, pre, K.cin, hb, K.cout, M, ACT_NONE, ACT_LRELU03, nullptr, 0, nullptr, 0, false, T, PAD_ZERO))) return rc;
         if (fold_sc) {
@@ -1396,15 +1409,16 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         const int Tn = K.downsample ? T / 3 : T;
         if (tail_fused) {
             // max-pool + AFMS + next pre-activation in one launch, the pooled activation held in registers      :228-229, :62-68
+            const bool tail_s32 = npre && x3_step_block(bi + 1, Tn);      // (F32X3: the next block's operand straight in the S32 layout)
             char tl[48] = "rn_tail";
             if (h->opt.layer_labels) snprintf(tl, sizeof(tl), "rn_tail T%d C%d", T, K.cout);
             if ((rc = run(h, tl, 2.0 * B * K.cout * K.cout, [&]() {
                      // (small batches: slice sums in rn_scratch, the gate in rn_gate[0]; option rn_tail_big keeps one workgroup per utterance)
                      const bool sliced = !h->opt.rn_tail_big;
                      return launch_rn_tail(o, x_dead ? nullptr : xn, npre, dt, K.downsample, K.alpha, K.afms_fcT, K.afms_fc.bias, nsc, nsh, B, T, K.cout, 0.3f, st,
-                                           resid_in_tail, sliced ? rn_scratch : nullptr, sliced ? rn_gate[0] : nullptr, h->num_cu);
+                                           resid_in_tail, sliced ? rn_scratch : nullptr, sliced ? rn_gate[0] : nullptr, h->num_cu, tail_s32);
                  }))) return rc;
-            pre_is_s32 = false;                                 // (the fused tails write fp32; a split consumer converts it: split_s32)
+            pre_is_s32 = tail_s32;
             T = Tn;
         } else {
             void* y = o;

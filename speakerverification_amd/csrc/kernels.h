@@ -320,7 +320,7 @@ hipError_t launch_rn_afms_apply(const void* x, void* y, int dt, const float* alp
 bool rn_tail_supported(int dt, int Tn, int C);
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
                           const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream,
-                          const void* res = nullptr, float* part = nullptr, float* gate = nullptr, int num_cu = 0);
+                          const void* res = nullptr, float* part = nullptr, float* gate = nullptr, int num_cu = 0, bool pre_s32 = false);
 // small batches (B * 4 <= num_cu) with `part` (B x 16 x C floats) and `gate` (B x C floats): the utterance in frame slices over several
 // workgroups (slice sums -> rn_afms_gate -> apply); returns the slice count, 0 = the one-workgroup-per-utterance kernel
 int rn_tail_slices(int dt, int B, int Tn, int C, int num_cu);       // res: the block input, added to x before the pool (16-bit handles; see rn_tail_kernel)

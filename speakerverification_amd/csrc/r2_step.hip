@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;        // rows wm * 64 .. + 63, channels wn * 64 .. + 63
     const int r16 = lane & 15, q4 = lane >> 4;
     const int m0 = blockIdx.x * RS_TILE;
+    const int n0 = MODE == 0 ? 0 : (int)blockIdx.y * RS_TILE;      // (modes 1 / 2: N may be several tiles of 128 channels)
 
     // ---- operand DMA addressing: thread -> four (row, 16-byte slot) items of a 128 x 128-byte half-buffer; the swizzle
     //      (slot ^ (row >> 1 & 7)) goes on the source chunk ----
@@ -52,11 +53,14 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         xm[q] = m;
         xt[q] = m % p.T;
         xc[q] = (uint32_t)c * 16u;
-        wo[q] = (uint32_t)row * (uint32_t)p.Kp * 4u + (uint32_t)c * 16u;          // weight row = output channel `row` (N = 128 rows)
+        wo[q] = (uint32_t)(n0 + row) * (uint32_t)p.Kp * 4u + (uint32_t)c * 16u;     // weight row = output channel n0 + row (< 2^32 bytes: host check)
     }
     auto issue = [&](int kt, int buf) {
-        const int tap = kt >> 2, kin = kt & 3;                                      // four 32-k blocks per tap (cin = 128)
-        const int shift = (tap - 1) * p.dil;
+        // 32-k blocks per tap: four (cin = 128) in the Res2Net step; cin / 32 in modes 1 / 2 (taps = 1 or 3, dilation 1)
+        int tap, kin;
+        if (MODE == 0) { tap = kt >> 2; kin = kt & 3; }
+        else { const int ktpt = p.cin >> 5; tap = kt / ktpt; kin = kt - tap * ktpt; }
+        const int shift = MODE == 0 ? (tap - 1) * p.dil : tap - (p.taps >> 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* s;
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = wn * 64 + j * 16 + 4 * q4;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + nl);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + nl);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + nl);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n0 + nl);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
             }
         }
         lds_barrier();
-        copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
+        copy_out(reinterpret_cast<char*>(p.Y) + (int64_t)n0 * 4, (int64_t)p.ldy * 4);      // (128 channels = four S32 blocks = 512 bytes, like 128 floats)
         return;
     }
     if (MODE == 2) {                                // out = acc (+ R), fp32, through the row image
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
                 const int row = pidx >> 5, pos = pidx & 31;
                 const int cs = (pos & ~7) | ((pos ^ row) & 7);
                 const int m = min(m0 + row, p.M - 1);
-                __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + n0 + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
                 *slot = Cn ? acc[i][j] + *slot : acc[i][j];
             }
         lds_barrier();
-        copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
+        copy_out(reinterpret_cast<char*>(p.Y) + (int64_t)n0 * 4, (int64_t)p.ldy * 4);
         return;
     }
     if (Cn) {
@@ -263,14 +267,16 @@ hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// RawNet2's 128 -> 128, k = 3 convolutions on F32X3 handles: A (M, lda) and W (128, 384) in the S32 layout, zero padding inside each utterance
-// (zero_page: >= 128 bytes of zeros), no bias.  mode 1: Y = lrelu0.3(BN(conv)) in S32 (row stride ldy elements); mode 2: Y = conv (+ R) in fp32.
+// RawNet2's convolutions on F32X3 handles (k = 3 with zero padding inside each utterance, or k = 1: the projection shortcuts; cin a multiple of
+// 32, N of 128): A (M, lda) and W (N, taps cin) in the S32 layout, zero_page >= 128 bytes of zeros, no bias.  mode 1: Y = lrelu0.3(BN(conv)) in
+// S32 (row stride ldy elements); mode 2: Y = conv (+ R) in fp32.  Grid (M tiles, N tiles of 128 channels).
 bool rn_step_supported(const GemmParams& p, int mode) {
-    if (!(mode == 1 || mode == 2) || p.x3 != 2 || p.taps != 3 || p.A2 || p.A3 || p.bias_utt || p.colsum || p.bias) return false;
-    if (p.cin != 128 || p.N != 128 || p.K != 384 || p.Kp != 384 || p.Wrows < 128 || p.pad_mode != PAD_ZERO || !p.zero_page) return false;
+    if (!(mode == 1 || mode == 2) || p.x3 != 2 || !(p.taps == 3 || p.taps == 1) || p.A2 || p.A3 || p.bias_utt || p.colsum || p.bias) return false;
+    if (p.cin < 32 || p.cin % 32 != 0 || p.N < 128 || p.N % 128 != 0 || p.K != p.taps * p.cin || p.Kp != p.K || p.Wrows < p.N || p.pad_mode != PAD_ZERO || !p.zero_page) return false;
+    if ((int64_t)p.Wrows * p.Kp * 4 >= ((int64_t)1 << 32) || p.N / 128 > 65535) return false;
     if (mode == 1 && (!p.scale || !p.shift || p.out_f32 || p.R || p.ldy % 32 != 0)) return false;
     if (mode == 2 && (!p.out_f32 || p.ldy % 4 != 0 || (p.R && p.ldr % 4 != 0))) return false;
-    if (!p.Y || !p.A || !p.W || p.lda < 128 || p.lda % 32 != 0) return false;
+    if (!p.Y || !p.A || !p.W || p.lda < p.cin || p.lda % 32 != 0 || p.ldy < p.N || (p.R && p.ldr < p.N)) return false;
     if (p.T < 2 || p.dil != 1 || p.M <= 0 || p.M % p.T != 0) return false;
     if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.R) |
          reinterpret_cast<uintptr_t>(p.zero_page) | reinterpret_cast<uintptr_t>(p.scale) | reinterpret_cast<uintptr_t>(p.shift)) & 15) return false;
@@ -279,7 +285,7 @@ bool rn_step_supported(const GemmParams& p, int mode) {
 
 hipError_t launch_rn_step(const GemmParams& p, int mode, hipStream_t stream) {
     if (!rn_step_supported(p, mode)) return hipErrorInvalidValue;
-    const dim3 grid((p.M + RS_TILE - 1) / RS_TILE);
+    const dim3 grid((p.M + RS_TILE - 1) / RS_TILE, p.N / RS_TILE);
     if (mode == 1) {
         static DeviceOnce attr1;
         if (hipError_t e = set_max_dynamic_lds(attr1, reinterpret_cast<const void*>(r2_step_kernel<1>), RS_LDS)) return e;

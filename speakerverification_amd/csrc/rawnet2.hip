@@ -664,7 +664,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
                                                                const float* __restrict__ alpha, const float* __restrict__ WT,
                                                                const float* __restrict__ bias, const float* __restrict__ nscale,
                                                                const float* __restrict__ nshift, int Tin, int Tn, int C, float slope,
-                                                               const T* __restrict__ res) {
+                                                               const T* __restrict__ res, int pre_s32) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float part[8192];                     // 32 KiB: column-sum partials, then the gate's partial dot products
     __shared__ float mean[512], gate[512];
@@ -758,7 +758,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void rn_tail_kernel(const T* __restri
                     const float v = fmaf(o.get(j), ns[j], nh[j]);
                     q.set(j, v > 0.0f ? v : slope * v);
                 }
-                *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+                if constexpr (sizeof(T) == 4) {
+                    if (pre_s32) {          // (fp32 handles: the next block's operand in the S32 split layout)
+                        const float vv[4] = {q.get(0), q.get(1), q.get(2), q.get(3)};
+                        store_s32_chunk(reinterpret_cast<char*>(pre), b * Tn + t, C, c, vv);
+                    } else *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+                } else *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
             }
         }
     }
@@ -835,7 +840,7 @@ template <typename T, bool POOL, bool RES>
 __global__ __launch_bounds__(TAILS_THREADS) void rn_tail_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, T* __restrict__ pre,
                                                                       const float* __restrict__ alpha, const float* __restrict__ gate,
                                                                       const float* __restrict__ nscale, const float* __restrict__ nshift,
-                                                                      int Tin, int Tn, int C, int per, float slope) {
+                                                                      int Tin, int Tn, int C, int per, float slope, int pre_s32) {
     constexpr int VEC = Vec16<T>::N;
     const int tid = threadIdx.x, s = blockIdx.x;
     const int64_t b = blockIdx.y;
@@ -865,7 +870,12 @@ __global__ __launch_bounds__(TAILS_THREADS) void rn_tail_apply_kernel(const T* _
                 const float w = fmaf(o.get(j), ns[j], nh[j]);
                 q.set(j, w > 0.0f ? w : slope * w);
             }
-            *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+            if constexpr (sizeof(T) == 4) {
+                    if (pre_s32) {          // (fp32 handles: the next block's operand in the S32 split layout)
+                        const float vv[4] = {q.get(0), q.get(1), q.get(2), q.get(3)};
+                        store_s32_chunk(reinterpret_cast<char*>(pre), b * Tn + t, C, c, vv);
+                    } else *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
+                } else *reinterpret_cast<Vec16<T>*>(pb + (int64_t)t * C) = q;
         }
     }
 }
@@ -993,7 +1003,8 @@ int rn_tail_slices(int dt, int B, int Tn, int C, int num_cu) {
 
 hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, const float* alpha, const float* WT, const float* bias,
                           const float* next_scale, const float* next_shift, int B, int Tin, int C, float slope, hipStream_t stream, const void* res,
-                          float* part, float* gate, int num_cu) {
+                          float* part, float* gate, int num_cu, bool pre_s32) {
+    if (pre_s32 && (dt != DT_F32 || !pre || C % 32 != 0 || (reinterpret_cast<uintptr_t>(pre) & 127))) return hipErrorInvalidValue;
     const int Tn = pool ? Tin / 3 : Tin;
     if (!x || (!y && !pre) || !alpha || !WT || !bias || B <= 0 || !rn_tail_supported(dt, Tn, C) || (pre && (!next_scale || !next_shift)))
         return hipErrorInvalidValue;
@@ -1004,7 +1015,7 @@ hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, 
         const dim3 grid(S, B), block(TAILS_THREADS);
 #define SV_PART(TT, P, R) hipLaunchKernelGGL((rn_tail_part_kernel<TT, P, R>), grid, block, 0, stream, (const TT*)x, (const TT*)res, part, Tin, Tn, C, per)
 #define SV_APPLY(TT, P, R) hipLaunchKernelGGL((rn_tail_apply_kernel<TT, P, R>), grid, block, 0, stream, (const TT*)x, (const TT*)res, (TT*)y, (TT*)pre, \
-                                              alpha, gate, next_scale, next_shift, Tin, Tn, C, per, slope)
+                                              alpha, gate, next_scale, next_shift, Tin, Tn, C, per, slope, pre_s32 ? 1 : 0)
 #define SV_BOTH16(WHAT, TT) { if (res) { if (pool) WHAT(TT, true, true); else WHAT(TT, false, true); } else { if (pool) WHAT(TT, true, false); else WHAT(TT, false, false); } }
         if (dt == DT_F16) SV_BOTH16(SV_PART, f16_t)
         else if (dt == DT_BF16) SV_BOTH16(SV_PART, bf16_t)
@@ -1020,7 +1031,7 @@ hipError_t launch_rn_tail(const void* x, void* y, void* pre, int dt, bool pool, 
         return hipGetLastError();
     }
 #define SV_TAIL(TT, P, R) hipLaunchKernelGGL((rn_tail_kernel<TT, P, R>), dim3(B), dim3(TAIL_THREADS), 0, stream, (const TT*)x, (TT*)y, (TT*)pre, \
-                                             alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope, (const TT*)res)
+                                             alpha, WT, bias, next_scale, next_shift, Tin, Tn, C, slope, (const TT*)res, pre_s32 ? 1 : 0)
 #define SV_TAIL16(TT) { if (res) { if (pool) SV_TAIL(TT, true, true); else SV_TAIL(TT, false, true); } else { if (pool) SV_TAIL(TT, true, false); else SV_TAIL(TT, false, false); } }
     if (dt == DT_F16) SV_TAIL16(f16_t)
     else if (dt == DT_BF16) SV_TAIL16(bf16_t)

@@ -192,10 +192,10 @@ def test_f32x3_sinc_front_end_on_split_halves_matches_the_exact_fp32_mfma(L, B):
 
 
 @pytest.mark.parametrize("L,B", [(32000, 3), (16001, 2), (20003, 5), (4000, 1), (32000, 33)])
-def test_f32x3_split_convolution_kernel_of_the_128_channel_blocks(L, B):
-    """Round 4: on F32X3 handles layer1 / layer2 (128 -> 128, k = 3, zero padding) run on the 128 x 128 split kernel (csrc/r2_step.hip, modes
-    1 / 2): operands in the S32 layout, conv1 -> BN -> LeakyReLU -> S32, conv2 + identity shortcut -> fp32; the pre-activations are written in
-    the S32 layout by their producers (rn_sinc_x3, rn_afms_apply).  Option rn_step_off keeps the tiled kernel that splits fp32 operands in
+def test_f32x3_split_convolution_kernel_of_the_residual_blocks(L, B):
+    """Round 4: on F32X3 handles the convolutions of all eight residual blocks (k = 3 with zero padding, and the k = 1 projection shortcuts)
+    run on the 128 x 128 split kernel (csrc/r2_step.hip, modes 1 / 2): operands in the S32 layout, conv1 -> BN -> LeakyReLU -> S32,
+    conv2 + shortcut -> fp32; the pre-activations are written in the S32 layout by their producers (rn_sinc_x3, rn_afms_apply, rn_tail).  Option rn_step_off keeps the tiled kernel that splits fp32 operands in
     registers: same three products per element, another summation order."""
     sd = synth.synth_state_dict(synth.rawnet2_param_spec(nb_samp=L), seed=10)
     wav = synth.synth_waveforms(B, L, seed=19)
@@ -211,9 +211,9 @@ def test_f32x3_split_convolution_kernel_of_the_128_channel_blocks(L, B):
         eng.profile(False)
         assert ("rn_step" in labels) == (not off), sorted(labels)
         if not off:
-            assert labels["rn_step"]["launches"] == 4 and "rn_bn_act" not in labels, sorted(labels)
-            # (short utterances: block 0's tail fits the fused rn_tail kernel, which writes fp32 — block 1's operand is then split by a pass)
-            assert ("split_s32" in labels) == (L <= 4000), sorted(labels)
+            # every convolution of the eight blocks (16 k = 3 convolutions + 2 projection shortcuts) on the split kernel, every pre-activation
+            # written in the S32 layout by its producer: no conversion pass, no separate rn_bn_act, no tiled GEMM besides the attention head
+            assert labels["rn_step"]["launches"] == 18 and "rn_bn_act" not in labels and "split_s32" not in labels and "gemm_conv" not in labels, sorted(labels)
     eng.close()
     f32 = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=B, samples=L)
     f32.load_state_dict(sd)
