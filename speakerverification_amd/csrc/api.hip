@@ -80,6 +80,7 @@ struct svhip_handle {
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
+        int rn_pool_off = 0;      // F32X3 handles: conv2 of the long pooled blocks writes the un-pooled output, rn_maxpool3 pools it (tests)
         int rn_step_off = 0;      // F32X3 handles: the 128 -> 128 blocks' convolutions on the tiled in-register-split kernel (tests)
         int rn_sinc_f32 = 0;      // F32X3 handles: the sinc front-end on the exact fp32 MFMA (tests) instead of three fp16 MFMAs per product
         int rn_tail_big = 0;      // RawNet2 block tail: one workgroup per utterance at every batch size (tests)
@@ -1353,6 +1354,7 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
         // F32X3: the block's convolutions (and its projection shortcut) on the 128 x 128 split kernel (r2_step.hip, modes 1 / 2) — pre in the
         // S32 layout, conv1's output stays S32 (conv2's operand), conv2 adds the shortcut on the way out.  (Otherwise they run on the tiled
         // kernel that splits its fp32 operands in registers: 170 - 190 TFLOP/s.)
+        bool pooled_by_conv = false;
         const bool x3_step = h->x3 && !h->opt.rn_step_off && K.cin % 32 == 0 && K.cout % 128 == 0 && K.conv1.Ws32 && K.conv2.Ws32 &&
                              (!K.has_shortcut || K.shortcut.Ws32) && T >= 2;
         if (K.has_shortcut && !fold_sc && !x3_step) {
@@ -1377,7 +1379,9 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
                 if (!pre_is_s32 && (rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(reinterpret_cast<const float*>(pre), K.cin, split_dst, M, K.cin, st); }))) return rc;
                 if (K.has_shortcut && (rc = run(h, "rn_step", (double)M * K.shortcut.flops_per_row, [&]() { return launch_rn_step(q0, 2, st); }))) return rc;
                 if ((rc = run(h, "rn_step", (double)M * K.conv1.flops_per_row, [&]() { return launch_rn_step(q1, 1, st); }))) return rc;
-                if ((rc = run(h, "rn_step", (double)M * K.conv2.flops_per_row, [&]() { return launch_rn_step(q2, 2, st); }))) return rc;
+                // (a pooled block whose tail is not the fused kernel — the long utterances of layers 1 - 3: conv2 pools on its way out)
+                pooled_by_conv = K.downsample && !tail_fused && T >= 3 && !h->opt.rn_pool_off && rn_step_supported(q2, 3);
+                if ((rc = run(h, "rn_step", (double)M * K.conv2.flops_per_row, [&]() { return launch_rn_step(q2, pooled_by_conv ? 3 : 2, st); }))) return rc;
                 goto convs_done;
             }
             if (pre_is_s32) SV_FAIL(h, SVHIP_ERR_STATE, "RawNet2 block %d: the split convolution kernel refused a shape its producer was told it takes", bi);
@@ -1422,7 +1426,9 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
             T = Tn;
         } else {
             void* y = o;
-            if (K.downsample) {                                                          // :228-229
+            if (K.downsample && pooled_by_conv) {                                        // (F32X3: conv2 pooled on its way out, into o)
+                T /= 3;
+            } else if (K.downsample) {                                                   // :228-229
                 if ((rc = run(h, "rn_maxpool3", 0, [&]() { return launch_rn_maxpool3(o, hb, dt, B, T, K.cout, st); }))) return rc;
                 T /= 3;
                 y = hb;
@@ -1564,7 +1570,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2346,7 +2352,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
         {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
-        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"n128_off", &o.n128_off}};
+        {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;

@@ -27,7 +27,9 @@ constexpr int RS_LDS = 4 * RS_HT;                  // {X, W} x two K tiles = 64 
 
 // MODE 0: the Res2Net step above.  MODE 1 / 2 (round 4, late): RawNet2's 128 -> 128 convolutions on F32X3 handles (models/RawNet_baseline.py
 // :224-227) — zero padding (rows outside the utterance read a zero page), no bias; 1 = conv1: BN -> LeakyReLU(0.3), output in the S32 layout
-// (conv2's operand); 2 = conv2: no activation, fp32 output = acc + R (the identity shortcut x, fp32) through the same 64 KiB row image.
+// (conv2's operand); 2 = conv2: no activation, fp32 output = acc + R (the identity shortcut x, fp32) through the same 64 KiB row image;
+// 3 = 2 followed by max_pool1d(3) (:228-229): tiles of 126 frames inside ONE utterance (42 pooled frames; the last two MFMA rows are idle),
+// the pooled rows leave from the image — the un-pooled conv2 output (1.4 GB for layer1 at B = 256) is never written or read back.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -35,8 +37,13 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;        // rows wm * 64 .. + 63, channels wn * 64 .. + 63
     const int r16 = lane & 15, q4 = lane >> 4;
-    const int m0 = blockIdx.x * RS_TILE;
-    const int n0 = MODE == 0 ? 0 : (int)blockIdx.y * RS_TILE;      // (modes 1 / 2: N may be several tiles of 128 channels)
+    const int n0 = MODE == 0 ? 0 : (int)blockIdx.y * RS_TILE;      // (modes 1 - 3: N may be several tiles of 128 channels)
+    // mode 3: workgroup = (utterance bu, tile of 126 frames starting at t0): its rows never cross an utterance
+    constexpr int PT = 126;
+    const int tiles_u = MODE == 3 ? (3 * (p.T / 3) + PT - 1) / PT : 1;
+    const int bu = MODE == 3 ? (int)blockIdx.x / tiles_u : 0;
+    const int t0 = MODE == 3 ? ((int)blockIdx.x - bu * tiles_u) * PT : 0;
+    const int m0 = MODE == 3 ? bu * p.T + t0 : (int)blockIdx.x * RS_TILE;
 
     // ---- operand DMA addressing: thread -> four (row, 16-byte slot) items of a 128 x 128-byte half-buffer; the swizzle
     //      (slot ^ (row >> 1 & 7)) goes on the source chunk ----
@@ -49,9 +56,9 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         const int pidx = q * 256 + tid;
         const int row = pidx >> 3, slot = pidx & 7;
         const int c = slot ^ ((row >> 1) & 7);
-        const int m = min(m0 + row, p.M - 1);
+        const int m = MODE == 3 ? bu * p.T + min(t0 + row, p.T - 1) : min(m0 + row, p.M - 1);
         xm[q] = m;
-        xt[q] = m % p.T;
+        xt[q] = MODE == 3 ? (t0 + row < p.T ? t0 + row : -(1 << 20)) : m % p.T;      // (mode 3: rows past the utterance read the zero page)
         xc[q] = (uint32_t)c * 16u;
         wo[q] = (uint32_t)(n0 + row) * (uint32_t)p.Kp * 4u + (uint32_t)c * 16u;     // weight row = output channel n0 + row (< 2^32 bytes: host check)
     }
@@ -166,14 +173,14 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
         copy_out(reinterpret_cast<char*>(p.Y) + (int64_t)n0 * 4, (int64_t)p.ldy * 4);      // (128 channels = four S32 blocks = 512 bytes, like 128 floats)
         return;
     }
-    if (MODE == 2) {                                // out = acc (+ R), fp32, through the row image
+    if (MODE == 2 || MODE == 3) {                   // out = acc (+ R), fp32, through the row image (mode 3: pooled on the way out)
         if (Cn) {
 #pragma unroll 4
             for (int q = 0; q < 16; ++q) {
                 const int pidx = q * 256 + tid;
                 const int row = pidx >> 5, pos = pidx & 31;
                 const int cs = (pos & ~7) | ((pos ^ row) & 7);
-                const int m = min(m0 + row, p.M - 1);
+                const int m = MODE == 3 ? bu * p.T + min(t0 + row, p.T - 1) : min(m0 + row, p.M - 1);
                 __builtin_amdgcn_global_load_lds((gbl_void*)(Cn + (int64_t)m * p.ldr + n0 + (cs << 2)), (lds_void*)(smem + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,6 +195,29 @@ __global__ __launch_bounds__(256, 2) void r2_step_kernel(GemmParams p) {
                 *slot = Cn ? acc[i][j] + *slot : acc[i][j];
             }
         lds_barrier();
+        if (MODE == 3) {
+            // pooled frame pr0 + prow of the utterance = max over image rows 3 prow .. + 2; 42 rows x 32 chunks of 16 bytes
+            const int Tp = p.T / 3, pr0 = t0 / 3;
+            float* yb = reinterpret_cast<float*>(p.Y) + n0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int pidx = q * 256 + tid;
+                const int prow = pidx >> 5, ch = pidx & 31;
+                if (prow < PT / 3 && pr0 + prow < Tp) {
+                    f32x4 v[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int row = 3 * prow + u;
+                        v[u] = *reinterpret_cast<const f32x4*>(smem + row * 512 + (ch & ~7) * 16 + (((ch & 7) ^ (row & 7)) << 4));
+                    }
+                    f32x4 m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v[0][e], v[1][e]), v[2][e]);
+                    *reinterpret_cast<f32x4*>(yb + ((int64_t)bu * Tp + pr0 + prow) * p.ldy + ch * 4) = m;
+                }
+            }
+            return;
+        }
         copy_out(reinterpret_cast<char*>(p.Y) + (int64_t)n0 * 4, (int64_t)p.ldy * 4);
         return;
     }
@@ -271,6 +301,7 @@ hipError_t launch_r2_step(const GemmParams& p, hipStream_t stream) {
 // 32, N of 128): A (M, lda) and W (N, taps cin) in the S32 layout, zero_page >= 128 bytes of zeros, no bias.  mode 1: Y = lrelu0.3(BN(conv)) in
 // S32 (row stride ldy elements); mode 2: Y = conv (+ R) in fp32.  Grid (M tiles, N tiles of 128 channels).
 bool rn_step_supported(const GemmParams& p, int mode) {
+    if (mode == 3) { if (p.taps != 3 || p.T < 3) return false; mode = 2; }          // (pooled conv2: the contract of mode 2; Y holds (M / T) * (T / 3) rows)
     if (!(mode == 1 || mode == 2) || p.x3 != 2 || !(p.taps == 3 || p.taps == 1) || p.A2 || p.A3 || p.bias_utt || p.colsum || p.bias) return false;
     if (p.cin < 32 || p.cin % 32 != 0 || p.N < 128 || p.N % 128 != 0 || p.K != p.taps * p.cin || p.Kp != p.K || p.Wrows < p.N || p.pad_mode != PAD_ZERO || !p.zero_page) return false;
     if ((int64_t)p.Wrows * p.Kp * 4 >= ((int64_t)1 << 32) || p.N / 128 > 65535) return false;
@@ -285,6 +316,15 @@ bool rn_step_supported(const GemmParams& p, int mode) {
 
 hipError_t launch_rn_step(const GemmParams& p, int mode, hipStream_t stream) {
     if (!rn_step_supported(p, mode)) return hipErrorInvalidValue;
+    if (mode == 3) {
+        const int tiles_u = (3 * (p.T / 3) + 125) / 126;
+        const int64_t gx = (int64_t)(p.M / p.T) * tiles_u;
+        if (gx >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+        static DeviceOnce attr3;
+        if (hipError_t e = set_max_dynamic_lds(attr3, reinterpret_cast<const void*>(r2_step_kernel<3>), RS_LDS)) return e;
+        hipLaunchKernelGGL(r2_step_kernel<3>, dim3((unsigned)gx, p.N / RS_TILE), dim3(256), RS_LDS, stream, p);
+        return hipGetLastError();
+    }
     const dim3 grid((p.M + RS_TILE - 1) / RS_TILE, p.N / RS_TILE);
     if (mode == 1) {
         static DeviceOnce attr1;

@@ -214,6 +214,17 @@ def test_f32x3_split_convolution_kernel_of_the_residual_blocks(L, B):
             # every convolution of the eight blocks (16 k = 3 convolutions + 2 projection shortcuts) on the split kernel, every pre-activation
             # written in the S32 layout by its producer: no conversion pass, no separate rn_bn_act, no tiled GEMM besides the attention head
             assert labels["rn_step"]["launches"] == 18 and "rn_bn_act" not in labels and "split_s32" not in labels and "gemm_conv" not in labels, sorted(labels)
+    # conv2 of the long pooled blocks pools on its way out (r2_step mode 3: tiles of 126 frames inside one utterance); option rn_pool_off
+    # writes the un-pooled output and lets rn_maxpool3 pool it: every row's products are summed in the same order -> the same bits
+    eng.set_option("rn_pool_off", 1)
+    eng.profile(True)
+    unpooled = eng.embed_wave(wav).reshape(B, -1).copy()
+    labels = eng.profile_results()
+    eng.profile(False)
+    eng.set_option("rn_pool_off", 0)
+    if L >= 16000:
+        assert "rn_maxpool3" in labels, sorted(labels)
+    np.testing.assert_array_equal(unpooled, res[0])
     eng.close()
     f32 = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=B, samples=L)
     f32.load_state_dict(sd)
