@@ -338,7 +338,7 @@ def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor
             assert np.abs(b[bi, t]).max() > 0
 
 
-@pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "f16", 50, 3),
+@pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "f16", 50, 3), ("rawnet2", "f32x3", 50, 3),
                                                    ("ecapa", "bf16", 64, 2), ("ecapa", "f32", 70, 2)])
 def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, lanes, monkeypatch):
     """SVHIP_LANES slices a batch over up to four streams (offsets into every per-utterance workspace buffer, lane
