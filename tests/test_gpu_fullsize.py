@@ -117,6 +117,33 @@ def test_rawnet2_full_batch_properties(big_rn):
     assert np.abs(a[:16] - ref).max() <= 0.03 * np.abs(ref).max()
 
 
+def test_rawnet2_f32x3_full_batch_properties(big_rn):
+    """The 1e-4 mode of RawNet2 at full size (B = 256: the split sinc kernel's persistent grid over 256 x 331 tiles, 21 166-tile launches of the
+    split convolution kernel, mode 3's 84 tiles of 126 frames per utterance): deterministic, rows independent of their place in the batch
+    (every reduction is per utterance in a fixed order: bit-identical under a permutation), 16 rows within 1e-4 of the exact-fp32 engine."""
+    _, sd, wav = big_rn
+    eng = Engine(model="rawnet2", compute="f32x3", embed_dim=320, max_batch=256)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    a = eng.embed_wave(wav)
+    assert a.shape == (256, 320) and np.isfinite(a).all()
+    assert np.array_equal(a, eng.embed_wave(wav))
+    perm = np.random.Generator(np.random.PCG64(12)).permutation(256)
+    shuffled = eng.embed_wave(wav[perm])
+    assert np.array_equal(shuffled, a[perm])
+    small = eng.embed_wave(wav[:8])
+    eng.close()
+    assert float(np.abs(small - a[:8]).max()) <= 1e-4 * float(np.abs(a).max())       # (B <= 64 takes the sliced tails: another summation order)
+    f32 = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=16)
+    f32.load_state_dict(sd)
+    f32.finalize()
+    ref = f32.embed_wave(wav[:16])
+    f32.close()
+    err = float(np.abs(a[:16] - ref).max() / np.abs(ref).max())
+    print("rawnet2 f32x3 B=256 vs f32: max err / scale", err)
+    assert err <= 1e-4
+
+
 def test_bench_shard_path_at_world_one(capsys):
     """`bench.py --config shard` (BASELINE configs[4]'s code path: utterances generated on the device, embedded in
     batches, ONE all-gather, row-sharded cosine + AS-norm scoring) was in no test.  2 000 utterances at world size 1: the record's
