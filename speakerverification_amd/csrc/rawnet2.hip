@@ -993,9 +993,15 @@ bool rn_tail_supported(int dt, int Tn, int C) {
 // slices per utterance of the small-batch form (0: one workgroup per utterance, rn_tail_kernel)
 int rn_tail_slices(int dt, int B, int Tn, int C, int num_cu) {
     const int vec = dt != DT_F32 ? 8 : 4;
-    if (B * 4 > num_cu || C % vec || C > 512 || C / vec < 32 || TAILS_THREADS % (C / vec)) return 0;
-    // the slice count depends on the utterance alone (about 48 frames per slice), never on the batch: an utterance's column mean is
-    // summed in the same order whatever batch (or batch slice: option lanes) it rides in
+    if (C % vec || C > 512 || C / vec < 32 || TAILS_THREADS % (C / vec)) return 0;
+    if (B * 4 > num_cu) {
+        // full batches: only the short utterances of the wide late blocks, where one workgroup per utterance streams 1 MiB of gate weights
+        // through its CU for a few KB of activations (16 frames per slice; the gate on the fp32 MFMA, rn_afms_gate_mfma)
+        if (C < 256 || Tn > 48) return 0;
+        return (Tn + 15) / 16;
+    }
+    // small batches: the slice count depends on the utterance alone (about 48 frames per slice), never on the batch: an utterance's column
+    // mean is summed in the same order whatever batch (or batch slice: option lanes) it rides in
     int S = (Tn + 47) / 48;
     if (S > TAILS_MAX_S) S = TAILS_MAX_S;
     return S >= 2 ? S : 0;

@@ -464,6 +464,57 @@ __global__ __launch_bounds__(256) void rn_afms_gate_kernel(const float* __restri
     if (b0 + u < B) s[(int64_t)(b0 + u) * C + n0 + n] = 1.0f / (1.0f + expf(-(acc + bias[n0 + n])));
 }
 
+// The same gate for full batches of wide blocks (B > 64, C = 256 / 512: the late block tails) on the exact fp32 MFMA: workgroup = 32 outputs x 32
+// utterances, its four waves split the C input channels, a lane's 16-byte load of the mean (summed from the partial rows on the fly) supplies
+// four MFMA steps and the matching weight rows are read with one coalesced 4-byte load each.  (The LDS-staged VALU kernel above: 28 us at
+// C = 512, B = 256; the one-workgroup-per-utterance tail streams the whole 1 MiB matrix through one CU per utterance: ~25 us.)
+__global__ __launch_bounds__(256) void rn_afms_gate_mfma_kernel(const float* __restrict__ part, int nparts, int B, int C, float inv_T,
+                                                                const float* __restrict__ WT, const float* __restrict__ bias,
+                                                                float* __restrict__ s) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int kper = C >> 2;                               // input channels per wave
+    const int kb = wave * kper + 4 * h;
+    const int b = min(b0 + r, B - 1);
+    const float* prow = part + (int64_t)b * nparts * C + kb;
+    const float* wcol = WT + (int64_t)kb * C + n0 + r;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int j = 0; j < kper / 8; ++j) {                  // groups of 8 input channels: this lane's four are 8 j + 4 h + e
+        f32x4 m = *reinterpret_cast<const f32x4*>(prow + 8 * j);
+        for (int t = 1; t < nparts; ++t) m += *reinterpret_cast<const f32x4*>(prow + (int64_t)t * C + 8 * j);
+        m *= inv_T;
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = wcol[(int64_t)(8 * j + e) * C];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], m[e], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave == 0 && b0 + r < B) {
+        // acc[e]: output n0 + (e & 3) + 8 (e >> 2) + 4 h of utterance b0 + r
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + 8 * g + 4 * h;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+            f32x4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = ((acc[4 * g + u] + red[0][4 * g + u][lane]) + red[1][4 * g + u][lane]) + red[2][4 * g + u][lane] + bv[u];
+                v[u] = 1.0f / (1.0f + expf(-a));
+            }
+            *reinterpret_cast<f32x4*>(s + (int64_t)(b0 + r) * C + n) = v;
+        }
+    }
+}
+
 }  // namespace
 
 int rn_block128_ntiles(int T) { return (3 * (T / 3) + RB_TT - 1) / RB_TT; }
@@ -510,6 +561,10 @@ hipError_t launch_rn_block128(const RnBlock128Params& p_in, int num_cu, hipStrea
 hipError_t launch_rn_afms_gate(const float* part, int nparts, int B, int C, int Tn, const float* WT, const float* bias, float* s,
                                hipStream_t stream) {
     if (!part || !WT || !bias || !s || C > 512 || C % 64 != 0 || nparts <= 0 || Tn <= 0 || B <= 0) return hipErrorInvalidValue;
+    if (B > 64 && C >= 256 && C % 32 == 0 && nparts <= 16 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        hipLaunchKernelGGL(rn_afms_gate_mfma_kernel, dim3(C / 32, (B + 31) / 32), dim3(256), 0, stream, part, nparts, B, C, 1.0f / (float)Tn, WT, bias, s);
+        return hipGetLastError();
+    }
     if (B <= 64) {
         const size_t lds = (size_t)C * (GATE_N + 4) * sizeof(float);
         hipLaunchKernelGGL(rn_afms_gate_kernel<4>, dim3(C / GATE_N, (B + 3) / 4), dim3(256), lds, stream, part, nparts, B, C, 1.0f / (float)Tn, WT, bias, s);
