@@ -299,12 +299,15 @@ hipError_t launch_cw(const Res2Params& p, int grid, hipStream_t stream) {
 int res2net_chain_slices(int B, int C, int T, int dil, int num_cu) {
     const int cw = C / 8;
     const int tmax_s = cw == 128 ? R2Cfg<128, 3>::TMAX : R2Cfg<64, 2>::TMAX;
-    for (int S = 2; S <= 8; ++S) {
+    // the LARGEST slice count whose workgroups still fit the chip at once and whose core is longer than its halo: a slice's rows (core + 14 dil
+    // of halo) set the launch's length (B = 20: 3 slices 178 us for the three launches, 5 - 7 slices 158 - 160; outputs bit-identical for any count)
+    int best = 1;
+    for (int S = 2; S <= 7; ++S) {
         const int tc = (T + S - 1) / S;
         if ((int64_t)S * B > (int64_t)num_cu) break;
-        if (tc + 14 * dil <= tmax_s && tc > 14 * dil) return S;
+        if (tc + 14 * dil <= tmax_s && tc > 14 * dil) best = S;
     }
-    return 1;
+    return best;
 }
 
 bool res2net_chain_supported(int C, int T, int dil, int Kp) {
