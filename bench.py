@@ -67,7 +67,94 @@ def parse():
                     help="N > 1: if the RCCL communicator cannot be created, carry the all-gather over gloo (host round trip) instead of "
                          "failing; the record then says so.  Without this flag a multi-GPU run that is not on RCCL exits non-zero.")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the extra back-to-back run reported as `sustained` (0: skip)")
+    ap.add_argument("--record-file", default=None,
+                    help="JSON-lines file that receives every sub-record and the full (verbose) headline record; default "
+                         "gpurun_out/bench_records.jsonl when gpurun_out/ exists, otherwise none.  stdout carries ONE compact line.")
     return ap.parse_args()
+
+
+HEADLINE_MAX_BYTES = 4096
+
+
+class Records:
+    """Where the detail goes.  stdout carries exactly ONE JSON line, the compact headline (<= HEADLINE_MAX_BYTES: the driver keeps
+    a bounded tail of stdout, and round 4's 20 KB line did not parse).  Every sub-record (`rawnet2`, `latency`, `scoring`, per-kernel
+    tables ...) is written as its own JSON line, tagged {"record": name}, to stderr as it is measured and to --record-file."""
+
+    def __init__(self, path=None):
+        if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            path = os.path.join(ROOT, "gpurun_out", "bench_records.jsonl")
+        self.path = path
+        self.f = None
+        if path:
+            try:
+                self.f = open(path, "w")
+            except OSError:
+                self.f = None
+
+    def emit(self, name, rec):
+        text = json.dumps({"record": name, **(rec if isinstance(rec, dict) else {"value": rec})})
+        print(text, file=sys.stderr, flush=True)
+        if self.f:
+            self.f.write(text + "\n")
+            self.f.flush()
+
+    def close(self):
+        if self.f:
+            self.f.close()
+            self.f = None
+
+
+def _num(x, nd=4):
+    """floats of the compact line: 6 significant digits are more than any of these measurements carry"""
+    if isinstance(x, float):
+        return float(f"{x:.6g}")
+    return x
+
+
+def compact_headline(full, sub=None, scoring=None):
+    """The ONE stdout line: the contract's fields, the roofline and cpu_baseline objects, the verification verdict, the sustained
+    figure, a flat `sub` map {name: embeddings/s} and a scoring summary.  Everything else lives in the records (see Records)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: _num(full[k]) for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "batch_per_gpu", "utterances_per_gpu", "batch", "collective") if k in cfg}
+    r = full.get("roofline")
+    if r:
+        line["roofline"] = {k: _num(r.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                          "flops_per_launch", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches")
+                            if k in r}
+    c = full.get("cpu_baseline")
+    line["cpu_baseline"] = ({k: _num(c.get(k)) for k in ("value", "unit", "cores", "kind", "cpu", "sample")} if c else None)
+    chk = full.get("check")
+    if chk:
+        line["check"] = {k: _num(chk.get(k)) for k in ("ok", "bitwise_rerun", "finite", "min_cosine_vs_f32_path", "max_err_over_scale")
+                         if k in chk}
+    if full.get("sustained"):
+        line["sustained"] = {k: _num(full["sustained"][k]) for k in ("value", "ms_per_step", "steps", "seconds")}
+    if "whole_path_TFLOPs" in full:
+        line["whole_path_TFLOPs"] = _num(full["whole_path_TFLOPs"])
+    sh = full.get("shard")
+    if sh:
+        line["shard"] = {k: _num(sh.get(k)) for k in ("allgather_ms", "allgather_carrier", "rccl_world", "gathered_rows",
+                                                       "blocks_bitwise_ok", "cross_rank_ok", "own_block_intact",
+                                                       "cosine_trials_per_s", "asnorm_trials_per_s") if k in sh}
+    for k in ("embed_seconds", "end_to_end_seconds"):
+        if k in full:
+            line[k] = _num(full[k])
+    if sub:
+        line["sub"] = {k: _num(v) for k, v in sub.items()}
+    if scoring:
+        line["scoring"] = {k: _num(v) for k, v in scoring.items()}
+    text = json.dumps(line)
+    if len(text) > HEADLINE_MAX_BYTES:            # never let the headline outgrow the driver's tail: drop the optional parts first
+        for k in ("sub", "shard", "sustained", "scoring", "check"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) <= HEADLINE_MAX_BYTES:
+                break
+    return text
 
 
 class quiet_stdout:
@@ -313,7 +400,8 @@ def roofline_of(prof, label, compute):
         except Exception:
             traffic = None
     return {"kernel": label, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": dom["launches"]}
+            "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+            "flops_per_launch": dom["flops"] / max(1, dom["launches"])}
 
 
 def embed_loop(eng, wavs, K, W, B, shard, label, barrier=lambda: None):
@@ -859,6 +947,7 @@ def run_batch(args, ranks, dev):
     kern = kernel_table(eng, wavs, B, n_all, dev) if rank == 0 else {}
 
     if rank == 0:
+        recs = Records(getattr(args, "record_file", None))
         total_utts = world * K * B
         line = {
             "metric": "embeddings/sec (2 s @16 kHz)", "value": total_utts / dt, "unit": "embeddings/s",
@@ -876,23 +965,33 @@ def run_batch(args, ranks, dev):
             "whole_path_TFLOPs": eng.flops_per_utterance * total_utts / dt / 1e12,
             "flops_per_utterance": eng.flops_per_utterance,
             "roofline": roofline_of(prof, label, args.compute),
-            "kernels": kern,
-            "kernels_note": "per-kernel table from a separate profiled pass of %d steps (every launch bracketed); "
-                            "the roofline kernel is timed live inside the timed region" % n_all,
         }
+        recs.emit("kernels", {"kernels": kern,
+                              "note": "per-kernel table from a separate profiled pass of %d steps (every launch bracketed); "
+                                      "the roofline kernel is timed live inside the timed region" % n_all})
         if shard_rec is not None:
             line["shard"] = shard_rec
         line["sustained"] = sustained
         line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu_baseline and args.model == "ecapa") else None
+        sub, scoring = {}, None
         if world == 1 and not args.no_scoring and args.model == "ecapa":
             try:
-                line["scoring"] = scoring_bench(dev, with_cpu=not args.no_cpu_baseline)
-                if not args.no_extras:   # same workload with the score GEMMs as split-bf16 MFMA triples (exact fp32 stays the default)
+                sc = scoring_bench(dev, with_cpu=not args.no_cpu_baseline)
+                recs.emit("scoring", sc)
+                scoring = {"cosine_pairs_per_s": sc["cosine_pairs_per_s"], "cosine_frac_of_hbm_peak": sc["cosine_pairs_frac_of_hbm_peak"],
+                           "asnorm_pairs_per_s": sc["asnorm_pairs_per_s"], "asnorm_stats_ms": sc["asnorm_stats_s"] * 1e3,
+                           "asnorm_frac": sc["asnorm_frac_of_split_ceiling"], "dense_pairs_per_s": sc["dense_pairs_per_s"],
+                           "dense_frac": sc["dense_frac_of_split_ceiling"], "workload": "configs[3]: 1.2 M x 192, cohort 5994, top 200"}
+                if sc.get("cpu_baseline"):
+                    scoring["cpu_asnorm_loop_trials_per_s"] = sc["cpu_baseline"].get("asnorm_per_trial_loop_trials_per_s")
+                    scoring["cpu_cosine_numpy_trials_per_s"] = sc["cpu_baseline"].get("cosine_numpy_batched_trials_per_s")
+                if not args.no_extras:   # same workload on an f32x3 handle
                     x3 = scoring_bench(dev, with_cpu=False, compute="f32x3")
-                    line["scoring_f32x3"] = {k: x3[k] for k in ("asnorm_pairs_per_s", "asnorm_stats_s", "asnorm_cohort_gemm_TFLOPs",
-                                                                 "dense_pairs_per_s", "dense_TFLOPs", "config")}
+                    recs.emit("scoring_f32x3", {k: x3[k] for k in ("asnorm_pairs_per_s", "asnorm_stats_s", "asnorm_cohort_gemm_TFLOPs",
+                                                                     "dense_pairs_per_s", "dense_TFLOPs", "config")})
             except Exception as e:  # scoring is reported next to, not inside, the headline
-                line["scoring"] = {"error": repr(e)}
+                recs.emit("scoring", {"error": repr(e)})
+                scoring = {"error": repr(e)[:200]}
         if world == 1 and not args.no_extras and args.model == "ecapa" and args.compute == "bf16":
             for name, fn in (("rawnet2", lambda: sub_bench("rawnet2", "f16", B, local, dev, wavs)),
                              ("rawnet2_3_streams", lambda: multi_stream_bench("rawnet2", "f16", B, local, dev, wavs)),
@@ -904,10 +1003,30 @@ def run_batch(args, ranks, dev):
                              ("fusion", lambda: fusion_bench(B, local, dev, wavs)),
                              ("pcie", lambda: pcie_bench(eng, dev, B))):
                 try:
-                    line[name] = fn()
+                    rec = fn()
                 except Exception as e:
-                    line[name] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+                    rec = {"error": repr(e)}
+                recs.emit(name, rec)
+                if "error" in rec:
+                    sub[name] = "error"
+                elif name == "latency":
+                    for mode, rows in rec.items():
+                        if isinstance(rows, dict) and "20" in rows:
+                            sub[f"latency_{mode}_B20_ms"] = rows["20"]["ms_per_call_pipelined"]
+                            if "10" in rows:
+                                sub[f"latency_{mode}_B10_ms"] = rows["10"]["ms_per_call_pipelined"]
+                    if "bf16" in rec and "20" in rec["bf16"]:
+                        sub["latency_bf16_B20_frac_of_B256_rate"] = rec["bf16"]["20"].get("fraction_of_B256_rate")
+                elif name == "fusion":
+                    sub["fusion_serial"], sub["fusion_two_streams"] = rec["serial"]["value"], rec["two_streams"]["value"]
+                else:
+                    sub[name] = rec["value"]
+                    if isinstance(rec.get("check"), dict) and not rec["check"].get("ok", True):
+                        sub[name + "_check"] = "FAILED"
+        recs.emit("headline_full", line)
+        recs.close()
+        sys.stderr.flush()
+        print(compact_headline(line, sub=sub, scoring=scoring), flush=True)
     eng.close()
 
 
@@ -971,7 +1090,11 @@ def run_shard(args, ranks, dev, keep=False):
                 "roofline": roofline_of(prof, label, args.compute), "shard": rec,
                 "end_to_end_seconds": dt + rec["allgather_ms"] * 1e-3 + rec.get("cosine_s", 0.0) + rec.get("asnorm_s", 0.0),
                 "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
+        recs = Records(getattr(args, "record_file", None))
+        recs.emit("headline_full", line)
+        recs.close()
+        sys.stderr.flush()
+        print(compact_headline(line), flush=True)
     eng.close()
     return (line, shard) if keep else None           # (tests/test_gpu_fullsize.py checks the record and the embeddings themselves)
 

@@ -1,6 +1,7 @@
 """GPU: the headline configuration at full size (BASELINE configs[1]: ECAPA-TDNN C = 1024, bf16, 256 utterances of 2 s)
 through size-independent properties — the oracle cannot run 256 utterances in seconds — and the C ABI's error behaviour."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -173,6 +174,32 @@ def test_bench_shard_path_at_world_one(capsys):
     f32.close()
     assert cos_rows(emb, ref).min() >= 0.999
     assert np.abs(emb - ref).max() <= 0.03 * np.abs(ref).max()
+
+
+def test_bench_stdout_is_one_compact_json_line(tmp_path):
+    """`python bench.py` as the driver runs it (a child process): stdout is exactly ONE line, <= 4 KB, that
+    json.loads and carries the contract's fields, `roofline` and (with the CPU leg on) `cpu_baseline`; the sub-records went to the
+    record file.  Short legs only (2 steps, no extras / scoring / CPU leg) — the full default run is the driver's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rf = tmp_path / "records.jsonl"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--no-scoring",
+                        "--no-cpu-baseline", "--sustain-seconds", "0", "--record-file", str(rf)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out_lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and len(out_lines[0]) <= 4096
+    line = json.loads(out_lines[0])
+    assert line["metric"].startswith("embeddings/sec") and line["steps"] == 2 and line["warmup"] == 1 and line["n_gpus"] == 1
+    assert line["dtype"] == "bf16" and "configs[1]" in line["config"]["workload"] and line["value"] > 0
+    assert abs(line["value"] - 256 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-3 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["kernel"] == "gemm_pw3" and r["launches"] == 14 and 0 < r["frac"] < 1 and r["peak"] == 2500.0
+    assert line["check"]["ok"] and line["cpu_baseline"] is None
+    recs = [json.loads(ln) for ln in open(rf)]
+    assert [x["record"] for x in recs] == ["kernels", "headline_full"] and "gemm_pw3" in recs[0]["kernels"]
 
 
 def test_c_abi_error_behaviour():

@@ -399,3 +399,48 @@ def test_bench_cross_rank_verification_at_world_three(corrupt):
         assert [recs[r]["blocks_bitwise_ok"] for r in range(3)] == [True, False, True]
     if corrupt == "content":
         assert all(recs[r]["blocks_bitwise_ok"] for r in range(3)) and recs[0]["cross_rank_min_cosine"] < 0.9
+
+
+def test_bench_headline_is_one_compact_parsable_line(tmp_path, capsys):
+    """round 4's ONE 20 KB stdout line outgrew the driver's stdout tail and `BENCH_r04.parsed` was null.  The
+    headline is now built by bench.compact_headline: <= 4 KB whatever the sub-records hold, json-parsable, carrying the contract's
+    fields + roofline + cpu_baseline; the detail goes to bench.Records (stderr + a JSON-lines file), never to stdout."""
+    import json
+    import bench
+    big = {"kernels": {f"kernel_{i}": {"avg_ms": 0.1 * i, "launches_per_step": 3.0, "ms_per_step": 0.3 * i, "TFLOPs": None} for i in range(60)}}
+    full = {"metric": "embeddings/sec (2 s @16 kHz)", "value": 58023.21234567, "unit": "embeddings/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 4.41203123, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ECAPA-TDNN C=1024 ... (BASELINE configs[1])", "batch_per_gpu": 256, "samples": 32000, "collective": "none"},
+            "check": {"ok": True, "bitwise_rerun": True, "finite": True, "min_cosine_vs_f32_path": 0.9999, "max_err_over_scale": 0.011,
+                      "bars": {"min_cosine": 0.999}},
+            "roofline": {"kernel": "gemm_pw3", "bound": "mfma", "achieved": 1098.4, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.43936,
+                         "traffic": 1.0256e9, "traffic_source": "x" * 300, "avg_launch_ms": 0.42, "launches": 140, "flops_per_launch": 4.6e11},
+            "cpu_baseline": {"value": 25.9, "unit": "embeddings/s", "cores": 16, "kind": "port", "cpu": "EPYC", "sample": "s" * 200,
+                             "B8": {"pass_s": [1.0] * 9}, "B256": {"pass_s": [9.0] * 3}},
+            "sustained": {"value": 58903.5, "ms_per_step": 4.346, "steps": 454, "seconds": 1.97, "unit": "embeddings/s"},
+            "whole_path_TFLOPs": 872.4, **big}
+    sub = {f"mode_{i}": 1234.5678 * i for i in range(12)}
+    text = bench.compact_headline(full, sub=sub, scoring={"cosine_pairs_per_s": 4.0e9, "asnorm_pairs_per_s": 1.1e8, "asnorm_frac": 0.31})
+    assert "\n" not in text and len(text) <= bench.HEADLINE_MAX_BYTES
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in line
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["config"]["workload"].startswith("ECAPA")
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches")) <= set(line["roofline"])
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert "kernels" not in line and "traffic_source" not in line["roofline"] and "B8" not in line["cpu_baseline"]
+    assert line["sub"]["mode_3"] == pytest.approx(3703.7, rel=1e-4) and line["scoring"]["asnorm_frac"] == 0.31
+    # a pathological sub map cannot push the line past the bound: optional parts are dropped, the contract's fields stay
+    text = bench.compact_headline(full, sub={f"k{i}": "x" * 50 for i in range(200)})
+    assert len(text) <= bench.HEADLINE_MAX_BYTES and "roofline" in json.loads(text) and "sub" not in json.loads(text)
+    # Records: tagged JSON lines to stderr and to the file, nothing on stdout
+    recs = bench.Records(str(tmp_path / "r.jsonl"))
+    recs.emit("kernels", big)
+    recs.emit("rawnet2", {"value": 1.0})
+    recs.close()
+    cap = capsys.readouterr()
+    assert cap.out == ""
+    lines = [json.loads(ln) for ln in open(tmp_path / "r.jsonl")]
+    assert [ln["record"] for ln in lines] == ["kernels", "rawnet2"] and len(lines[0]["kernels"]) == 60
+    assert [json.loads(ln)["record"] for ln in cap.err.strip().splitlines()] == ["kernels", "rawnet2"]
