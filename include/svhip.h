@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SVHIP_ABI_VERSION 3
+#define SVHIP_ABI_VERSION 4
 
 typedef struct svhip_handle svhip_handle;
 
@@ -39,7 +39,11 @@ typedef enum svhip_status {
     SVHIP_ERR_STATE = -3,       /* call order violated (e.g. embed before finalize) */
     SVHIP_ERR_NOMEM = -4,
     SVHIP_ERR_UNSUPPORTED = -5,
-    SVHIP_ERR_MISSING = -6      /* a required weight tensor was never loaded */
+    SVHIP_ERR_MISSING = -6,     /* a required weight tensor was never loaded */
+    SVHIP_ERR_NONFINITE = -7,   /* the call completed and wrote its embeddings, but some of them are inf / NaN: an fp16 activation
+                                   overflowed (SVHIP_F16 stores activations as IEEE half: 65504), or the input was not finite */
+    SVHIP_ERR_RANGE = -8        /* the call completed, but input values left the range the handle's arithmetic represents (SVHIP_F32X3:
+                                   operands travel as IEEE-half hi | lo planes, |x| <= 65504) and were clamped */
 } svhip_status;
 
 enum { SVHIP_MODEL_ECAPA = 0, SVHIP_MODEL_RAWNET2 = 1, SVHIP_MODEL_NONE = 2 /* fbank + scoring only */ };
@@ -50,8 +54,12 @@ typedef struct svhip_config {
     int32_t struct_size;    /* = sizeof(svhip_config), for ABI evolution */
     int32_t model;          /* SVHIP_MODEL_* */
     int32_t compute;        /* SVHIP_F32: fp32 MFMA, 1e-4 parity path; SVHIP_BF16: bf16 MFMA, fp32 accumulate;
-                               SVHIP_F32X3: fp32 storage and arithmetic everywhere except the k = 1 / k = 5 convolution GEMMs, whose
-                               products are three bf16 MFMAs on hi / lo-split fp32 operands (~2^-17 per product): 1e-4 parity, ~2x faster;
+                               SVHIP_F32X3: fp32 storage and arithmetic everywhere except the convolution GEMMs, whose products are three
+                               fp16 MFMAs on operands split into IEEE-half hi | lo parts (11 + 11 significant bits: 2^-23 relative while
+                               |x| >= 2^-3, at most 2^-25 absolute below that): 1e-4 parity at ~3x the fp32 speed.  RANGE CONTRACT: an operand
+                               of such a GEMM must satisfy |x| <= 65504 (hi saturates there; lo carries the remainder up to ~1.3e5, beyond
+                               that the value is clamped).  Activations behind a BatchNorm are O(10); the network INPUT is checked on every
+                               call (SVHIP_ERR_RANGE), the embeddings are checked for inf / NaN on every call (SVHIP_ERR_NONFINITE);
                                SVHIP_F16 (RawNet2 handles only): fp16 storage + fp16 MFMA, fp32 accumulate — the same speed as bf16 with
                                three more mantissa bits (RawNet2's un-normalised residual stack loses two digits to bf16 WEIGHT rounding);
                                an fp16 value overflows at 65504: the input is LayerNorm'ed, so only the weights decide the activation scale */
@@ -83,7 +91,12 @@ int  svhip_abi_version(void);
 int svhip_create(const svhip_config* cfg, svhip_handle** out);
 int svhip_destroy(svhip_handle* h);
 const char* svhip_last_error(const svhip_handle* h);   /* h may be NULL: last create() error */
-int svhip_synchronize(svhip_handle* h);
+int svhip_synchronize(svhip_handle* h);      /* also reports (and clears) the numeric status of the asynchronous calls it waited for */
+/* Numeric status of the forwards since the last reset.  Every forward checks (a) its embeddings for inf / NaN (in the kernel that writes
+ * them out) and (b), on SVHIP_F32X3 handles, its input features against the split planes' range.  A synchronous call returns
+ * SVHIP_ERR_NONFINITE / SVHIP_ERR_RANGE itself (after writing its outputs); after SVHIP_ASYNC calls ask here (waits for the stream) or
+ * call svhip_synchronize.  reset != 0 clears the status.  Returns SVHIP_OK, SVHIP_ERR_NONFINITE or SVHIP_ERR_RANGE (message: last_error). */
+int svhip_numeric_status(svhip_handle* h, int32_t reset);
 
 /* Weights.  Replaces: ModelHandling.loadParameters' name-matched state_dict copy
  * (src/model.py:718-746).  `name` is the reference state_dict key of the __S__ module (e.g.
@@ -158,6 +171,11 @@ enum { SVHIP_TRIAL_COSINE = 0, SVHIP_TRIAL_PNORM = 1, SVHIP_TRIAL_PDIST = 2 };
 int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_files, int32_t n_crops, int32_t D,
                        const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags);
 int svhip_mean_crops(svhip_handle* h, const float* F, int64_t n_files, int32_t n_crops, int32_t D, float* out, int32_t flags);
+/* SVHIP_TRIAL_PNORM with the reference's `p` argument (pnorm_similarity(ref, com, p), utils.py:167-169 -> F.pairwise_distance(p=p, eps=1e-6)):
+ * out[t] = mean_i || F[a, i] - F[b, i] + 1e-6 ||_p; p = +-inf: max / min |d|, p = 0: the count of non-zero d, otherwise (sum |d|^p)^(1/p).
+ * p = 2 is svhip_score_trials(SVHIP_TRIAL_PNORM). */
+int svhip_score_trials_pnorm(svhip_handle* h, float p, const float* F, int64_t n_files, int32_t n_crops, int32_t D,
+                             const int32_t* ia, const int32_t* ib, int64_t P, float* out, int32_t flags);
 
 /* Verification metrics over a scored trial list: the sort-and-accumulate core of the reference's
  * evaluation tail, which it runs as Python list sorts and loops (src/utils.py:221-275) and sklearn calls (utils.py:74-121).

@@ -181,6 +181,25 @@ def golden_scoring(ref):
                         pnorm=np.array(pn, np.float64))
 
 
+def golden_pnorm_p(ref):
+    """pnorm_similarity's `p` argument (src/utils.py:167-169: F.pairwise_distance(ref, com, p=p, eps=1e-06)) at values other than the 2
+    the reference's own call site passes (model.py:446): what svhip_score_trials_pnorm has to reproduce."""
+    rng = np.random.Generator(np.random.PCG64(47))
+    n_trials, n_crop, dim = 12, 4, 192
+    R = rng.standard_normal((n_trials, n_crop, dim)).astype(np.float32)
+    Cm = (0.5 * R + 0.9 * rng.standard_normal((n_trials, n_crop, dim))).astype(np.float32)
+    R[3, 1, :17] = 0.0
+    Cm[3, 1, :17] = np.float32(1e-6)          # 17 differences that cancel the eps exactly: p = 0 counts the non-zeros, p < 0 divides by zero
+    ps = [1.0, 3.0, 0.5, 1.5, float("inf"), float("-inf"), 0.0, -2.0]
+    out = np.zeros((len(ps), n_trials), np.float64)
+    for k, pv in enumerate(ps):
+        for i in range(n_trials):
+            r, c = torch.from_numpy(R[i]), torch.from_numpy(Cm[i])
+            out[k, i] = ref.utils.similarity_measure("pnorm", r, c, p=pv)
+            assert abs(o_scoring.pnorm_similarity(r, c, p=pv) - out[k, i]) <= 1e-7 * max(1.0, abs(out[k, i]))
+    np.savez_compressed(os.path.join(GOLD, "pnorm_p.npz"), R=R, C=Cm, p=np.array(ps, np.float64), pnorm=out)
+
+
 from tests.metrics_data import metrics_case  # noqa: E402  (seeded trial lists shared with the tests)
 
 
@@ -424,9 +443,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
+    if "--only-pnorm-p" in sys.argv:        # (round 5: the one fixture added since the others were frozen)
+        golden_pnorm_p(ref)
+        return
     specs = {}
     golden_preemph(ref)
     golden_scoring(ref)
+    golden_pnorm_p(ref)
     golden_metrics(ref)
     try:
         golden_crop()

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVHIP_LIB_PATH") or os.path.join(HERE, "libsvhip.so")     # (override: developer A/B of two builds)
 
 OK = 0
+ERR_NONFINITE, ERR_RANGE = -7, -8          # the call completed and wrote its outputs; they are numerically suspect (include/svhip.h)
 MODEL_ECAPA, MODEL_RAWNET2, MODEL_NONE = 0, 1, 2
 F32, BF16, I64, F32X3, F16 = 0, 1, 2, 3, 4
 IN_DEVICE, OUT_DEVICE, ASYNC = 1, 2, 4
@@ -28,6 +29,11 @@ class SvhipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"svhip error {code}: {msg}")
         self.code = code
+
+
+class SvhipNumericError(SvhipError):
+    """SVHIP_ERR_NONFINITE / SVHIP_ERR_RANGE: the call completed and wrote its outputs, but they are numerically suspect (an fp16
+    activation overflowed, the input left the range of an f32x3 handle's half-precision planes, the input was not finite)."""
 
 
 class Config(C.Structure):
@@ -50,6 +56,7 @@ _SIGNATURES = {
     "svhip_destroy": (C.c_int, [_P]),
     "svhip_last_error": (C.c_char_p, [_P]),
     "svhip_synchronize": (C.c_int, [_P]),
+    "svhip_numeric_status": (C.c_int, [_P, C.c_int32]),
     "svhip_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "svhip_finalize_weights": (C.c_int, [_P]),
     "svhip_fbank": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32]),
@@ -64,6 +71,7 @@ _SIGNATURES = {
     "svhip_asnorm_last_fallback": (C.c_int64, [_P]),
     "svhip_score_trials": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_mean_crops": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "svhip_score_trials_pnorm": (C.c_int, [_P, C.c_float, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_roc_points": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64), _P, _P, _P, C.c_int32]),
     "svhip_error_rates": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32]),
     "svhip_min_dcf": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double),
@@ -140,7 +148,20 @@ def default_config() -> Config:
     return cfg
 
 
-def check(handle, rc):
-    if rc != OK:
-        msg = load().svhip_last_error(handle)
-        raise SvhipError(rc, msg.decode() if msg else "?")
+def check(handle, rc, on_numeric="raise"):
+    """rc of a C call -> exception.  The two numeric codes (the call DID complete and wrote its outputs) follow `on_numeric`:
+    "raise" (SvhipNumericError), "warn" (RuntimeWarning, the caller gets the outputs as computed - what the reference, which never
+    looks, would hand back) or "ignore"."""
+    if rc == OK:
+        return
+    msg = load().svhip_last_error(handle)
+    text = msg.decode() if msg else "?"
+    if rc in (ERR_NONFINITE, ERR_RANGE):
+        if on_numeric == "ignore":
+            return
+        if on_numeric == "warn":
+            import warnings
+            warnings.warn(f"svhip numeric status {rc}: {text}", RuntimeWarning, stacklevel=3)
+            return
+        raise SvhipNumericError(rc, text)
+    raise SvhipError(rc, text)

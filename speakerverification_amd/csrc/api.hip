@@ -172,6 +172,12 @@ struct svhip_handle {
     size_t lin_part_per_utt = 0;
     float *d_pool_raw = nullptr, *d_pool_bn = nullptr, *d_emb = nullptr;
     int lastB = 0;
+    // numeric status of the forwards since the last reset: d_status[0] = SVHIP_STATUS_* bits, [1] = non-finite embedding values,
+    // [2] = input values beyond the split planes' range; host_flag (pinned, mapped) is set by the same kernels, so that a synchronous
+    // call learns of a problem without a copy
+    uint32_t* d_status = nullptr;
+    uint32_t* host_flag = nullptr;
+    uint32_t* host_flag_dev = nullptr;
 
     // profiling: event pairs are recorded around every launch without blocking the host and
     // resolved (hipEventElapsedTime) when results are read
@@ -258,10 +264,8 @@ inline uint32_t x3_split_word(float v) {
     float hf; memcpy(&hf, &hu, 4);
     return hu | f32_to_bf16_rne(v - hf);
 #else
-    const float c = std::fmin(std::fmax(v, -65504.0f), 65504.0f);
-    const _Float16 h = static_cast<_Float16>(c);
-    const float r = std::fmin(std::fmax(v - static_cast<float>(h), -65504.0f), 65504.0f);
-    const _Float16 l = static_cast<_Float16>(r);
+    const _Float16 h = static_cast<_Float16>(v);                 // (plain conversions: overflow -> inf, NaN stays NaN — common.h, RANGE)
+    const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
     uint16_t hb, lb;
     memcpy(&hb, &h, 2); memcpy(&lb, &l, 2);
     return ((uint32_t)hb << 16) | lb;
@@ -823,6 +827,11 @@ int alloc_workspace(svhip_handle* h) {
         if ((rc = dev_upload(h, &h->d_zeros, zero))) return rc;
     }
     if ((rc = dev_alloc(h, &h->d_emb, B * (size_t)c.embed_dim))) return rc;
+    if ((rc = dev_alloc(h, &h->d_status, 4))) return rc;
+    SV_HIP(h, hipMemset(h->d_status, 0, 16));
+    SV_HIP(h, hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocMapped));
+    *h->host_flag = 0;
+    SV_HIP(h, hipHostGetDevicePointer((void**)&h->host_flag_dev, h->host_flag, 0));
     if (c.model == SVHIP_MODEL_RAWNET2) {
         h->rn_T1 = (c.samples - 250) / 3;
         const size_t per_utt = (size_t)h->rn_T1 * 128;           // largest activation: (T1, 128); later stages shrink 3x per doubling
@@ -995,7 +1004,8 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     float* cs_base = ((bf || h->x3) && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
     int rc;
     if ((rc = run(h, "prologue", 0, [&]() {
-             return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st);
+             return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st,
+                                    h->x3 ? h->d_status : nullptr, h->host_flag_dev, 65504.0f);
          }))) return rc;
     // F32X3: se_apply also leaves each block output in the S32 split layout (CAT's twin), so tdnn1 of the next block and mfa read
     // their A operand without a conversion pass
@@ -1495,8 +1505,44 @@ int check_ready(svhip_handle* h, int B) {
     return SVHIP_OK;
 }
 
+// The numeric status of the forwards since the last reset (the stream must be idle): the kernels that raise a bit also set the mapped
+// host flag, so the common case costs one host load.  Non-finite embeddings outrank the range warning (they are what it leads to).
+enum { SVHIP_STATUS_NONFINITE = 1, SVHIP_STATUS_RANGE = 2 };
+int numeric_status(svhip_handle* h, bool reset) {
+    if (!h->host_flag || !*h->host_flag) return SVHIP_OK;
+    uint32_t st[4] = {0, 0, 0, 0};
+    SV_HIP(h, hipMemcpy(st, h->d_status, 16, hipMemcpyDeviceToHost));
+    if (reset) {
+        SV_HIP(h, hipMemset(h->d_status, 0, 16));
+        *h->host_flag = 0;
+    }
+    if (st[0] & SVHIP_STATUS_NONFINITE)
+        SV_FAIL(h, SVHIP_ERR_NONFINITE, "%u embedding value(s) are not finite%s (the embeddings were written as computed)", st[1],
+                h->f16 ? ": an fp16 activation overflowed 65504 (or the input was not finite) - this checkpoint needs compute = bf16 (range-safe) or f32"
+                : h->x3 ? ": a GEMM operand exceeded 65504, the range of SVHIP_F32X3's half-precision hi | lo planes (or the input was not finite) - "
+                          "use compute = f32 (exact) or bf16 (range-safe)"
+                        : ": the input was not finite, or the weights overflow fp32");
+    if (st[0] & SVHIP_STATUS_RANGE)
+        SV_FAIL(h, SVHIP_ERR_RANGE, "%u input feature value(s) exceed 65504 in magnitude: SVHIP_F32X3 carries operands as IEEE-half hi | lo planes "
+                "and they were clamped (normalise the input - log_input / input_norm - or use compute = f32)", st[2]);
+    return SVHIP_OK;
+}
+
 int finish(svhip_handle* h, int flags) {
-    if (!(flags & SVHIP_ASYNC)) SV_HIP(h, hipStreamSynchronize(h->stream));
+    if (flags & SVHIP_ASYNC) return SVHIP_OK;
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    return numeric_status(h, true);
+}
+
+// the embeddings leave the workspace: device output through emb_out_kernel (copy + finite check in one pass), host output checked in
+// place and copied
+int emit_embeddings(svhip_handle* h, int B, float* emb_out, int flags) {
+    const int n = B * h->cfg.embed_dim;
+    h->cur = h->stream;
+    float* dst = (flags & SVHIP_OUT_DEVICE) ? emb_out : h->d_emb;
+    int rc = run(h, "emb_out", 0, [&]() { return launch_emb_out(h->d_emb, dst, n, h->d_status, h->host_flag_dev, h->stream); });
+    if (rc) return rc;
+    if (!(flags & SVHIP_OUT_DEVICE)) SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     return SVHIP_OK;
 }
 
@@ -1622,6 +1668,7 @@ int svhip_destroy(svhip_handle* h) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->host_flag) (void)hipHostFree(h->host_flag);
     prof_collect(h);
     for (hipEvent_t e : h->ev_free) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (h->lane_stream[i]) { (void)hipStreamSynchronize(h->lane_stream[i]); (void)hipStreamDestroy(h->lane_stream[i]); }
@@ -1634,7 +1681,14 @@ int svhip_destroy(svhip_handle* h) {
 int svhip_synchronize(svhip_handle* h) {
     if (!h) return SVHIP_ERR_INVALID;
     SV_HIP(h, hipStreamSynchronize(h->stream));
-    return SVHIP_OK;
+    return numeric_status(h, true);
+}
+
+int svhip_numeric_status(svhip_handle* h, int32_t reset) {
+    if (!h) return SVHIP_ERR_INVALID;
+    SV_HIP(h, hipSetDevice(h->cfg.device));
+    SV_HIP(h, hipStreamSynchronize(h->stream));
+    return numeric_status(h, reset != 0);
 }
 
 int svhip_load_tensor(svhip_handle* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype) {
@@ -1737,8 +1791,7 @@ int svhip_embed_features(svhip_handle* h, const float* feat, int32_t B, int32_t 
         d_in = h->d_feat;
     }
     if ((rc = ecapa_forward(h, d_in, B))) return rc;
-    const size_t bytes = (size_t)B * h->cfg.embed_dim * 4;
-    SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, bytes, (flags & SVHIP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if ((rc = emit_embeddings(h, B, emb_out, flags))) return rc;
     return finish(h, flags);
 }
 
@@ -1764,8 +1817,7 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
         if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
         if ((rc = ecapa_forward(h, h->d_feat, B))) return rc;
     }
-    const size_t bytes = (size_t)B * h->cfg.embed_dim * 4;
-    SV_HIP(h, hipMemcpyAsync(emb_out, h->d_emb, bytes, (flags & SVHIP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if ((rc = emit_embeddings(h, B, emb_out, flags))) return rc;
     return finish(h, flags);
 }
 
@@ -1961,7 +2013,7 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     return pairs_common(h, 1, E, N, D, mu, sigma, ia, ib, P, out, flags);
 }
 
-int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_files, int32_t n_crops, int32_t D, const int32_t* ia,
+static int score_trials_impl(svhip_handle* h, int32_t mode, float pexp, const float* F, int64_t n_files, int32_t n_crops, int32_t D, const int32_t* ia,
                        const int32_t* ib, int64_t P, float* out, int32_t flags) {
     if (!h || !F || !ia || !ib || !out || n_files <= 0 || n_crops <= 0 || D <= 0 || P < 0) return SVHIP_ERR_INVALID;
     if (mode < SVHIP_TRIAL_COSINE || mode > SVHIP_TRIAL_PDIST) SV_FAIL(h, SVHIP_ERR_INVALID, "unknown trial scoring mode %d", mode);
@@ -1979,11 +2031,22 @@ int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_
     if ((rc = tB.in(ib, (size_t)P * 4, din, &dB))) return rc;
     if ((rc = tO.out(out, (size_t)P * 4, dout, &dO))) return rc;
     if ((rc = run(h, "score_trials", 2.0 * P * n_crops * D, [&]() {
-             return launch_trial_crops(mode, (const float*)dF, n_crops, D, (const int32_t*)dA, (const int32_t*)dB, P, (float*)dO, h->stream);
+             return launch_trial_crops(mode, pexp, (const float*)dF, n_crops, D, (const int32_t*)dA, (const int32_t*)dB, P, (float*)dO, h->stream);
          }))) return rc;
     if (!dout) SV_HIP(h, hipMemcpyAsync(out, dO, (size_t)P * 4, hipMemcpyDeviceToHost, h->stream));
     if (!(din && dout && (flags & SVHIP_ASYNC))) SV_HIP(h, hipStreamSynchronize(h->stream));
     return SVHIP_OK;
+}
+
+int svhip_score_trials(svhip_handle* h, int32_t mode, const float* F, int64_t n_files, int32_t n_crops, int32_t D, const int32_t* ia,
+                       const int32_t* ib, int64_t P, float* out, int32_t flags) {
+    return score_trials_impl(h, mode, 2.0f, F, n_files, n_crops, D, ia, ib, P, out, flags);
+}
+
+int svhip_score_trials_pnorm(svhip_handle* h, float p, const float* F, int64_t n_files, int32_t n_crops, int32_t D, const int32_t* ia,
+                             const int32_t* ib, int64_t P, float* out, int32_t flags) {
+    if (h && p != p) SV_FAIL(h, SVHIP_ERR_INVALID, "pnorm: p is NaN");
+    return score_trials_impl(h, SVHIP_TRIAL_PNORM, p, F, n_files, n_crops, D, ia, ib, P, out, flags);
 }
 
 int svhip_mean_crops(svhip_handle* h, const float* F, int64_t n_files, int32_t n_crops, int32_t D, float* out, int32_t flags) {

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
             f16x8 a8, b8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const float v = u < 4 ? v0[u] : v1[u - 4];
                 const f16_t a = static_cast<f16_t>(v);
                 a8[u] = a;
                 b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
             f16x8 a8, b8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const float v = u < 4 ? v0[u] : v1[u - 4];
                 const f16_t a = static_cast<f16_t>(v);
                 a8[u] = a;
                 b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
             f16x8 a8, b8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float v = __builtin_amdgcn_fmed3f(u < 4 ? v0[u] : v1[u - 4], -65504.0f, 65504.0f);
+                const float v = u < 4 ? v0[u] : v1[u - 4];
                 const f16_t a = static_cast<f16_t>(v);
                 a8[u] = a;
                 b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restr
     const int64_t n = (int64_t)(n0 + n1) * D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / D;
-        const float v = __builtin_amdgcn_fmed3f(r < n0 ? A[i] : B[i - (int64_t)n0 * D], -65504.0f, 65504.0f);
+        const float v = r < n0 ? A[i] : B[i - (int64_t)n0 * D];
         const f16_t a = static_cast<f16_t>(v);
         planes[i] = a;
         planes[n + i] = static_cast<f16_t>(v - static_cast<float>(a));

@@ -136,20 +136,22 @@ template <> struct Half16<f16_t> {
 // ---- the split ("X3") forms: fp32 values as hi | lo planes of a 16-bit type, a product as three MFMAs (hi.hi + hi.lo + lo.hi) ----------
 // Round 4: the planes are IEEE half, not bf16.  bf16 planes carry 8 + 8 significant bits (v - hi - lo ~ 2^-17 |v|: the error of rounds
 // 2 - 3's f32x3 mode); fp16 planes carry 11 + 11 (2^-23 |v| while lo is a normal half, i.e. |v| >= 2^-3; below that lo is a subnormal
-// and the residual is at most 2^-25 ABSOLUTE) at the same MFMA rate: the mode becomes fp32-grade.  hi saturates at the
-// largest half (65504) instead of overflowing to infinity; lo then carries what it can.  -DSVHIP_X3_BF16 rebuilds the old planes (A/B).
+// and the residual is at most 2^-25 ABSOLUTE) at the same MFMA rate: the mode becomes fp32-grade.  -DSVHIP_X3_BF16 rebuilds
+// the old planes (A/B).
+// RANGE (round 5): the conversion is the plain one — |v| > 65504 becomes inf, a NaN stays a NaN — so that what the planes cannot carry
+// shows up in the embeddings, where every forward looks (emb_out_kernel -> SVHIP_ERR_NONFINITE).  Round 4 clamped with v_med3_f32, which
+// kept the result finite and WRONG, and turned a NaN input into +-65504 (a NaN sample gave a finite, meaningless embedding on f32x3
+// handles only: tests/test_gpu_rawnet2.py::test_nonfinite_input_is_reported_on_every_handle_kind).
 #ifdef SVHIP_X3_BF16
 typedef bf16_t x3_t;
-constexpr float X3_MAX = 3.0e38f;
 #else
 typedef f16_t x3_t;
-constexpr float X3_MAX = 65504.0f;
 #endif
 typedef Half16<x3_t> X3H;
 typedef x3_t x3x2_t __attribute__((ext_vector_type(2)));
 typedef x3_t x3x4_t __attribute__((ext_vector_type(4)));
 typedef x3_t x3x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ x3_t x3_hi(float v) { return static_cast<x3_t>(__builtin_amdgcn_fmed3f(v, -X3_MAX, X3_MAX)); }
+__device__ __forceinline__ x3_t x3_hi(float v) { return static_cast<x3_t>(v); }
 __device__ __forceinline__ x3_t x3_lo(float v, x3_t h) { return x3_hi(v - static_cast<float>(h)); }
 // two values -> one dword of their hi parts and one of their lo parts
 __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hd, uint32_t& ld) {

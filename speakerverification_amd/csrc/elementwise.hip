@@ -636,6 +636,34 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
     return hipGetLastError();
 }
 
+// ---- the last kernel of every forward: the embeddings leave the workspace, and the numeric status of the call is recorded --------------
+// dst[i] = src[i] (dst == src: check only); a value that is not finite — an fp16 activation that overflowed (SVHIP_F16 storage, pack2 ->
+// inf), a NaN in the input — raises bit 0 of status[0], is counted in status[1], and sets the host-visible flag word (pinned, mapped
+// memory: the host reads it after a stream synchronisation without a copy).  Nothing is written in the normal case.
+__global__ __launch_bounds__(256) void emb_out_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, uint32_t* __restrict__ status,
+                                                      volatile uint32_t* __restrict__ host_flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const float v = src[i];
+        if (dst != src) dst[i] = v;
+        bad = !(fabsf(v) <= 3.4028234663852886e38f);         // inf or NaN
+    }
+    const unsigned long long m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == 0) {
+        atomicOr(status, 1u);
+        atomicAdd(status + 1, (uint32_t)__popcll(m));
+        __threadfence_system();
+        *host_flag = 1u;
+    }
+}
+
+hipError_t launch_emb_out(const float* src, float* dst, int n, uint32_t* status, uint32_t* host_flag, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emb_out_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, n, status, host_flag);
+    return hipGetLastError();
+}
+
 size_t rowvec_linear_scratch_bytes(int B, int N, int K) { return (K % LIN_KS == 0 && K >= 8 * LIN_KS) ? (size_t)(K / LIN_KS) * B * N * sizeof(float) : 0; }
 
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,

@@ -410,10 +410,12 @@ __global__ __launch_bounds__(256) void prologue_stats_kernel(const float* __rest
 template <typename T_>
 __global__ __launch_bounds__(256) void prologue_apply_kernel(const float* __restrict__ feat, const float* __restrict__ stats,
                                                              T_* __restrict__ out, int n_mels, int T, int log_input,
-                                                             const float* __restrict__ in_w, const float* __restrict__ in_b) {
+                                                             const float* __restrict__ in_w, const float* __restrict__ in_b,
+                                                             uint32_t* __restrict__ status, volatile uint32_t* __restrict__ host_flag, float limit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);      // [n_mels][33]
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    bool bad = false;
     for (int idx = threadIdx.x; idx < n_mels * 32; idx += 256) {
         const int i = idx & 31, m = idx >> 5;
         const int t = t0 + i;
@@ -426,6 +428,18 @@ __global__ __launch_bounds__(256) void prologue_apply_kernel(const float* __rest
             if (in_w) v = v * in_w[m] + in_b[m];
         }
         tile[m * 33 + i] = v;
+        bad |= !(fabsf(v) <= limit);
+    }
+    // range guard of the split (F32X3) handles: the network's input leaves for half-precision hi | lo planes, whose hi part saturates at
+    // 65504 — a value beyond `limit` (or a NaN) raises bit 1 of status[0], is counted in status[2] and sets the host-visible flag
+    if (status) {
+        const unsigned long long mb = __ballot(bad);
+        if (mb && (threadIdx.x & 63) == 0) {
+            atomicOr(status, 2u);
+            atomicAdd(status + 2, (uint32_t)__popcll(mb));
+            __threadfence_system();
+            *host_flag = 1u;
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < n_mels * 32; idx += 256) {
@@ -471,7 +485,7 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
 }
 
 hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, int n_mels, int T, int log_input,
-                           const float* in_w, const float* in_b, float* stats, hipStream_t stream) {
+                           const float* in_w, const float* in_b, float* stats, hipStream_t stream, uint32_t* status, uint32_t* host_flag, float limit) {
     const int rows = B * n_mels;
     hipLaunchKernelGGL(prologue_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, feat, stats, rows, T,
                        log_input, in_w != nullptr ? 1 : 0);
@@ -479,10 +493,10 @@ hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, i
     const size_t lds = (size_t)n_mels * 33 * sizeof(float);
     if (out_bf16)
         hipLaunchKernelGGL(prologue_apply_kernel<bf16_t>, grid, dim3(256), lds, stream, feat, stats,
-                           reinterpret_cast<bf16_t*>(out), n_mels, T, log_input, in_w, in_b);
+                           reinterpret_cast<bf16_t*>(out), n_mels, T, log_input, in_w, in_b, status, host_flag, limit);
     else
         hipLaunchKernelGGL(prologue_apply_kernel<float>, grid, dim3(256), lds, stream, feat, stats,
-                           reinterpret_cast<float*>(out), n_mels, T, log_input, in_w, in_b);
+                           reinterpret_cast<float*>(out), n_mels, T, log_input, in_w, in_b, status, host_flag, limit);
     return hipGetLastError();
 }
 

@@ -212,7 +212,8 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
 // with optional log(x+1e-6) - mean_t and optional InstanceNorm1d(affine).
 // `stats` is a (B * n_mels * 2) fp32 scratch buffer.
 hipError_t launch_prologue(const float* feat, void* out, bool out_bf16, int B, int n_mels, int T,
-                           int log_input, const float* in_w, const float* in_b, float* stats, hipStream_t stream);
+                           int log_input, const float* in_w, const float* in_b, float* stats, hipStream_t stream,
+                           uint32_t* status = nullptr, uint32_t* host_flag = nullptr, float limit = 3.0e38f);       // range guard: fbank.hip
 
 // ---------------------------------------------------------------------------------------------
 // Frame-major reductions / elementwise (activation dtype templated inside)
@@ -229,6 +230,9 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
 size_t rowvec_linear_scratch_bytes(int B, int N, int K);
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
                                 int B, int N, int K, int act, hipStream_t stream, float* part = nullptr);
+// the embeddings leave the workspace (dst == src: no copy) and the call's numeric status is recorded: a non-finite value raises bit 0 of
+// status[0], is counted in status[1] and sets *host_flag (mapped pinned memory).  SVHIP_STATUS_* bits: api.hip
+hipError_t launch_emb_out(const float* src, float* dst, int n, uint32_t* status, uint32_t* host_flag, hipStream_t stream);
 // s[b, :] = sigmoid(W2 relu(W1 mean[b, :] + b1) + b2); W1 [H][C], W2T = W2 transposed [H][C]
 hipError_t launch_se_mlp(const float* mean, const float* part, int T, const void* W1, const float* b1, const void* W2T,
                          const float* b2, float* s, bool w_bf16, int B, int C, int H, hipStream_t stream, int row_groups = 8);
@@ -365,7 +369,7 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
                                const int32_t* ib, int64_t P, float* out, hipStream_t stream);
 // whole-trial forms over the aligned crops of two files, F (n_files, n_crops, D): mode 0 mean |cos|, 1 mean p-2 distance (+1e-6),
 // 2 minus the mean pairwise distance over the (n, D, n) broadcast (src/utils.py:163-169, src/model.py:425-431)
-hipError_t launch_trial_crops(int mode, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
+hipError_t launch_trial_crops(int mode, float pexp, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
                               hipStream_t stream);
 hipError_t launch_mean_crops(const float* F, int64_t n_files, int n_crops, int D, float* out, hipStream_t stream);
 // S (rows x K, row stride ld) fp32 cohort scores -> mean / population std of the `top` largest per row

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void pair_kernel(const float* __restrict__ E, 
 //   MODE 1: mean_i || R_i - C_i + 1e-6 ||_2                                                      src/utils.py:167-169
 //   MODE 2: - mean_{i,d} sqrt( sum_j (R[i,d] - C[j,d] + 1e-6)^2 )  — F.pairwise_distance of ref (n, D, 1) against com (1, D, n)
 //           takes the 2-norm over the LAST axis of the broadcast (n, D, n) difference (src/model.py:425-431)
+//   MODE 3: mean_i || R_i - C_i + 1e-6 ||_p for any p (pnorm_similarity's `p` argument, src/utils.py:167-169 -> F.pairwise_distance ->
+//           torch.linalg.vector_norm): p = inf max |d|, p = -inf min |d|, p = 0 the count of non-zero d, p = 1 the sum of |d|,
+//           otherwise (sum |d|^p)^(1/p) — negative p included, as torch evaluates it
 template <int MODE>
 __global__ __launch_bounds__(256) void trial_crops_kernel(const float* __restrict__ F, int n_crops, int D, const int32_t* __restrict__ ia,
-                                                          const int32_t* __restrict__ ib, int64_t P, float* __restrict__ out) {
+                                                          const int32_t* __restrict__ ib, int64_t P, float* __restrict__ out, float pexp) {
     const int sub = threadIdx.x & 15;
     const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool ok = p < P;
@@ -97,6 +100,31 @@ __global__ __launch_bounds__(256) void trial_crops_kernel(const float* __restric
             }
         acc = group16_sum(acc);
         if (ok && sub == 0) out[p] = -acc / ((float)n_crops * (float)D);
+        return;
+    }
+    if (MODE == 3) {
+        const bool pinf = pexp > 3.0e38f, ninf = pexp < -3.0e38f;
+        for (int i = 0; i < n_crops; ++i) {
+            const float* __restrict__ ea = fa + (int64_t)i * D;
+            const float* __restrict__ eb = fb + (int64_t)i * D;
+            float r = ninf ? __builtin_inff() : 0.0f;
+            for (int k = sub; k < D; k += 16) {
+                const float t = fabsf((ea[k] - eb[k]) + 1e-6f);
+                if (pinf) r = fmaxf(r, t);
+                else if (ninf) r = fminf(r, t);
+                else if (pexp == 0.0f) r += t != 0.0f ? 1.0f : 0.0f;
+                else if (pexp == 1.0f) r += t;
+                else r += powf(t, pexp);
+            }
+            // the 16 lanes of a trial: xor shuffles inside the group
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                const float u = __shfl_xor(r, o, 64);
+                r = pinf ? fmaxf(r, u) : ninf ? fminf(r, u) : r + u;
+            }
+            acc += (pinf || ninf || pexp == 0.0f || pexp == 1.0f) ? r : powf(r, 1.0f / pexp);
+        }
+        if (ok && sub == 0) out[p] = acc / (float)n_crops;
         return;
     }
     for (int i = 0; i < n_crops; ++i) {
@@ -325,14 +353,15 @@ hipError_t launch_asnorm_pairs(const float* E, int D, const float* mu, const flo
     return hipGetLastError();
 }
 
-hipError_t launch_trial_crops(int mode, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
+hipError_t launch_trial_crops(int mode, float pexp, const float* F, int n_crops, int D, const int32_t* ia, const int32_t* ib, int64_t P, float* out,
                               hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     if (n_crops <= 0 || D <= 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((P + 15) / 16)), block(256);
-    if (mode == 0) hipLaunchKernelGGL(trial_crops_kernel<0>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
-    else if (mode == 1) hipLaunchKernelGGL(trial_crops_kernel<1>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
-    else if (mode == 2) hipLaunchKernelGGL(trial_crops_kernel<2>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out);
+    if (mode == 0) hipLaunchKernelGGL(trial_crops_kernel<0>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out, 2.0f);
+    else if (mode == 1 && pexp == 2.0f) hipLaunchKernelGGL(trial_crops_kernel<1>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out, 2.0f);
+    else if (mode == 1) hipLaunchKernelGGL(trial_crops_kernel<3>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out, pexp);
+    else if (mode == 2) hipLaunchKernelGGL(trial_crops_kernel<2>, grid, block, 0, stream, F, n_crops, D, ia, ib, P, out, 2.0f);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -82,7 +82,13 @@ class _Buf:
 class Engine:
     def __init__(self, model="ecapa", compute="f32", channels=1024, n_mels=80, embed_dim=192, max_batch=8,
                  samples=32000, log_input=True, input_norm=False, device=0, stream=None,
-                 sr=8000, n_fft=512, win_length=200, hop_length=80, fmin=0.0, fmax=None, pre_emphasis=True):
+                 sr=8000, n_fft=512, win_length=200, hop_length=80, fmin=0.0, fmax=None, pre_emphasis=True, on_numeric="raise"):
+        """``on_numeric``: what a forward does when the library reports SVHIP_ERR_NONFINITE / SVHIP_ERR_RANGE (the outputs were written,
+        but an fp16 activation overflowed / the input left an f32x3 handle's range / the input was not finite): "raise"
+        (_lib.SvhipNumericError, default), "warn" (RuntimeWarning; the outputs are returned as computed, as the reference would) or "ignore"."""
+        if on_numeric not in ("raise", "warn", "ignore"):
+            raise ValueError("on_numeric must be 'raise', 'warn' or 'ignore'")
+        self.on_numeric = on_numeric
         self.lib = _lib.load()
         cfg = _lib.default_config()
         cfg.model = {"ecapa": _lib.MODEL_ECAPA, "rawnet2": _lib.MODEL_RAWNET2, "none": _lib.MODEL_NONE}[model]
@@ -144,10 +150,15 @@ class Engine:
             pass
 
     def _ck(self, rc):
-        _lib.check(self.h, rc)
+        _lib.check(self.h, rc, self.on_numeric)
 
     def synchronize(self):
+        """waits for the handle's stream; reports (per on_numeric) and clears the numeric status of the async calls it waited for"""
         self._ck(self.lib.svhip_synchronize(self.h))
+
+    def numeric_status(self, reset=True):
+        """0, _lib.ERR_NONFINITE or _lib.ERR_RANGE for the forwards since the last reset (waits for the stream; never raises)"""
+        return int(self.lib.svhip_numeric_status(self.h, 1 if reset else 0))
 
     # ---- weights ---------------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, object], strict=True, show_error=False):
@@ -348,16 +359,20 @@ class Engine:
 
     TRIAL_MODES = {"cosine": _lib.TRIAL_COSINE, "pnorm": _lib.TRIAL_PNORM, "pdist": _lib.TRIAL_PDIST}
 
-    def score_trials(self, F, ia, ib, mode="cosine", out=None):
-        """whole-trial scores over the crops of two files: F (n_files, n_crops, D), ia / ib file indices (svhip_score_trials)"""
+    def score_trials(self, F, ia, ib, mode="cosine", out=None, p=2):
+        """whole-trial scores over the crops of two files: F (n_files, n_crops, D), ia / ib file indices (svhip_score_trials);
+        mode "pnorm" takes the reference's `p` (utils.py:167: any float, +-inf, 0)"""
         n_files, n_crops, D = F.shape
         P = int(ia.shape[0])
         if out is None:
             out = self._out(F, (P,))
         f, a, b, o = _Buf(F, np.float32), _Buf(ia, np.int32), _Buf(ib, np.int32), _Buf(out, np.float32, writable=True)
         dev = self._same_space(f, a, b, o)
-        self._ck(self.lib.svhip_score_trials(self.h, self.TRIAL_MODES[mode], f.ptr, n_files, n_crops, D, a.ptr, b.ptr, P, o.ptr,
-                                             (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0))
+        fl = (_lib.IN_DEVICE | _lib.OUT_DEVICE) if dev else 0
+        if mode == "pnorm" and float(p) != 2.0:
+            self._ck(self.lib.svhip_score_trials_pnorm(self.h, float(p), f.ptr, n_files, n_crops, D, a.ptr, b.ptr, P, o.ptr, fl))
+        else:
+            self._ck(self.lib.svhip_score_trials(self.h, self.TRIAL_MODES[mode], f.ptr, n_files, n_crops, D, a.ptr, b.ptr, P, o.ptr, fl))
         _count([f, a, b], [o])
         return out
 

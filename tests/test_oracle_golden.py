@@ -109,6 +109,13 @@ def test_scoring(golden_dir):
         assert abs(o_scoring.zt_norm_similarity(r.numpy(), c.numpy(), g["cohort"], top) - g["zt_norm"][i]) < 1e-5
         assert abs(o_scoring.zt_norm_similarity(r.numpy(), c.numpy(), g["cohort"]) - g["zt_norm_default_top"][i]) < 1e-5
         assert abs(o_scoring.pnorm_similarity(r, c) - g["pnorm"][i]) < 1e-6
+    # pnorm_similarity's `p` argument (utils.py:167) at values the reference's own call site never passes: tests/golden/pnorm_p.npz
+    gp = np.load(os.path.join(golden_dir, "pnorm_p.npz"))
+    for k, pv in enumerate(gp["p"]):
+        for i in range(gp["R"].shape[0]):
+            want = gp["pnorm"][k, i]
+            got = o_scoring.pnorm_similarity(torch.from_numpy(gp["R"][i]), torch.from_numpy(gp["C"][i]), p=float(pv))
+            assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (pv, i)
     # batched GEMM statement on crop means == the reference's per-trial loop
     Rn = torch.nn.functional.normalize(torch.from_numpy(g["R"]), p=2, dim=2).numpy()
     Cn = torch.nn.functional.normalize(torch.from_numpy(g["C"]), p=2, dim=2).numpy()
