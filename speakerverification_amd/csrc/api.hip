@@ -75,9 +75,12 @@ struct svhip_handle {
         int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
         int score_tiled = 0;      // dense score GEMMs on the tiled split kernel (gemm_pw) instead of the row-streaming one (score_h3w)
         int asnorm_w32 = 0;       // AS-norm two-half-plane kernel on the 32-wide MFMA (round 4's first form) instead of 16x16x32
+        int asnorm_dbg = 0;       // developer ablations of the AS-norm kernel (AsnormFusedParams::dbg; results are then wrong: timing only)
+        int asnorm_2s = 0;        // AS-norm split forms: candidate statistics of chunk c on a second stream under the matrix kernel of chunk c + 1
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
+        int pw3_tail_off = 0;     // persistent 16-bit GEMMs: the last partial round as whole tiles (round 4) instead of column halves
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
         int rn_pool_off = 0;      // F32X3 handles: conv2 of the long pooled blocks writes the un-pooled output, rn_maxpool3 pools it (tests)
@@ -924,7 +927,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.lda = lda; p.lda2 = lda2; p.ldy = ldy; p.ld_bu = ld_bu;
     p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
-    p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus;
+    p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.tail_split = h->opt.pw3_tail_off ? 0 : 1;
     const bool bf = h->bf16;
     hipStream_t st = h->cur;
     (void)label;
@@ -1018,7 +1021,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         q.A = a32; q.lda = lda32; q.W = L.Ws32; q.x3 = 2; q.Y = MFA; q.ldy = L.N;
         q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
         q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.Wrows = L.Np; q.T = T; q.taps = L.taps; q.act1 = ACT_GELU; q.num_cu = h->num_cu;
-        q.pw3_cus = h->opt.pw3_cus;
+        q.pw3_cus = h->opt.pw3_cus; q.tail_split = h->opt.pw3_tail_off ? 0 : 1;
         if (cs) { q.colsum = cs_base; q.colsum_sq = 1; q.colsum_stride = h->colsum_region; }
         return gemm_pw3x3_supported(q);
     };
@@ -1034,7 +1037,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
         q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
         q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
-        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus;
+        q.act1 = ACT_GELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus; q.tail_split = h->opt.pw3_tail_off ? 0 : 1;
         // (with s32_only and tdnn1 of the first block on the X3 kernel, X0 itself is written in the split layout: no conversion pass,
         //  block 1's residual is read as hi + lo, svhip_get_stage rebuilds the fp32 view)
         q.y_s32 = (s32_only && x3_route(h->tdnn1[0], X0, C, false)) ? 1 : 0;
@@ -1064,7 +1067,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
             q.A = us[(j - 1) & 1]; q.lda = C8; q.W = L.Ws32; q.Wrows = L.N; q.x3 = 2;
             q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
             q.M = M; q.N = L.N; q.K = L.K; q.Kp = L.Kp; q.T = T; q.taps = 3; q.dil = L.dil; q.cin = L.cin; q.pad_mode = PAD_REFLECT;
-            q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus;
+            q.act1 = ACT_RELU; q.act2 = ACT_NONE; q.num_cu = h->num_cu; q.pw3_cus = h->opt.pw3_cus; q.tail_split = h->opt.pw3_tail_off ? 0 : 1;
             q.Y = h2s + (size_t)j * C8 * 4; q.ldy = C;
             if (j < 7) { q.R = static_cast<const float*>(H1) + (size_t)(j + 1) * C8; q.ldr = C; q.Y2 = us[j & 1]; q.lda2 = C8; }
             return q;
@@ -1223,7 +1226,7 @@ static GemmParams conv2sc_params(svhip_handle* h, const svhip_handle::RnBlock& K
     p.M = M; p.N = K.cout; p.K = K.conv2.K; p.Kp = K.conv2.K + K.cin; p.Wrows = K.conv2.Np;
     p.lda = K.cout; p.ldy = K.cout; p.T = T; p.taps = 3; p.dil = 1; p.cin = K.cout; p.pad_mode = PAD_ZERO;
     p.A3 = pre; p.lda3 = K.cin; p.K3 = K.cin;
-    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus;
+    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.tail_split = h->opt.pw3_tail_off ? 0 : 1;
     return p;
 }
 static bool conv2sc_fits(svhip_handle* h, const svhip_handle::RnBlock& K, const void* pre, const void* hb, void* o, int M, int T) {
@@ -1238,7 +1241,7 @@ static bool conv_cv_persistent(svhip_handle* h, const ConvLayer& L, const void* 
     p.bias = L.bias; p.scale = L.scale; p.shift = L.shift; p.zeros = h->d_zeros; p.ones = h->d_ones; p.zero_page = zero_page_for(h, A);
     p.M = M; p.N = L.N; p.K = L.K; p.Kp = L.Kp; p.Wrows = L.Np; p.lda = lda; p.ldy = L.N; p.T = T;
     p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
-    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.cv_off = h->opt.cv_off;
+    p.num_cu = h->num_cu; p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.tail_split = h->opt.pw3_tail_off ? 0 : 1; p.cv_off = h->opt.cv_off;
     return h->bf16 && gemm_route(p, true) == ROUTE_PW3CV;
 }
 
@@ -1516,15 +1519,17 @@ int numeric_status(svhip_handle* h, bool reset) {
         SV_HIP(h, hipMemset(h->d_status, 0, 16));
         *h->host_flag = 0;
     }
+    // (the range report outranks the non-finite one: it names the cause — an input the planes cannot carry ends as inf / NaN embeddings)
+    if (st[0] & SVHIP_STATUS_RANGE)
+        SV_FAIL(h, SVHIP_ERR_RANGE, "%u input feature value(s) exceed 65504 in magnitude (or are not finite): SVHIP_F32X3 carries operands as IEEE-half "
+                "hi | lo planes and cannot represent them; %u embedding value(s) came out non-finite (normalise the input - log_input / input_norm - "
+                "or use compute = f32)", st[2], st[1]);
     if (st[0] & SVHIP_STATUS_NONFINITE)
         SV_FAIL(h, SVHIP_ERR_NONFINITE, "%u embedding value(s) are not finite%s (the embeddings were written as computed)", st[1],
                 h->f16 ? ": an fp16 activation overflowed 65504 (or the input was not finite) - this checkpoint needs compute = bf16 (range-safe) or f32"
                 : h->x3 ? ": a GEMM operand exceeded 65504, the range of SVHIP_F32X3's half-precision hi | lo planes (or the input was not finite) - "
                           "use compute = f32 (exact) or bf16 (range-safe)"
                         : ": the input was not finite, or the weights overflow fp32");
-    if (st[0] & SVHIP_STATUS_RANGE)
-        SV_FAIL(h, SVHIP_ERR_RANGE, "%u input feature value(s) exceed 65504 in magnitude: SVHIP_F32X3 carries operands as IEEE-half hi | lo planes "
-                "and they were clamped (normalise the input - log_input / input_norm - or use compute = f32)", st[2]);
     return SVHIP_OK;
 }
 
@@ -1616,7 +1621,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.cv_off = is1("SVHIP_CV_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2065,35 +2070,44 @@ int svhip_mean_crops(svhip_handle* h, const float* F, int64_t n_files, int32_t n
     return SVHIP_OK;
 }
 
-// out (Na, Nb) = A @ B^T on the fp32 MFMA GEMM (B plays the packed-weight role: rows clamp, no padding needed).  On an
-// SVHIP_F32X3 handle the products are split-bf16 MFMA triples: `dBsplit` is B as (hi << 16 | lo) words (split_b below).
+// out (Na, Nb) = A @ B^T.  The route is decided ONCE (split_b and score_gemm used to re-derive it from different predicates):
+//   SCORE_H3W     rows of A in registers, B streamed past them as half planes (asnorm_fused.hip: score_h3w; D = 192 / 256, aligned operands);
+//                 the kernel's launcher fills the planes itself (and scales both operands by exact powers of two)
+//   SCORE_WORDS   the tiled GEMM with B as (hi half << 16 | lo half) words, A split in registers (gemm_pw's x3 form)
+//   SCORE_F32MFMA the exact fp32 MFMA GEMM (option score_f32mfma, or shapes gemm_pw's split form does not take)
+// The split forms run as three fp16 MFMAs per product on every handle since round 4 (a score of unit vectors within ~4e-8 of the float64
+// oracle, the exact fp32 MFMA 3.5e-8) at twice the fp32 matrix rate.
+enum ScoreRoute { SCORE_F32MFMA = 0, SCORE_WORDS = 1, SCORE_H3W = 2 };
+static ScoreRoute score_route(const svhip_handle* h, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D) {
+    if (h->opt.score_f32mfma && !h->x3) return SCORE_F32MFMA;
+    if (!h->opt.score_tiled && score_h3w_supported(D, Na, Nb) && ((reinterpret_cast<uintptr_t>(dA) | reinterpret_cast<uintptr_t>(dB)) & 15) == 0) return SCORE_H3W;
+    return SCORE_WORDS;
+}
+
 static int score_gemm(svhip_handle* h, const char* label, const float* dA, int64_t Na, const float* dB, int64_t Nb, int D, float* dO, int64_t ldo,
-                      const void* dBsplit = nullptr) {
+                      ScoreRoute route, const void* dBsplit) {
     if (D % 32 != 0) SV_FAIL(h, SVHIP_ERR_UNSUPPORTED, "embedding dim %d must be a multiple of 32", D);
     if (Na > (1 << 30) / 1 || Nb > (1 << 30)) SV_FAIL(h, SVHIP_ERR_INVALID, "matrix too large");
-    // D = 192 / 256 (what the models produce): rows of A in registers, B streamed past them as half planes (asnorm_fused.hip: score_h3w)
-    if (dBsplit && !h->opt.score_tiled && score_h3w_supported(D, Na, Nb) && ((reinterpret_cast<uintptr_t>(dA) | reinterpret_cast<uintptr_t>(dB)) & 15) == 0) {
-        hipStream_t st = h->stream;
+    hipStream_t st = h->stream;
+    if (route == SCORE_H3W) {
+        if (!dBsplit || (reinterpret_cast<uintptr_t>(dA) & 15)) SV_FAIL(h, SVHIP_ERR_STATE, "score route: the row-streaming kernel was chosen without its plane scratch");
         return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_score_h3w(dA, Na, dB, Nb, D, dO, ldo, const_cast<void*>(dBsplit), h->num_cu, st); });
     }
     GemmParams p;
     p.A = dA; p.W = dB; p.Y = dO;
     p.M = (int)Na; p.N = (int)Nb; p.K = D; p.Kp = D; p.Wrows = (int)Nb;
     p.lda = D; p.ldy = (int)ldo; p.T = 1;
-    if (dBsplit && gemm_pw_supported(p, false)) { p.W = dBsplit; p.x3 = 1; }
-    hipStream_t st = h->stream;
+    if (route == SCORE_WORDS && dBsplit && gemm_pw_supported(p, false)) { p.W = dBsplit; p.x3 = 1; }      // (the words exist: split_b ran launch_split_words)
     return run(h, label, 2.0 * Na * Nb * D, [&]() { return launch_gemm(p, false, st); });
 }
 
-// B as split words (hi half << 16 | lo half) in a scratch slot of the handle: the score GEMMs run as three fp16 MFMAs per product on
-// every handle since round 4 — with half planes the split form is fp32-grade (a score of unit vectors within ~4e-8 of the float64
-// oracle, the exact fp32 MFMA 3.5e-8) at twice the fp32 matrix rate; option score_f32mfma keeps the exact fp32 MFMA.
-static int split_b(svhip_handle* h, const float* dB, int64_t Nb, int D, void** out) {
+// the split operand of the chosen route in a scratch slot of the handle: half planes (filled by the row-streaming kernel's own launcher:
+// [2][Nb][D] halves + its scale word) or split words (filled here)
+static int split_b(svhip_handle* h, ScoreRoute route, const float* dB, int64_t Nb, int D, void** out) {
     *out = nullptr;
-    if (h->opt.score_f32mfma && !h->x3) return SVHIP_OK;
-    if (int rc = scratch(h, svhip_handle::SCR_SPLIT, (size_t)Nb * D * 4, out)) return rc;
-    // (the row-streaming kernel fills the same scratch with its own half planes: [2][Nb][D] halves are the same Nb * D * 4 bytes)
-    if (!h->opt.score_tiled && score_h3w_supported(D, 1, Nb) && (reinterpret_cast<uintptr_t>(dB) & 15) == 0) return SVHIP_OK;
+    if (route == SCORE_F32MFMA) return SVHIP_OK;
+    if (int rc = scratch(h, svhip_handle::SCR_SPLIT, std::max((size_t)Nb * D * 4, score_h3w_planes_bytes(D, Nb)), out)) return rc;
+    if (route == SCORE_H3W) return SVHIP_OK;
     return run(h, "split_words", 0, [&]() { return launch_split_words(dB, *out, Nb * D, h->stream); });
 }
 
@@ -2109,8 +2123,9 @@ int svhip_score_matrix(svhip_handle* h, const float* A, int64_t Na, const float*
     if ((rc = tB.in(B, (size_t)Nb * D * 4, din, &dB))) return rc;
     if ((rc = tO.out(out, (size_t)Na * Nb * 4, dout, &dO))) return rc;
     void* bsplit = nullptr;
-    if ((rc = split_b(h, (const float*)dB, Nb, D, &bsplit))) return rc;
-    rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb, bsplit);
+    const ScoreRoute route = score_route(h, (const float*)dA, Na, (const float*)dB, Nb, D);
+    if ((rc = split_b(h, route, (const float*)dB, Nb, D, &bsplit))) return rc;
+    rc = score_gemm(h, "score_matrix", (const float*)dA, Na, (const float*)dB, Nb, D, (float*)dO, Nb, route, bsplit);
     if (!rc && !dout) { const hipError_t e = hipMemcpyAsync(out, dO, (size_t)Na * Nb * 4, hipMemcpyDeviceToHost, h->stream); if (e != hipSuccess) rc = SVHIP_ERR_HIP; }
     if (!(din && dout && (flags & SVHIP_ASYNC))) (void)hipStreamSynchronize(h->stream);
     return rc;
@@ -2125,11 +2140,12 @@ static int asnorm_stats_slab(svhip_handle* h, const float* dE, int64_t N, int D,
     void* csplit = nullptr;
     void* slab = nullptr;
     int rc;
-    if ((rc = split_b(h, dC, K, D, &csplit))) return rc;
+    const ScoreRoute route = score_route(h, dE, slab_rows, dC, K, D);       // (every slab starts r0 * D * 4 bytes into E: the same alignment)
+    if ((rc = split_b(h, route, dC, K, D, &csplit))) return rc;
     if ((rc = scratch(h, svhip_handle::SCR_SLAB, (size_t)slab_rows * ldk * 4, &slab))) return rc;
     for (int64_t r0 = 0; r0 < N; r0 += slab_rows) {
         const int64_t rows = std::min(slab_rows, N - r0);
-        rc = score_gemm(h, "asnorm_cohort_gemm", dE + r0 * D, rows, dC, K, D, (float*)slab, ldk, csplit);
+        rc = score_gemm(h, "asnorm_cohort_gemm", dE + r0 * D, rows, dC, K, D, (float*)slab, ldk, route, csplit);
         if (!rc) rc = run(h, "asnorm_topk", 0, [&]() { return launch_topk_stats((const float*)slab, rows, K, (int)ldk, top, dM + r0, dS + r0, h->stream); });
         if (rc) return rc;
     }
@@ -2169,7 +2185,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         const bool x6 = asnorm_fused6_supported(D, nplanes) && !h->opt.asnorm_f32mfma;
         // (x6: the candidate kernel takes 1.7 ms of 17 on its own and 7 when it shares the CUs with the matrix kernel: one stream.
         //  The fp32-MFMA form keeps the second stream: 26.1 - 26.9 against 27.5 ms)
-        const int nbuf = (N > chunk && !x6) ? 2 : 1;
+        const int nbuf = (N > chunk && (!x6 || h->opt.asnorm_2s)) ? 2 : 1;
         const size_t mom_bytes = (cohort_moments_scratch_bytes(D) + 255) & ~(size_t)255;
         if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + mom_bytes + (x6 ? asnorm_planes_bytes(D, K) : 0), &mb))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CAND, cand_elems * 4 * nbuf, &cand))) return rc;
@@ -2186,9 +2202,13 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         fp.cohort = (const float*)dC; fp.K = K; fp.MB = (const float*)mb; fp.z = asnorm_tail_z(K, top);
         if (x6) {
             void* planes = (char*)mb + mb_bytes + mom_bytes;
-            if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream, nplanes); }))) return rc;
             fp.planes = planes; fp.nplanes = nplanes;
             fp.nlists = (nplanes == 2 && !h->opt.asnorm_w32) ? 4 : 2;       // the 16-wide-MFMA kernel: four lists per embedding
+            // the default kernel scales its operands by exact powers of two (asnorm_fused.hip, "operand scaling"): the cohort's max |x| goes to
+            // a device word behind the two planes (the buffer is sized for three)
+            uint32_t* pscale = fp.nlists == 4 ? reinterpret_cast<uint32_t*>((char*)planes + (size_t)2 * (D + 32 + K) * D * 2) : nullptr;
+            if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream, nplanes, pscale); }))) return rc;
+            fp.pscale = pscale; fp.dbg = h->opt.asnorm_dbg;
         }
         int c = 0;
         for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
@@ -2414,7 +2434,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_dbg", &o.asnorm_dbg}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

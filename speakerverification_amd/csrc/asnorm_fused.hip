@@ -341,6 +341,33 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
     if (valid) p.cnt[row * 2 + h] = cnt;
 }
 
+// ---- operand scaling of the half-plane forms (round 5) --------------------------------------------------------------------------
+// IEEE-half planes have fp16's exponent range: a component beyond 65504 overflows, one below 2^-14 loses bits of its hi part, and lo is a
+// subnormal (2^-24 absolute) below 2^-3.  Embeddings are not always unit vectors (the reference scores raw embeddings when `normalize` is
+// off: src/model.py:421, utils.py:142-150), so every operand is brought to a fixed magnitude by an EXACT power of two before it is split:
+// a row of the register operand by its own max |x| (found in the kernel, per row), the streamed operand by the max |x| of the whole matrix
+// (absmax_bits_kernel -> a device word the split pass and the kernels read: no host round trip).  max |x| lands in [64, 128): hi is exact
+// to 11 bits and lo a normal half for every component down to 2^-10 of the largest; squares (the AS-norm moment rows) stay below 2^14.
+// Products and sums are formed on the scaled values — binary floating point is scale-invariant, so the fp32 accumulation rounds exactly
+// as it would have — and the result is multiplied back by the exact inverse.  Zero rows keep scale 1; inf / NaN stay inf / NaN.
+__device__ __forceinline__ float pow2_scale_of_bits(uint32_t bits) {      // s = 2^k with (max |x|) * s in [64, 128)
+    const int e = (int)((bits >> 23) & 255u);
+    if (e == 0) return 1.0f;                                              // zero (or subnormal) row: nothing to scale
+    const int se = min(253, max(1, 260 - e));                             // biased exponent of s = 127 + 6 - (e - 127)
+    return __uint_as_float((uint32_t)se << 23);
+}
+__device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }      // s = 2^k, biased k in [1, 253]
+
+// max |x| of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer; a NaN ranks above everything), by atomicMax
+// into *out (zeroed by the caller)
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ X, int64_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(X[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // ---- the two-half-plane form on v_mfma_f32_16x16x32_f16 ("h3w", round 4, the default) -------------------------------------------------
 // Same arithmetic as asnorm_fused6_kernel<D, 2> (hi.hi + hi.lo + lo.hi on IEEE-half planes, fp32 accumulate), on the 16-wide MFMA: on random
 // data the chip holds a higher clock under the 16x16x32 instruction than under 32x32x16 (bare loops: 1.87 against 1.63 PFLOP/s,
@@ -374,10 +401,28 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
         eoff[eg] = (uint32_t)((valid[eg] ? r : p.N - 1) * D);
     }
 
-    // B operand: embedding (16 eg + c), k = 32 s + 8 q .. + 7, as half hi | lo parts
+    // B operand: embedding (16 eg + c), k = 32 s + 8 q .. + 7, as half hi | lo parts of the row SCALED by a power of two (its max |x| in
+    // [64, 128): "operand scaling" above).  With p.pscale the planes are scaled too (cohort and mean row by sC, moment rows by sC^2): every
+    // score of this kernel lives in the scaled domain — the threshold is formed and compared there — and only a stored candidate is
+    // multiplied back (exact).
     bf16x8 bh[2][NS], bl[2][NS];
+    float se[2] = {1.0f, 1.0f}, unscale[2] = {1.0f, 1.0f};
 #pragma unroll
-    for (int eg = 0; eg < 2; ++eg)
+    for (int eg = 0; eg < 2; ++eg) {
+        if (p.pscale) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m = max(m, max(w0[u] & 0x7fffffffu, w1[u] & 0x7fffffffu));
+            }
+            m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+            m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
+            se[eg] = pow2_scale_of_bits(m);
+            unscale[eg] = pow2_inverse(se[eg]) * pow2_inverse(pow2_scale_of_bits(*p.pscale));
+        }
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q);
@@ -385,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
             f16x8 a8, b8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float v = u < 4 ? v0[u] : v1[u - 4];
+                const float v = (u < 4 ? v0[u] : v1[u - 4]) * se[eg];
                 const f16_t a = static_cast<f16_t>(v);
                 a8[u] = a;
                 b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -393,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
             bh[eg][s_] = __builtin_bit_cast(bf16x8, a8);
             bl[eg][s_] = __builtin_bit_cast(bf16x8, b8);
         }
+    }
 
     const int rows_total = NP * 32 + p.K;
     const int nb = (rows_total + 31) / 32;
@@ -468,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                 for (int rg = 0; rg < 2; ++rg) {
                     const f32x4 ev = *reinterpret_cast<const f32x4*>(p.E + eoff[eg] + 32 * b + 16 * rg + 4 * q);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) second[eg] = fmaf(a[rg][eg][u], ev[u], second[eg]);
+                    for (int u = 0; u < 4; ++u) second[eg] = fmaf(a[rg][eg][u], ev[u] * se[eg], second[eg]);      // (scaled domain: sC^2 sE^2 e^T M e)
                 }
         } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of row group 0 of the q = 0 lanes
 #pragma unroll
@@ -544,9 +590,25 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
         valid[eg] = arow[eg] < p.Na;
     }
     bf16x8 bh[2][NS], bl[2][NS];
+    float unscale[2] = {1.0f, 1.0f};            // per row of A: 1 / (its own scale * the scale of the B planes), exact powers of two
 #pragma unroll
     for (int eg = 0; eg < 2; ++eg) {
         const float* src = p.A + (valid[eg] ? arow[eg] : p.Na - 1) * D;
+        float sa = 1.0f;
+        if (p.pscale) {                         // "operand scaling" above: the row by its own max |x|, the planes by the matrix's
+            uint32_t m = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const u32x4 w0 = *reinterpret_cast<const u32x4*>(src + 32 * s_ + 8 * q);
+                const u32x4 w1 = *reinterpret_cast<const u32x4*>(src + 32 * s_ + 8 * q + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m = max(m, max(w0[u] & 0x7fffffffu, w1[u] & 0x7fffffffu));
+            }
+            m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+            m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
+            sa = pow2_scale_of_bits(m);
+            unscale[eg] = pow2_inverse(sa) * pow2_inverse(pow2_scale_of_bits(*p.pscale));
+        }
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 32 * s_ + 8 * q);
@@ -554,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
             f16x8 a8, b8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float v = u < 4 ? v0[u] : v1[u - 4];
+                const float v = (u < 4 ? v0[u] : v1[u - 4]) * sa;
                 const f16_t a = static_cast<f16_t>(v);
                 a8[u] = a;
                 b8[u] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -638,12 +700,13 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 const int j0 = 32 * b + 16 * rg + 4 * q;
+                const f32x4 o4 = acc[rg][eg] * unscale[eg];
                 if (vec_ok && j0 + 4 <= p.Nb) {
-                    __builtin_nontemporal_store(acc[rg][eg], reinterpret_cast<f32x4*>(orow + j0));      // (written once, read by a later kernel at best)
+                    __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(orow + j0));      // (written once, read by a later kernel at best)
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (j0 + e < p.Nb) orow[j0 + e] = acc[rg][eg][e];
+                        if (j0 + e < p.Nb) orow[j0 + e] = o4[e];
                 }
             }
         }
@@ -666,12 +729,15 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
     }
 }
 // ... -> two half planes [2][rows_total][D] (hi, lo) for the three-fp16-MFMA form
+// `pscale` (optional): the max-|x| word of B (absmax_bits_kernel): every row is multiplied by s = pow2_scale_of_bits(*pscale), the first
+// `sq_rows` rows of A (second-moment rows: products of two cohort values) by s^2
 __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
-                                                            f16_t* __restrict__ planes) {
+                                                            f16_t* __restrict__ planes, const uint32_t* __restrict__ pscale, int sq_rows) {
     const int64_t n = (int64_t)(n0 + n1) * D;
+    const float sc = pscale ? pow2_scale_of_bits(*pscale) : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / D;
-        const float v = r < n0 ? A[i] : B[i - (int64_t)n0 * D];
+        const float v = (r < n0 ? A[i] : B[i - (int64_t)n0 * D]) * (r < sq_rows ? sc * sc : sc);
         const f16_t a = static_cast<f16_t>(v);
         planes[i] = a;
         planes[n + i] = static_cast<f16_t>(v - static_cast<float>(a));
@@ -711,7 +777,8 @@ __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __r
         ck[q] = in ? fkey(v) : 0u;
     }
     float m, sd;
-    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd);
+    // (the lists are read as one compacted sequence: slots past ceil(total / 64) per lane are empty, and total >= top was checked above)
+    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd, __builtin_amdgcn_readfirstlane((total + 63) >> 6), true);
     if (lane == 0) { mu[row_base + row] = m; sigma[row_base + row] = sd; }
 }
 
@@ -802,11 +869,16 @@ hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, f
 bool asnorm_fused6_supported(int D, int planes) { return planes == 2 ? (D == 192 || D == 256) : (planes == 3 && D == 192); }
 size_t asnorm_planes_bytes(int D, int K) { return (size_t)3 * (D + 32 + K) * D * 2; }
 
-hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes) {
-    if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0 || !(nplanes == 2 || nplanes == 3)) return hipErrorInvalidValue;
+hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes, uint32_t* pscale) {
+    if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0 || !(nplanes == 2 || nplanes == 3) || (pscale && nplanes != 2)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)(D + 32 + K) * D;
     const int64_t g = (n + 255) / 256;
-    if (nplanes == 2) hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<f16_t*>(planes));
+    if (pscale) {           // the cohort's max |x| -> *pscale; cohort rows and the mean row are scaled by s, the D moment rows by s^2
+        if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
+        const int64_t gc = ((int64_t)K * D + 255) / 256;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(gc > 1024 ? 1024 : gc)), dim3(256), 0, stream, cohort, (int64_t)K * D, pscale);
+    }
+    if (nplanes == 2) hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<f16_t*>(planes), pscale, D);
     else hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
     return hipGetLastError();
 }
@@ -878,7 +950,7 @@ hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* i
 }
 
 bool score_h3w_supported(int D, int64_t Na, int64_t Nb) { return (D == 192 || D == 256) && Na > 0 && Nb > 0 && Nb < ((int64_t)1 << 30) && Na < ((int64_t)1 << 31); }
-size_t score_h3w_planes_bytes(int D, int64_t Nb) { return (size_t)2 * Nb * D * 2; }
+size_t score_h3w_planes_bytes(int D, int64_t Nb) { return (size_t)2 * Nb * D * 2 + 256; }      // two half planes + the scale word of B behind them
 
 // out (Na, ldo) = A (Na, D) . B (Nb, D)^T; `planes` = score_h3w_planes_bytes of scratch (filled here with the half parts of B)
 hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t Nb, int D, float* out, int64_t ldo, void* planes, int num_cu,
@@ -887,9 +959,12 @@ hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t 
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(planes)) & 15) return hipErrorInvalidValue;
     const int64_t n = Nb * D;
     const int64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, B, 0, B, (int)Nb, D, reinterpret_cast<f16_t*>(planes));
+    uint32_t* pscale = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(planes) + (size_t)2 * Nb * D * 2);      // (16-byte aligned: Nb * D * 4 bytes in)
+    if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, stream, B, n, pscale);
+    hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, B, 0, B, (int)Nb, D, reinterpret_cast<f16_t*>(planes), pscale, 0);
     ScoreH3Params p;
-    p.A = A; p.Na = Na; p.planes = planes; p.Nb = (int)Nb; p.out = out; p.ldo = ldo;
+    p.A = A; p.Na = Na; p.planes = planes; p.Nb = (int)Nb; p.out = out; p.ldo = ldo; p.pscale = pscale;
     const int panels = (int)((Na + 127) / 128), nb_all = (int)((Nb + 31) / 32);
     // column slices: enough workgroups for ~4 per CU, at least 8 blocks per slice
     int slices = (4 * (num_cu > 0 ? num_cu : 256) + panels - 1) / panels;

@@ -115,6 +115,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         const int q = G >> 3, r = G & 7, xcd = perm & 7;
         perm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (perm >> 3);
     }
+    // Tail split (round 5; 16-bit pointwise / conv-gather forms): ntiles = q G + R with 0 < R <= G / 2 leaves the last round with R busy
+    // workgroups and G - R idle ones for a whole tile time (the K = 1024 layers of ECAPA at B = 256: 1 604 tiles on 256 CUs = 6.27
+    // rounds, run as 7).  The R tail tiles are then walked as 2 R HALF items, one per workgroup: the tile's 256 frames x 128 of its 256
+    // channels — the W-lo column set of the four-phase K tile (phases 0 and 3: X-lo x W-lo, X-hi x W-lo) for the first half, and the
+    // same code on a channel origin 32 higher for the second (its "W-lo" rows are then the tile's W-hi set).  Phases 1 and 2 keep their
+    // DMA issue, waits, barriers and fragment reads (a skipped W-hi read would keep the old fragments alive across the loop: 16 VGPRs, and
+    // the column-sum instances spilled) and skip their MFMAs; the epilogue runs for j < 2.  Every output element and every
+    // column sum sees the same products in the same order as in a whole tile: bit-identical results.
+    constexpr bool SPLIT_OK = !X3 && !R2;
+    const int qfull = (ntiles / G) * G;
+    const int rtail = ntiles - qfull;
+    const bool split = SPLIT_OK && p.tail_split && qfull > 0 && rtail > 0 && 2 * rtail <= G;
+    const int nitems = split ? qfull + 2 * rtail : ntiles;
+    // item w -> tile index and half selector (0: whole tile, 1: first column half, 2: second)
+    auto item_tile = [&](int w, int& hsel) {
+        if (!split || w < qfull) { hsel = 0; return w; }
+        hsel = 1 + ((w - qfull) & 1);
+        return qfull + ((w - qfull) >> 1);
+    };
     auto tile_of = [&](int w, int& tm, int& tn) {
         const int per = PGROUP_M * ntn;
         const int grp = w / per;
@@ -249,10 +268,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     const unsigned long long tstart = tprev;
 
     int w = perm;                                 // (the host launches G <= ntiles workgroups)
-    int tm, tn;
-    tile_of(w, tm, tn);
-    set_src(tm * 256, tn * 256);
-    issue_consts(tn * 256, 0);
+    int tm, tn, hsel;
+    tile_of(item_tile(w, hsel), tm, tn);
+    set_src(tm * 256, tn * 256 + (hsel == 2 ? 32 : 0));
+    issue_consts(tn * 256 + (hsel == 2 ? 32 : 0), 0);
     issue_prologue();
     bool relaxed = false;                         // the queue holds exactly NST stores behind this tile's first 14 DMAs
     int ntile_done = 0;
@@ -274,13 +293,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     }
 
     for (int it = 0;; ++it) {
-        const int m0 = tm * 256, n0 = tn * 256, par = it & 1;
+        const bool half = SPLIT_OK && hsel != 0;      // wave-uniform: this item is a column half of its tile
+        const int m0 = tm * 256, n0 = tn * 256 + (hsel == 2 ? 32 : 0), par = it & 1;
         const char* cb = smem + RING + par * CST;
         const int w_next = w + G;
-        const bool more = w_next < ntiles;
+        const bool more = w_next < nitems;
         const bool pf = more && !R2;            // the stream runs on into the next tile (R2: its epilogue needs the ring, see there)
-        int tm_n = 0, tn_n = 0;
-        if (more) tile_of(w_next, tm_n, tn_n);
+        int tm_n = 0, tn_n = 0, hsel_n = 0;
+        if (more) tile_of(item_tile(w_next, hsel_n), tm_n, tn_n);
+        const int n0_n = tn_n * 256 + (hsel_n == 2 ? 32 : 0);
         PW3_STAMP(0)
         if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 runs one phase behind group 0
         const int lane = lane_now();
@@ -322,9 +343,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();                                                               \
     }
         // (X3: terms hi.hi, hi.lo, lo.hi of a fragment pair — [0] = hi, [1] = lo — term-major like the plain kernel's k steps)
-#define PW3_MFMA(I0, WARR, J0)                                                                      \
+#define PW3_MFMA(I0, WARR, J0, GUARD)                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                  \
-    if (!(ABL & 1))                                                                                 \
+    if (!(ABL & 1) && (GUARD))                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks)                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
@@ -342,20 +363,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
                 if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
         PW3_PHASE_END(0)                                                                            \
-        PW3_MFMA(0, WCUR, 0)                                                                        \
+        PW3_MFMA(0, WCUR, 0, true)                                                                  \
         HOOK                                                                                        \
         /* phase 1: W-hi(kt); X-lo x W-hi */                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
                 if (!(ABL & 16)) whi[j][ks] = *reinterpret_cast<const bf16x8*>(bb + 3 * HT + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
         PW3_PHASE_END(1)                                                                            \
-        PW3_MFMA(0, whi, 2)                                                                         \
+        PW3_MFMA(0, whi, 2, !half)                                                                  \
         /* phase 2: X-hi(kt); X-hi x W-hi */                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
                 if (!(ABL & 16)) xf[i][ks] = *reinterpret_cast<const bf16x8*>(bb + HT + xoff + i * 2048 + (((ks * 4 + q4) ^ xkey) << 4)); \
         PW3_PHASE_END(2)                                                                            \
-        PW3_MFMA(4, whi, 2)                                                                         \
+        PW3_MFMA(4, whi, 2, !half)                                                                  \
         /* phase 3: W-lo(kt+1) into the other W-lo register set; X-hi x W-lo(kt) */                 \
         {   /* (on the workgroup's last K tile this reads a buffer nobody refilled: unused) */     \
             const char* bn = smem + ((kt + 1) & 1) * 4 * HT + 2 * HT;                               \
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                     if (!(ABL & 16)) WNXT[j][ks] = *reinterpret_cast<const bf16x8*>(bn + woff + j * 2048 + (((ks * 4 + q4) ^ wkey) << 4)); \
         }                                                                                           \
         PW3_PHASE_END(3)                                                                            \
-        PW3_MFMA(4, WCUR, 0)                                                                        \
+        PW3_MFMA(4, WCUR, 0, true)                                                                  \
     }
 #define PW3_ROLL                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         // the stream runs on: after X-hi of this tile's last K tile (phase 0 of K tile nkt - 2) every issue fetches the next tile
         // (nkt is even: buffer parities continue), and the last phase leaves its W-lo(0) in wlo
         PW3_KTILE(2, kt0, wlo, wnx, 0,
-                  if (pf) { set_src(tm_n * 256, tn_n * 256); issue_consts(tn_n * 256, par ^ 1); kbias = nkt; })
+                  if (pf) { set_src(tm_n * 256, n0_n); issue_consts(n0_n, par ^ 1); kbias = nkt; })
         PW3_ROLL
         ++kt0;
         PW3_KTILE(1, kt0, wlo, wnx, 0, )
@@ -499,8 +520,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             copy_out(reinterpret_cast<char*>(p.Y), (int64_t)p.ldy * 4);
             if (more) {         // the next tile starts from scratch, like the first one
                 __builtin_amdgcn_s_barrier();                   // every wave has read its c values: the ring may be refilled
-                set_src(tm_n * 256, tn_n * 256);
-                issue_consts(tn_n * 256, par ^ 1);
+                set_src(tm_n * 256, n0_n);
+                issue_consts(n0_n, par ^ 1);
                 issue_prologue();
                 wait_left(5);
                 __builtin_amdgcn_s_barrier();
@@ -564,7 +585,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             char* Yb = reinterpret_cast<char*>(p.Y);
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) {
-                f32x4 sc[2], sh[2];
+                // a column half: the wave's first 32 channels only (the sums below are formed for all four j; the stores of j >= 2 are masked)
+                if (half && jp == 1) break;
+                                f32x4 sc[2], sh[2];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int nl = wn * 64 + (2 * jp + jj) * 16 + 4 * q4e;
@@ -605,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             const bool whole = (lo + 128 <= rend) && (lo + 128 <= rb || lo >= rb);      // wave-uniform: one segment, every row valid
             float* csp = p.colsum + ((int64_t)(tm * 2 + wm) * 2) * p.N + n0 + wn * 64 + 4 * q4e;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const int jn = half ? 2 : 4;            // a column half owns the sums of its first 32 channels only (the other half item writes the rest)
             // (the zeros that are STORED are made per use: hoisted out of the tile loop they were spilled, and every reload of a spill
             //  is a vector-memory load whose wait also waits for the tile's stores)
             auto fresh_zero4 = [&]() { float z = 0.f; asm volatile("" : "+v"(z)); return f32x4{z, z, z, z}; };
@@ -623,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) s[e] = row16_sum(s[e]);
                         }
-                        if (r16e == 0) {
+                        if (r16e == 0 && j < jn) {
                             *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)sg * p.N) = s;
                             *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)(1 - sg) * p.N) = fresh_zero4();
                         }
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { sa[e] = row16_sum(sa[e]); s1[e] = row16_sum(s1[e]); }
-                        if (r16e == 0) {
+                        if (r16e == 0 && j < jn) {
                             *reinterpret_cast<f32x4*>(cs + j * 16) = sa - s1;
                             *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
                         }
@@ -672,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { s0[e] = row16_sum(s0[e]); s1[e] = row16_sum(s1[e]); }
-                        if (r16e == 0) {
+                        if (r16e == 0 && j < jn) {
                             *reinterpret_cast<f32x4*>(cs + j * 16) = s0;
                             *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
                         }
@@ -686,8 +710,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         ++ntile_done;
         if (!more) break;
         // every row of the tile just stored was inside M: each wave issued exactly NST stores behind the K loop's DMAs
-        relaxed = !R2 && !(ABL & 128) && !(ABL & 8) && (m0 + 256 <= p.M);       // (R2: the store count differs from wave to wave)
-        w = w_next; tm = tm_n; tn = tn_n;
+        relaxed = !R2 && !half && !(ABL & 128) && !(ABL & 8) && (m0 + 256 <= p.M);       // (R2, half items: another store count)
+        w = w_next; tm = tm_n; tn = tn_n; hsel = hsel_n;
     }
     if (DBG3 && (p.debug & 16384) && p.ts) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

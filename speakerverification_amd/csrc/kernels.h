@@ -88,6 +88,7 @@ struct GemmParams {
     int cv_off = 0;                 // developer option cv_off: 16-bit conv-gather GEMMs stay on the per-tile kernel
     int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
                                     // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
+    int tail_split = 1;             // persistent 16-bit GEMMs: a last partial round of <= G / 2 tiles is walked as column halves (gemm_pw3.hip)
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;
     int lda = 0, lda2 = 0, ldy = 0, ld_bu = 0;
@@ -389,6 +390,8 @@ struct AsnormFusedParams {
     int32_t* cnt = nullptr;         // (N, 2) scores above the threshold seen by each of the two lanes (may exceed the list size)
     const void* planes = nullptr;   // optional: [nplanes][D + 32 + K][D] 16-bit parts of [MB ; cohort] (launch_asnorm_planes): the split forms
     int nplanes = 2;                // 2: half hi | lo, three fp16 MFMAs per product block (default); 3: bf16 h | m | l, six bf16 MFMAs
+    int dbg = 0;                    // developer ablations of the 16-wide kernel (option asnorm_dbg): 1 = count candidates, store none (timing only)
+    const uint32_t* pscale = nullptr;   // the 16-wide half-plane kernel: max-|x| word of the cohort the planes were scaled by (launch_asnorm_planes)
     int nlists = 2;                 // candidate lists per embedding: 2 (cnt (N, 2), lists of ASNORM_CAND_PER_LANE), or 4 with nplanes = 2: the
                                     // 16-wide-MFMA kernel (cnt (N, 4), lists of ASNORM_CAND_PER_LANE / 2)
 };
@@ -401,6 +404,7 @@ struct ScoreH3Params {
     float* out = nullptr;
     int64_t ldo = 0;
     int per = 0;                    // blocks of 32 rows of B per workgroup (column slice)
+    const uint32_t* pscale = nullptr;   // max-|x| word of B: the planes hold B * 2^k (asnorm_fused.hip, "operand scaling")
 };
 bool score_h3w_supported(int D, int64_t Na, int64_t Nb);
 size_t score_h3w_planes_bytes(int D, int64_t Nb);
@@ -408,7 +412,8 @@ hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t 
                             hipStream_t stream);
 bool asnorm_fused6_supported(int D, int planes);
 size_t asnorm_planes_bytes(int D, int K);
-hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes = 2);
+// pscale (two half planes only): a device word that receives the cohort's max |x|; the planes are then scaled by an exact power of two
+hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int D, void* planes, hipStream_t stream, int nplanes = 2, uint32_t* pscale = nullptr);
 bool asnorm_fused_supported(int D, int K, int top);
 float asnorm_tail_z(int K, int top);
 // `part`: cohort_moments_scratch_bytes(D) of scratch (slice partials, summed in a fixed order)

@@ -1000,8 +1000,12 @@ int rn_tail_slices(int dt, int B, int Tn, int C, int num_cu) {
         if (C < 256 || Tn > 48) return 0;
         return (Tn + 15) / 16;
     }
-    // small batches: the slice count depends on the utterance alone (about 48 frames per slice), never on the batch: an utterance's column
-    // mean is summed in the same order whatever batch (or batch slice: option lanes) it rides in
+    // small batches: WITHIN this branch the slice count depends on the utterance alone (about 48 frames per slice).  Which branch a call
+    // takes does depend on its batch (B * 4 > CUs above; launch_rn_afms_gate and launch_rowvec_linear switch kernels at B = 64 as well,
+    // and with option `lanes` it is the lane's share of B that counts): an utterance's column means are then summed in another order, and its
+    // embedding moves by fp32 round-off with the batch it rides in — measured at the B = 64 | 65 boundary: 5.5e-6 of the embedding scale
+    // on f32x3 handles, 1.1e-5 on f32 (tests/test_gpu_rawnet2.py::test_an_utterance_embeds_alike_on_both_sides_of_the_batch_size_switches).
+    // INTEGRATION.md states the bound.
     int S = (Tn + 47) / 48;
     if (S > TAILS_MAX_S) S = TAILS_MAX_S;
     return S >= 2 ? S : 0;

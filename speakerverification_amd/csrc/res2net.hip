@@ -294,8 +294,8 @@ hipError_t launch_cw(const Res2Params& p, int grid, hipStream_t stream) {
 
 }  // namespace
 
-// time slices for small batches: the smallest S >= 2 whose slices (core + two halos of 7 * dil frames) fit the short LDS image and whose
-// S * B workgroups are all resident at once (two per CU: 80 / 48 KiB of LDS each); 1 = whole utterances
+// time slices for small batches: the LARGEST S in 2 .. 7 whose slices (core + two halos of 7 * dil frames) fit the short LDS image, whose
+// core is longer than its halo and whose S * B workgroups are all resident at once (80 / 48 KiB of LDS each); 1 = whole utterances
 int res2net_chain_slices(int B, int C, int T, int dil, int num_cu) {
     const int cw = C / 8;
     const int tmax_s = cw == 128 ? R2Cfg<128, 3>::TMAX : R2Cfg<64, 2>::TMAX;
@@ -320,9 +320,14 @@ hipError_t launch_res2net_chain(const Res2Params& p_in, int B, int C, hipStream_
     Res2Params p = p_in;
     if (p.slices > 1) {
         const int tmax_s = C / 8 == 128 ? R2Cfg<128, 3>::TMAX : R2Cfg<64, 2>::TMAX;
-        p.Tc = (p.T + p.slices - 1) / p.slices;
-        if (p.Tc + 14 * p.dil > tmax_s || p.Tc <= 14 * p.dil) return hipErrorInvalidValue;
-        return C / 8 == 128 ? launch_cw<128, 3>(p, B * p.slices, stream) : launch_cw<64, 2>(p, B * p.slices, stream);
+        // a slice count that does not fit (the developer option r2_slices forces one): the nearest smaller count that does, down to whole
+        // utterances — never a failed forward
+        while (p.slices > 1) {
+            p.Tc = (p.T + p.slices - 1) / p.slices;
+            if (p.Tc + 14 * p.dil <= tmax_s && p.Tc > 14 * p.dil) break;
+            --p.slices;
+        }
+        if (p.slices > 1) return C / 8 == 128 ? launch_cw<128, 3>(p, B * p.slices, stream) : launch_cw<64, 2>(p, B * p.slices, stream);
     }
     p.slices = 1;
     return C / 8 == 128 ? launch_cw<128, 7>(p, B, stream) : launch_cw<64, 4>(p, B, stream);

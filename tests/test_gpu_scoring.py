@@ -315,6 +315,51 @@ def test_whole_trial_scoring_modes(eng, n_files, n_crops, D, P):
         eng.score_trials(F, np.array([n_files], np.int32), np.array([0], np.int32), "cosine")      # index out of range
 
 
+@pytest.mark.parametrize("sa,sb", [(1.0, 1.0), (3.0e5, 1.0), (1.0e-6, 1.0e-6), (7.0e6, 2.0e-7), (40.0, 1.0e5)])
+def test_half_plane_score_kernels_take_operands_of_any_magnitude(sa, sb):
+    """since round 4 the dense score GEMMs and the AS-norm kernel carry their operands as IEEE-half hi | lo planes — on
+    every handle, the 'exact' scoring handle included — and the reference scores RAW embeddings when `normalize` is off.  Round 4 clamped
+    |x| > 65504 silently and lost the low bits of components below 2^-3.  Round 5 scales every operand by an exact power of two first
+    (a row by its own max |x|, the streamed matrix by its global max |x|; asnorm_fused.hip "operand scaling"): embeddings of norm 3e5,
+    1e-6, 7e6 x 2e-7 ... against the float64 statement, relative to |a| |b| — the bar of the unit-vector test, 2e-7.  One row holds a
+    component 2^-20 of its largest (it must not vanish), one is all zeros."""
+    eng = Engine(model="none", max_batch=1)
+    rng = np.random.Generator(np.random.PCG64(77))
+    Na, Nb, D, K, top = 300, 517, 192, 5994, 200      # (K = 5994: the fused AS-norm kernel; smaller cohorts take the slab path)
+    A = rng.standard_normal((Na, D)).astype(np.float32); A /= np.linalg.norm(A, axis=1, keepdims=True)
+    B = rng.standard_normal((Nb, D)).astype(np.float32); B /= np.linalg.norm(B, axis=1, keepdims=True)
+    A[7, 1:] *= np.float32(2.0 ** -20)                                  # one dominant component, the rest 2^-20 of it
+    A[9] = 0.0
+    A, B = (A * np.float32(sa)).astype(np.float32), (B * np.float32(sb)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64).T
+    got = eng.score_matrix(A, B)
+    na, nb = np.linalg.norm(A.astype(np.float64), axis=1), np.linalg.norm(B.astype(np.float64), axis=1)
+    rel = np.abs(got - want) / np.maximum(np.outer(na, nb), 1e-300)
+    rel[9] = np.abs(got[9])                                              # the zero row: exactly zero
+    print(f"score_matrix, |a| = {sa:g}, |b| = {sb:g}: max error {rel.max():.2e} of |a||b|")
+    assert np.isfinite(got).all() and float(rel.max()) <= 2e-7
+    # AS-norm statistics of un-normalised embeddings against an un-normalised cohort: mu and sigma scale with |e| |c|
+    E = A[:256].copy()
+    E[9] = E[10]
+    C = rng.standard_normal((K, D)).astype(np.float32); C /= np.linalg.norm(C, axis=1, keepdims=True)
+    C = (C * np.float32(sb)).astype(np.float32)
+    mu, sd = eng.asnorm_stats(E, C, top)
+    rmu, rsd = o_scoring.asnorm_stats(E.astype(np.float64), C.astype(np.float64), top)
+    scale = np.linalg.norm(E.astype(np.float64), axis=1) * float(sb)
+    emu = float(np.max(np.abs(mu - rmu) / scale)); esd = float(np.max(np.abs(sd - rsd) / scale))
+    print(f"asnorm_stats: mu within {emu:.2e}, sigma within {esd:.2e} of |e| |c|; fallback rows {eng.asnorm_last_fallback}")
+    assert emu <= 2e-7 and esd <= 2e-6 and eng.asnorm_last_fallback >= 0       # (>= 0: the fused kernel ran; some rows may have been handed over)
+    eng.set_option("asnorm_slab", 1)                                      # the slab path: score_h3w + the top-k kernel
+    mu2, sd2 = eng.asnorm_stats(E, C, top)
+    eng.set_option("asnorm_slab", 0)
+    assert float(np.max(np.abs(mu2 - rmu) / scale)) <= 2e-7 and float(np.max(np.abs(sd2 - rsd) / scale)) <= 2e-6
+    # a NaN component stays a NaN in its row of the score matrix, and nowhere else
+    A2 = A.copy(); A2[3, 5] = np.nan
+    g2 = eng.score_matrix(A2, B)
+    assert np.isnan(g2[3]).all() and np.array_equal(np.delete(g2, 3, axis=0), np.delete(got, 3, axis=0))
+    eng.close()
+
+
 def test_pnorm_similarity_for_any_p_matches_the_reference(eng, golden_dir):
     """VERDICT r4 item 7b / ADVICE r3: pnorm_similarity(ref, com, p) (src/utils.py:167-169 -> F.pairwise_distance(p=p, eps=1e-6)) raised
     for p != 2.  svhip_score_trials_pnorm serves every p torch does: golden values generated by the reference itself

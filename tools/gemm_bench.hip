@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
         for (int debug : debugs) {
             p.debug = debug;
             p.cv_off = (debug & 32768) ? 1 : 0;            // 32768: conv-gather shapes on the per-tile kernel
+            p.tail_split = (debug & 65536) ? 0 : 1;        // 65536: the persistent kernel's last partial round as whole tiles (round 4)
             if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; } else { p.colsum = nullptr; }
             for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
             CK(hipStreamSynchronize(st));
