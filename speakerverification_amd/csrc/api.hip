@@ -75,7 +75,6 @@ struct svhip_handle {
         int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
         int score_tiled = 0;      // dense score GEMMs on the tiled split kernel (gemm_pw) instead of the row-streaming one (score_h3w)
         int asnorm_w32 = 0;       // AS-norm two-half-plane kernel on the 32-wide MFMA (round 4's first form) instead of 16x16x32
-        int asnorm_dbg = 0;       // developer ablations of the AS-norm kernel (AsnormFusedParams::dbg; results are then wrong: timing only)
         int asnorm_2s = 0;        // AS-norm split forms: candidate statistics of chunk c on a second stream under the matrix kernel of chunk c + 1
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
@@ -2189,7 +2188,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         const size_t mom_bytes = (cohort_moments_scratch_bytes(D) + 255) & ~(size_t)255;
         if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + mom_bytes + (x6 ? asnorm_planes_bytes(D, K) : 0), &mb))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CAND, cand_elems * 4 * nbuf, &cand))) return rc;
-        if ((rc = scratch(h, svhip_handle::SCR_CNT, cnt_elems * 4 * nbuf, &cnt))) return rc;
+        if ((rc = scratch(h, svhip_handle::SCR_CNT, (cnt_elems + (size_t)chunk) * 4 * nbuf, &cnt))) return rc;      // per buffer: [counts (chunk, 4) | row factors (chunk)]
         if ((rc = scratch(h, svhip_handle::SCR_FLAG, (size_t)(N + 1) * 4, &flag))) return rc;
         if (nbuf == 2 && !h->aux_stream) {
             SV_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
@@ -2208,14 +2207,15 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             // a device word behind the two planes (the buffer is sized for three)
             uint32_t* pscale = fp.nlists == 4 ? reinterpret_cast<uint32_t*>((char*)planes + (size_t)2 * (D + 32 + K) * D * 2) : nullptr;
             if ((rc = run(h, "asnorm_planes", 0, [&]() { return launch_asnorm_planes((const float*)mb, (const float*)dC, K, D, planes, h->stream, nplanes, pscale); }))) return rc;
-            fp.pscale = pscale; fp.dbg = h->opt.asnorm_dbg;
+            fp.pscale = pscale;
         }
         int c = 0;
         for (int64_t r0 = 0; r0 < N; r0 += chunk, ++c) {
             const int64_t rows = std::min(chunk, N - r0);
             const int b = c & (nbuf - 1);
             fp.E = (const float*)dE + r0 * D; fp.N = rows;
-            fp.cand = (float*)cand + b * cand_elems; fp.cnt = (int32_t*)cnt + b * cnt_elems;
+            fp.cand = (float*)cand + b * cand_elems; fp.cnt = (int32_t*)cnt + b * (cnt_elems + (size_t)chunk);
+            fp.rowscale = fp.pscale ? reinterpret_cast<float*>(fp.cnt + cnt_elems) : nullptr;
             if (nbuf == 2 && c >= 2) SV_HIP(h, hipStreamWaitEvent(h->stream, h->aux_ev[2 + b], 0));       // the statistics of chunk c - 2 have read this buffer
             if ((rc = run(h, "asnorm_fused", 2.0 * rows * K * D, [&]() { return launch_asnorm_fused(fp, D, h->stream); }))) {
                 if (nbuf == 2 && h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
@@ -2229,7 +2229,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             }
             h->cur = st2;
             rc = run(h, "asnorm_cand_stats", 0, [&]() {
-                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2, fp.nlists);
+                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2, fp.nlists, fp.rowscale);
             });
             h->cur = h->stream;
             if (rc) {           // leave no aux-stream work pending behind a failed call
@@ -2434,7 +2434,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_dbg", &o.asnorm_dbg}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

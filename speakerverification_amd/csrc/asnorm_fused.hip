@@ -19,6 +19,8 @@
 //
 // Work per embedding: 2 K D FLOP on the fp32 matrix pipe (157 TFLOP/s peak), ~K/32 x 24 KB of LDS-DMA per 128 embeddings from an
 // L2 / Infinity-Cache resident cohort, ~1.6 top x 4 bytes of candidate stores.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "score_select.h"
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
 
     // B operand: embedding (16 eg + c), k = 32 s + 8 q .. + 7, as half hi | lo parts of the row SCALED by a power of two (its max |x| in
     // [64, 128): "operand scaling" above).  With p.pscale the planes are scaled too (cohort and mean row by sC, moment rows by sC^2): every
-    // score of this kernel lives in the scaled domain — the threshold is formed and compared there — and only a stored candidate is
-    // multiplied back (exact).
+    // score of this kernel lives in the scaled domain — the threshold is formed and compared there, the candidates are stored there — and
+    // the candidate kernel multiplies a row's mean and deviation back by p.rowscale[row] (exact).
     bf16x8 bh[2][NS], bl[2][NS];
     float se[2] = {1.0f, 1.0f}, unscale[2] = {1.0f, 1.0f};
 #pragma unroll
@@ -523,23 +525,38 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                 float sec = second[eg];
                 sec += __shfl_xor(sec, 16, 64);
                 sec += __shfl_xor(sec, 32, 64);
-                tau[eg] = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+                // (rows past N never hit: no separate validity test in the selection below)
+                tau[eg] = valid[eg] ? m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f)) : __builtin_inff();
             }
         } else {
-            const int kb = (b - NP) * 32 + 4 * q;
+            // The selection, 32 scores per lane per block.  It issues for the whole wave whenever ONE lane hits (4.7 % of the scores pass:
+            // 95 % of the instructions see a hit somewhere), so what counts is its instruction count, not how rarely a lane stores.  Round 4's
+            // form — row-bound test, threshold test, list-capacity test as nested ifs, a 64-bit store address — was ~7 vector + ~8 scalar
+            // instructions and two branches per score: ~1.7 k issue cycles per block beside 1.15 k of MFMAs.  Now: one compare, a clamped slot
+            // (an overflowing list is flagged by its count and never read, so its last slot may be overwritten), a 32-bit offset from the
+            // scalar base, one masked store, one add; the row-bound test exists only in the cohort's last block.
+            const int kb0 = (b - NP) * 32;
+            char* cbase = reinterpret_cast<char*>(p.cand);
+            auto select = [&](auto bounded) {                   // bounded: the cohort's last block, whose rows past K repeat row K - 1
 #pragma unroll
-            for (int eg = 0; eg < 2; ++eg)
+                for (int eg = 0; eg < 2; ++eg)
 #pragma unroll
-                for (int rg = 0; rg < 2; ++rg)
+                    for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = kb + 16 * rg + u;
-                        const float v = a[rg][eg][u];
-                        if (i < p.K && v > tau[eg]) {
-                            if (cnt[eg] < CAPQ && valid[eg]) p.cand[coff[eg] + cnt[eg]] = v;
-                            ++cnt[eg];
+                        for (int u = 0; u < 4; ++u) {
+                            const float v = a[rg][eg][u];
+                            bool hit = v > tau[eg];
+                            if (decltype(bounded)::value) hit = hit && (kb0 + 4 * q + 16 * rg + u < p.K);
+                            if (hit) {
+                                uint32_t off = (coff[eg] + (uint32_t)min(cnt[eg], CAPQ - 1)) << 2;
+                                asm volatile("" : "+v"(off));      // (keeps the zero-extension out of the address: scalar base + 32-bit vector offset)
+                                *reinterpret_cast<float*>(cbase + off) = v;
+                            }
+                            if (hit) ++cnt[eg];
                         }
-                    }
+            };
+            if (kb0 + 32 <= p.K) select(std::false_type{});     // (wave-uniform)
+            else select(std::true_type{});
         }
     };
 
@@ -560,7 +577,10 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
     process(accp, nb - 1);
 #pragma unroll
     for (int eg = 0; eg < 2; ++eg)
-        if (valid[eg]) p.cnt[(row0 + 16 * eg) * 4 + q] = cnt[eg];
+        if (valid[eg]) {
+            p.cnt[(row0 + 16 * eg) * 4 + q] = cnt[eg];
+            if (q == 0 && p.rowscale) p.rowscale[row0 + 16 * eg] = unscale[eg];
+        }
 }
 
 // ---- dense score matrix on the same machinery: out[i][j] = A_i . B_j (svhip_score_matrix, the slab path's cohort GEMM) --------------------
@@ -749,11 +769,20 @@ __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restr
 template <int NL>
 __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cnt, int64_t rows,
                                                                 int top, float* __restrict__ mu, float* __restrict__ sigma,
-                                                                int64_t row_base, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag) {
+                                                                int64_t row_base, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag,
+                                                                const float* __restrict__ rowscale) {
     constexpr int CAP = 2 * AF_CAPL / NL;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // every slot of the row is loaded at once, BEFORE the counts are known — one memory round trip instead of two (this kernel is one wave per
+    // embedding and lives on latency); a slot past its list's count becomes key 0 below.  (Never-written slots hold whatever the scratch
+    // held: they are masked by the counts.)
+    const float* c = cand + row * 2 * AF_CAPL;
+    uint32_t ck[2 * AF_CAPL / 64];
+    float cv[2 * AF_CAPL / 64];
+#pragma unroll
+    for (int q = 0; q < 2 * AF_CAPL / 64; ++q) cv[q] = __builtin_nontemporal_load(c + lane + 64 * q);
     int cn[NL], total = 0;
     bool over = false;
 #pragma unroll
@@ -762,24 +791,20 @@ __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __r
         if (lane == 0) flagged[atomicAdd(nflag, 1)] = (int32_t)(row_base + row);
         return;
     }
-    const float* c = cand + row * 2 * AF_CAPL;
-    uint32_t ck[2 * AF_CAPL / 64];
 #pragma unroll
     for (int q = 0; q < 2 * AF_CAPL / 64; ++q) {
-        int idx = lane + 64 * q;            // position in the concatenation of the lists
-        float v = 0.0f;
-        bool in = false;
+        const int pos = lane + 64 * q, l = pos / CAP, idx = pos - l * CAP;
+        int cl = 0;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            if (!in && idx >= 0 && idx < cn[l]) { v = c[l * CAP + idx]; in = true; }
-            idx -= cn[l];
-        }
-        ck[q] = in ? fkey(v) : 0u;
+        for (int k = 0; k < NL; ++k) cl = l == k ? cn[k] : cl;
+        ck[q] = idx < cl ? fkey(cv[q]) : 0u;
     }
     float m, sd;
-    // (the lists are read as one compacted sequence: slots past ceil(total / 64) per lane are empty, and total >= top was checked above)
-    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd, __builtin_amdgcn_readfirstlane((total + 63) >> 6), true);
-    if (lane == 0) { mu[row_base + row] = m; sigma[row_base + row] = sd; }
+    // (total >= top populated keys was checked above: the search may start below the bits they share)
+    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd, 2 * AF_CAPL / 64, true);
+    // (candidates of the scaled kernels are stored in the scaled domain: mean and deviation are linear in the scale, a power of two)
+    const float rs = rowscale ? rowscale[row] : 1.0f;
+    if (lane == 0) { mu[row_base + row] = m * rs; sigma[row_base + row] = sd * rs; }
 }
 
 // MB = [M ; cbar ; 0]: M[i][j] = (1/K) sum_k C[k][i] C[k][j] (D x D), cbar[j] = (1/K) sum_k C[k][j].
@@ -890,6 +915,8 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
     if (p.nlists != 2 && !(p.nlists == 4 && p.planes && p.nplanes == 2)) return hipErrorInvalidValue;      // (four lists: the 16-wide half-plane kernel only)
     if (p.planes) {                                       // the split forms: three fp16 MFMAs on two half planes / six bf16 MFMAs on three
         if (!asnorm_fused6_supported(D, p.nplanes) || (reinterpret_cast<uintptr_t>(p.planes) & 15) || p.N > (int64_t)1 << 21) return hipErrorInvalidValue;      // (32-bit lane offsets)
+        if (p.nlists == 4 && p.N * 2 * ASNORM_CAND_PER_LANE * 4 >= (int64_t)1 << 32) return hipErrorInvalidValue;      // (32-bit byte offsets into the candidate lists)
+        if (p.pscale && (p.nlists != 4 || !p.rowscale)) return hipErrorInvalidValue;                                    // (scaled planes: the 16-wide kernel, with its row factors)
         const dim3 grid((unsigned)((p.N + 127) / 128));
 #define SV_AF6(DD, NP)                                                                                                      \
         {                                                                                                                   \
@@ -925,14 +952,14 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
 }
 
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
-                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists) {
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists, const float* rowscale) {
     if (rows <= 0) return hipSuccess;
     if (nlists == 4)
         hipLaunchKernelGGL(asnorm_cand_stats_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
-                           flagged, nflag);
+                           flagged, nflag, rowscale);
     else if (nlists == 2)
         hipLaunchKernelGGL(asnorm_cand_stats_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
-                           flagged, nflag);
+                           flagged, nflag, rowscale);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

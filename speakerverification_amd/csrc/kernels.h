@@ -390,7 +390,8 @@ struct AsnormFusedParams {
     int32_t* cnt = nullptr;         // (N, 2) scores above the threshold seen by each of the two lanes (may exceed the list size)
     const void* planes = nullptr;   // optional: [nplanes][D + 32 + K][D] 16-bit parts of [MB ; cohort] (launch_asnorm_planes): the split forms
     int nplanes = 2;                // 2: half hi | lo, three fp16 MFMAs per product block (default); 3: bf16 h | m | l, six bf16 MFMAs
-    int dbg = 0;                    // developer ablations of the 16-wide kernel (option asnorm_dbg): 1 = count candidates, store none (timing only)
+    float* rowscale = nullptr;      // the 16-wide half-plane kernel with pscale: (N) factor that takes a row's candidates (stored in the scaled
+                                    // domain) back to scores: asnorm_cand_stats multiplies mu and sigma by it
     const uint32_t* pscale = nullptr;   // the 16-wide half-plane kernel: max-|x| word of the cohort the planes were scaled by (launch_asnorm_planes)
     int nlists = 2;                 // candidate lists per embedding: 2 (cnt (N, 2), lists of ASNORM_CAND_PER_LANE), or 4 with nplanes = 2: the
                                     // 16-wide-MFMA kernel (cnt (N, 4), lists of ASNORM_CAND_PER_LANE / 2)
@@ -422,7 +423,7 @@ hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, f
 hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t stream);
 // mu / sigma [row_base + r] for r < rows; embeddings that cannot be decided from their candidates: flagged[atomicAdd(nflag, 1)] = index
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
-                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists = 2);
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists = 2, const float* rowscale = nullptr);
 hipError_t launch_gather_rows(const float* E, const int32_t* ids, int n, int D, float* out, hipStream_t stream);
 hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* ids, int n, float* mu, float* sigma, hipStream_t stream);
 
