@@ -373,7 +373,8 @@ GemmRoute gemm_route(const GemmParams& p, bool bf16) {
         const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
         const bool pw3 = !no_pw3 && gemm_pw3_supported(p, bf16);
         // (a capped persistent grid — the test switch SVHIP_PW3_CUS — also takes the small grids that would go to the narrow tile)
-        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu && !(pw3 && pw3_grid_cap(p) < p.num_cu)) return ROUTE_PW_NARROW;
+        // (round 5: the persistent kernel walks such a grid as column halves of its 256 x 256 tiles — pw3_half_off keeps the narrow tile)
+        if (pw && !no_narrow && !p.colsum && 2 * tiles <= p.num_cu && !(pw3 && (pw3_grid_cap(p) < p.num_cu || p.tail_split))) return ROUTE_PW_NARROW;
         if (pw3) return ROUTE_PW3;
         return ROUTE_PW2;
     }

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     constexpr bool SPLIT_OK = !X3 && !R2;
     const int qfull = (ntiles / G) * G;
     const int rtail = ntiles - qfull;
-    const bool split = SPLIT_OK && p.tail_split && qfull > 0 && rtail > 0 && 2 * rtail <= G;
+    // (qfull == 0: a grid of 2 * ntiles workgroups over ntiles <= CUs / 2 tiles — a small batch — walks nothing but halves, one each)
+    const bool split = SPLIT_OK && p.tail_split && rtail > 0 && 2 * rtail <= G;
     const int nitems = split ? qfull + 2 * rtail : ntiles;
     // item w -> tile index and half selector (0: whole tile, 1: first column half, 2: second)
     auto item_tile = [&](int w, int& hsel) {
@@ -727,13 +728,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #undef PW3_STAMP
 }
 
+// workgroups of a persistent launch: the grid cap, or one per tile — or, for the 16-bit pointwise form with the tail split on, one per
+// column half when the tiles fill at most half of the capped grid (small batches: 128 tiles of a K = 1024 layer at B = 20 become 256 halves)
+inline int pw3_grid(const GemmParams& p, int ntiles, bool splittable) {
+    const int cap = pw3_grid_cap(p);
+    if (ntiles >= cap) return cap;
+    return (splittable && p.tail_split && 2 * ntiles <= cap) ? 2 * ntiles : ntiles;
+}
+
 template <int EPI, int CS, bool X3>
 hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS, X3>), PW3_LDS)) return e;
-    const int cap = pw3_grid_cap(p);
-    const int grid = ntiles < cap ? ntiles : cap;
+    const int grid = pw3_grid(p, ntiles, !X3);
     hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS, X3>), dim3(grid), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
 }
@@ -789,7 +797,8 @@ bool gemm_pw3_supported(const GemmParams& p, bool bf16) {
     if (p.act2 != ACT_NONE || !(p.act1 == ACT_NONE || p.act1 == ACT_RELU || p.act1 == ACT_GELU)) return false;
     if (p.num_cu <= 0 || p.num_cu > 1024) return false;
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
-    return ntiles > pw3_grid_cap(p);
+    // more tiles than workgroups (something to overlap an epilogue with), or so few that every tile can be walked as two column halves
+    return ntiles > pw3_grid_cap(p) || (p.tail_split && 2 * ntiles <= pw3_grid_cap(p) && pw3_grid_cap(p) <= p.num_cu);
 }
 
 // developer option pw3_cus = n (GemmParams::pw3_cus, from the handle: SVHIP_PW3_CUS at svhip_create or svhip_set_option): launch at

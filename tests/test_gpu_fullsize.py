@@ -247,16 +247,21 @@ def test_profile_filter_brackets_only_the_named_kernel():
     eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=512), seed=2))
     eng.finalize()
     wav = synth.synth_waveforms(8, 32000)
-    eng.profile(True, only="gemm_pw2")
-    eng.embed_wave(wav)
-    only = eng.profile_results()
-    # (how many of the 7 big GEMMs take the 256 x 256 kernel depends on the grid: small grids route to gemm_pw's narrower tile)
-    assert set(only) == {"gemm_pw2"} and 1 <= only["gemm_pw2"]["launches"] <= 7 and only["gemm_pw2"]["ms"] > 0
+    # (which kernel the 7 big GEMMs take depends on the grid: at B = 8 the persistent kernel walks their few tiles as column halves —
+    #  round 5 — and what it does not take goes to the per-tile 256 x 256 kernel or gemm_pw's narrower tile)
     eng.profile(True)
     eng.embed_wave(wav)
     every = eng.profile_results()
-    assert {"fbank", "gemm_pw2", "res2net_slices", "asp_bf16", "se_apply"} <= set(every)         # (B = 8: the time-sliced chain)
-    assert every["gemm_pw2"]["launches"] == only["gemm_pw2"]["launches"]
+    assert {"fbank", "res2net_slices", "asp_bf16", "se_apply"} <= set(every)         # (B = 8: the time-sliced chain)
+    label = "gemm_pw3" if "gemm_pw3" in every else "gemm_pw2"
+    assert 1 <= every[label]["launches"] <= 7
+    eng.profile(True, only=label)
+    eng.embed_wave(wav)
+    only = eng.profile_results()
+    assert set(only) == {label} and only[label]["launches"] == every[label]["launches"] and only[label]["ms"] > 0
+    eng.profile(True)
+    eng.embed_wave(wav)
+    every = eng.profile_results()
     eng.profile(False)
     eng.embed_wave(wav)
     assert eng.profile_results() == every            # nothing recorded while profiling is off
