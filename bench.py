@@ -14,13 +14,14 @@ assembled with ONE RCCL all-gather at the end of the timed region (reference: al
 issued through the C ABI (svhip_allgather_rows) on the library's stream; torch.distributed (gloo) only carries the
 128-byte RCCL id, the barriers and the max-over-ranks of the wall time.
 
-Prints ONE JSON line on rank 0 (field contract: README / DESIGN.md §5): `value` is whole-job embeddings/s; `roofline` is
-the dominant kernel (the pointwise-conv MFMA GEMM) timed with HIP events on the launch stream inside the timed region;
-`cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample (rank 0, N = 1 only); sub-records:
-`check` (the last timed step's embeddings verified against the fp32-parity path and a bitwise re-run), `scoring`
-(BASELINE configs[3] + CPU baselines), `rawnet2` (configs[2]), `ecapa_f32` / `ecapa_f32x3` (the 1e-4-parity paths: exact fp32
-MFMA / split-bf16 MFMA triples on fp32 operands), `pcie` (int16 PCM over
-PCIe -> device crop -> embed), `shard` (multi-GPU: all-gather + row-sharded scoring of the gathered matrix).
+stdout carries exactly ONE JSON line on rank 0, compact (<= 4 KB: `compact_headline`; the driver keeps a bounded tail of stdout and
+round 4's 20 KB line did not parse): the contract's fields; `roofline` = the dominant kernel (the pointwise-conv MFMA GEMM) timed with HIP
+events on the launch stream inside the timed region; `cpu_baseline` = the CPU oracle timed on this box's host cores on a bounded sample
+(rank 0, N = 1 only); `check` (the last timed step's embeddings verified against the fp32-parity path and a bitwise re-run); `sustained`;
+`sub` = {record name: embeddings/s} and `scoring` = the BASELINE configs[3] summary (trial pairs/s).  The sub-records themselves — `kernels`
+(per-kernel table), `scoring` (+ CPU baselines), `rawnet2` (configs[2]), `ecapa_f32` / `ecapa_f32x3` / `rawnet2_f32x3` (the 1e-4-parity
+paths), `latency` (B = 1 .. 32 per call), `fusion`, `pcie`, `headline_full` — are written one JSON line each, tagged {"record": name}, to
+stderr as they are measured and to --record-file (default gpurun_out/bench_records.jsonl).
 """
 from __future__ import annotations
 
