@@ -362,12 +362,25 @@ __device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float(
 
 // max |x| of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer; a NaN ranks above everything), by atomicMax
 // into *out (zeroed by the caller)
+// (16-byte loads, one atomic per workgroup: with one per wave of a 1 024-workgroup grid the 4 096 atomics on one word WERE the kernel, 50 us)
 __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ X, int64_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t wm[4];
     uint32_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(X[i]) & 0x7fffffffu);
+    const int64_t n4 = n >> 2;
+    const u32x4* __restrict__ X4 = reinterpret_cast<const u32x4*>(X);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const u32x4 v = X4[i];
+        m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(X[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m) atomicMax(out, m);
+    }
 }
 
 // ---- the two-half-plane form on v_mfma_f32_16x16x32_f16 ("h3w", round 4, the default) -------------------------------------------------
@@ -901,7 +914,7 @@ hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int
     if (pscale) {           // the cohort's max |x| -> *pscale; cohort rows and the mean row are scaled by s, the D moment rows by s^2
         if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
         const int64_t gc = ((int64_t)K * D + 255) / 256;
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(gc > 1024 ? 1024 : gc)), dim3(256), 0, stream, cohort, (int64_t)K * D, pscale);
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(gc > 1024 ? 256 : (gc + 3) / 4)), dim3(256), 0, stream, cohort, (int64_t)K * D, pscale);
     }
     if (nplanes == 2) hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<f16_t*>(planes), pscale, D);
     else hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
@@ -988,7 +1001,7 @@ hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t 
     const int64_t g = (n + 255) / 256;
     uint32_t* pscale = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(planes) + (size_t)2 * Nb * D * 2);      // (16-byte aligned: Nb * D * 4 bytes in)
     if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, stream, B, n, pscale);
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(g > 1024 ? 256 : (g + 3) / 4)), dim3(256), 0, stream, B, n, pscale);
     hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, B, 0, B, (int)Nb, D, reinterpret_cast<f16_t*>(planes), pscale, 0);
     ScoreH3Params p;
     p.A = A; p.Na = Na; p.planes = planes; p.Nb = (int)Nb; p.out = out; p.ldo = ldo; p.pscale = pscale;
