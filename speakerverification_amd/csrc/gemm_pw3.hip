@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     // DMA issue, waits, barriers and fragment reads (a skipped W-hi read would keep the old fragments alive across the loop: 16 VGPRs, and
     // the column-sum instances spilled) and skip their MFMAs; the epilogue runs for j < 2.  Every output element and every
     // column sum sees the same products in the same order as in a whole tile: bit-identical results.
-    constexpr bool SPLIT_OK = !X3 && !R2;
+    constexpr bool SPLIT_OK = !R2 && !(X3 && CV);     // (the X3 conv-gather form keeps whole tiles: its y_s32 output is addressed per tile)
     const int qfull = (ntiles / G) * G;
     const int rtail = ntiles - qfull;
     // (qfull == 0: a grid of 2 * ntiles workgroups over ntiles <= CUs / 2 tiles — a small batch — walks nothing but halves, one each)
@@ -543,12 +543,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             // lane their lo halves: 16-byte stores
             const int sc_w = p.side_c;
             // wave-uniform; 0: side_a (or, with y_s32, the whole output: Y itself is an S32 buffer), 1: side_b, else fp32
-            const int side_chunk = p.y_s32 ? 0 : (sc_w > 0 && n0 == 0) ? (wn * 64) / sc_w : 2;
+            const int noff = hsel == 2 ? 32 : 0;       // a second column half: this wave's channels start 32 past its whole-tile origin
+            const int side_chunk = p.y_s32 ? 0 : (sc_w > 0 && tn == 0) ? (wn * 64) / sc_w : 2;
             char* sbase = p.y_s32 ? reinterpret_cast<char*>(p.Y) : side_chunk == 0 ? reinterpret_cast<char*>(p.side_a) : reinterpret_cast<char*>(p.side_b);
             const int64_t sld = (int64_t)(p.y_s32 ? p.ldy : side_chunk == 0 ? p.side_lda : p.side_ldb) * 4;
-            const int scol0 = p.y_s32 ? n0 + wn * 64 : side_chunk < 2 ? wn * 64 - side_chunk * sc_w : 0;
+            const int scol0 = p.y_s32 ? n0 + wn * 64 : side_chunk < 2 ? wn * 64 + noff - side_chunk * sc_w : 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (half && j >= 2) break;          // a column half: the wave's first 32 channels only
                 const int nl = wn * 64 + j * 16 + 4 * q4e;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(cb + 1024 + nl * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(cb + 2048 + nl * 4);
@@ -741,7 +743,7 @@ hipError_t launch_inst(const GemmParams& p, hipStream_t stream) {
     const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
     static DeviceOnce attr;
     if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(gemm_pw3_kernel<EPI, CS, X3>), PW3_LDS)) return e;
-    const int grid = pw3_grid(p, ntiles, !X3);
+    const int grid = pw3_grid(p, ntiles, true);
     hipLaunchKernelGGL((gemm_pw3_kernel<EPI, CS, X3>), dim3(grid), dim3(512), PW3_LDS, stream, p);
     return hipGetLastError();
 }
