@@ -475,3 +475,31 @@ def test_f32x3_input_range_guard():
     assert np.isfinite(xl.embed_features(big)).all() and xl.numeric_status() == 0
     for e in (x3, f32, xl):
         e.close()
+
+
+# (cases in which every big GEMM is on the persistent kernel in BOTH runs: a 16-bit layer whose tile count lies in (CUs / 2, CUs] takes the
+#  per-tile kernel by default, whose column sums are cut into other row groups)
+@pytest.mark.parametrize("compute,C,L,B", [("bf16", 1024, 32000, 5), ("bf16", 512, 32000, 10), ("f32x3", 1024, 32000, 5),
+                                            ("f32x3", 512, 16000, 12), ("bf16", 1024, 32000, 70)])
+def test_column_halves_of_the_persistent_gemm_are_bit_identical_to_whole_tiles(compute, C, L, B):
+    """Round 5: the persistent GEMM walks the last partial round of its grid — and every tile of a grid that fills at most half the chip
+    (small batches) — as column HALVES of its 256 x 256 tiles (gemm_pw3.hip, "Tail split"): phases 0 and 3 of the four-phase K tile, the
+    epilogue for j < 2, the second half on a channel origin 32 higher.  Every output element and every column sum sees the same products
+    in the same order as in a whole tile, so the embeddings must be the same BITS with the option off (round 4's schedule), on 16-bit and
+    on split (f32x3, with its S32 side outputs) handles; B = 70 at C = 1024 leaves 71 x 4 = 284 tiles = one whole round + 28 tail tiles."""
+    eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=L)
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=5))
+    eng.finalize()
+    wav = synth.synth_waveforms(B, L, seed=23)
+    eng.profile(True)
+    a = eng.embed_wave(wav).copy()
+    labels = set(eng.profile_results())
+    eng.profile(False)
+    # the whole-tile walk of the SAME kernel: halves off and the grid capped at three workgroups (without the cap a small grid would
+    # leave the persistent kernel for the per-tile ones, whose column sums are cut into other row groups: equal to bf16 rounding, not bits)
+    eng.set_option("pw3_tail_off", 1)
+    eng.set_option("pw3_cus", 3)
+    b = eng.embed_wave(wav).copy()
+    eng.close()
+    assert ("gemm_pw3" in labels) or ("gemm_pw3x3" in labels), labels          # the persistent kernel did run
+    assert np.isfinite(a).all() and np.array_equal(a, b)
