@@ -360,10 +360,11 @@ __device__ __forceinline__ float pow2_scale_of_bits(uint32_t bits) {      // s =
 }
 __device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }      // s = 2^k, biased k in [1, 253]
 
-// max |x| of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer; a NaN ranks above everything), by atomicMax
-// into *out (zeroed by the caller)
-// (16-byte loads, one atomic per workgroup: with one per wave of a 1 024-workgroup grid the 4 096 atomics on one word WERE the kernel, 50 us)
-__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ X, int64_t n, uint32_t* __restrict__ out) {
+// max |x| of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer; a NaN ranks above everything): ABSMAX_WGS
+// workgroups leave one partial each in part[0 .. ABSMAX_WGS) (no atomics, no zero-fill launch); the consumer's first kernel folds them
+// (absmax_fold: 256 loads per workgroup) and its workgroup 0 publishes the result in part[-1] = *pscale for the kernels after it
+constexpr int ABSMAX_WGS = 256;
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ X, int64_t n, uint32_t* __restrict__ part) {
     __shared__ uint32_t wm[4];
     uint32_t m = 0;
     const int64_t n4 = n >> 2;
@@ -377,10 +378,17 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-        if (m) atomicMax(out, m);
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+// (called by every thread of a 256-thread workgroup)
+__device__ __forceinline__ uint32_t absmax_fold(const uint32_t* __restrict__ part) {
+    __shared__ uint32_t fm[4];
+    uint32_t m = part[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) fm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return max(max(fm[0], fm[1]), max(fm[2], fm[3]));
 }
 
 // ---- the two-half-plane form on v_mfma_f32_16x16x32_f16 ("h3w", round 4, the default) -------------------------------------------------
@@ -765,9 +773,14 @@ __global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restr
 // `pscale` (optional): the max-|x| word of B (absmax_bits_kernel): every row is multiplied by s = pow2_scale_of_bits(*pscale), the first
 // `sq_rows` rows of A (second-moment rows: products of two cohort values) by s^2
 __global__ __launch_bounds__(256) void split2_planes_kernel(const float* __restrict__ A, int n0, const float* __restrict__ B, int n1, int D,
-                                                            f16_t* __restrict__ planes, const uint32_t* __restrict__ pscale, int sq_rows) {
+                                                            f16_t* __restrict__ planes, uint32_t* __restrict__ pscale, int sq_rows) {
     const int64_t n = (int64_t)(n0 + n1) * D;
-    const float sc = pscale ? pow2_scale_of_bits(*pscale) : 1.0f;
+    float sc = 1.0f;
+    if (pscale) {           // pscale[1 ..] = the partials of absmax_bits_kernel; pscale[0] <- their maximum, for the kernels behind this one
+        const uint32_t bits = absmax_fold(pscale + 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *pscale = bits;
+        sc = pow2_scale_of_bits(bits);
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / D;
         const float v = (r < n0 ? A[i] : B[i - (int64_t)n0 * D]) * (r < sq_rows ? sc * sc : sc);
@@ -911,11 +924,8 @@ hipError_t launch_asnorm_planes(const float* MB, const float* cohort, int K, int
     if (!MB || !cohort || !planes || K <= 0 || D % 32 != 0 || !(nplanes == 2 || nplanes == 3) || (pscale && nplanes != 2)) return hipErrorInvalidValue;
     const int64_t n = (int64_t)(D + 32 + K) * D;
     const int64_t g = (n + 255) / 256;
-    if (pscale) {           // the cohort's max |x| -> *pscale; cohort rows and the mean row are scaled by s, the D moment rows by s^2
-        if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
-        const int64_t gc = ((int64_t)K * D + 255) / 256;
-        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(gc > 1024 ? 256 : (gc + 3) / 4)), dim3(256), 0, stream, cohort, (int64_t)K * D, pscale);
-    }
+    if (pscale)             // the cohort's max |x| -> pscale[1 ..] (partials; the split pass folds them into pscale[0]); cohort rows and the mean row are scaled by s, the D moment rows by s^2
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3(ABSMAX_WGS), dim3(256), 0, stream, cohort, (int64_t)K * D, pscale + 1);
     if (nplanes == 2) hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<f16_t*>(planes), pscale, D);
     else hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, MB, D + 32, cohort, K, D, reinterpret_cast<bf16_t*>(planes));
     return hipGetLastError();
@@ -990,7 +1000,7 @@ hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* i
 }
 
 bool score_h3w_supported(int D, int64_t Na, int64_t Nb) { return (D == 192 || D == 256) && Na > 0 && Nb > 0 && Nb < ((int64_t)1 << 30) && Na < ((int64_t)1 << 31); }
-size_t score_h3w_planes_bytes(int D, int64_t Nb) { return (size_t)2 * Nb * D * 2 + 256; }      // two half planes + the scale word of B behind them
+size_t score_h3w_planes_bytes(int D, int64_t Nb) { return (size_t)2 * Nb * D * 2 + 2048; }      // two half planes + the scale word of B and its 256 partials behind them
 
 // out (Na, ldo) = A (Na, D) . B (Nb, D)^T; `planes` = score_h3w_planes_bytes of scratch (filled here with the half parts of B)
 hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t Nb, int D, float* out, int64_t ldo, void* planes, int num_cu,
@@ -1000,8 +1010,7 @@ hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t 
     const int64_t n = Nb * D;
     const int64_t g = (n + 255) / 256;
     uint32_t* pscale = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(planes) + (size_t)2 * Nb * D * 2);      // (16-byte aligned: Nb * D * 4 bytes in)
-    if (hipError_t e = hipMemsetAsync(pscale, 0, 4, stream)) return e;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(g > 1024 ? 256 : (g + 3) / 4)), dim3(256), 0, stream, B, n, pscale);
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(ABSMAX_WGS), dim3(256), 0, stream, B, n, pscale + 1);
     hipLaunchKernelGGL(split2_planes_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, B, 0, B, (int)Nb, D, reinterpret_cast<f16_t*>(planes), pscale, 0);
     ScoreH3Params p;
     p.A = A; p.Na = Na; p.planes = planes; p.Nb = (int)Nb; p.out = out; p.ldo = ldo; p.pscale = pscale;
