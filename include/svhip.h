@@ -140,10 +140,14 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
  *   l2norm       : F.normalize(p=2, dim=1) in place (src/model.py:421-423), eps 1e-12.
  *   score_pairs  : out[p] = | cos(E[ia[p]], E[ib[p]]) |, per-norm clamp 1e-5 (utils.py:163-164,
  *                  one crop per row).
- *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150) — fp32 MFMA.
+ *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150).  On every handle the product runs as three fp16 MFMAs on IEEE-half
+ *                  hi | lo planes of the operands (fp32-grade: ~1e-7 of |a||b| from the float64 product); both operands are first scaled
+ *                  by exact powers of two on the device (a row of A by its own max |x|, B by its global max |x|), so ANY magnitude is
+ *                  served and a NaN stays a NaN in its row.  Option score_f32mfma keeps the exact fp32 MFMA.
  *   asnorm_stats : per row of E: S = cohort @ e (utils.py:142), top-`top` largest, population
  *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  For D in {192, 256}, top <= 256 and K >= 4 top the cohort
- *                  scores never reach memory (fused selection in the fp32 MFMA kernel, csrc/asnorm_fused.hip); otherwise, and for
+ *                  scores never reach memory (fused selection in the half-plane MFMA kernel, csrc/asnorm_fused.hip: the same three-MFMA
+ *                  products and the same power-of-two operand scaling as score_matrix; option asnorm_f32mfma: exact fp32 MFMA); otherwise, and for
  *                  the embeddings that kernel cannot decide, they exist only as <= 2 GiB slabs.  svhip_asnorm_last_fallback():
  *                  how many embeddings of the last call took the slab path after the fused kernel (-1: the whole call did).
  *   asnorm_pairs : out[p] = 0.5*((s-mu[a])/sd[a] + (s-mu[b])/sd[b]), s = E[a].E[b] (utils.py:148-160).

@@ -346,7 +346,7 @@ def test_fused_blocks_agree_with_the_separate_kernels_at_the_first_shared_tensor
 
 
 @pytest.mark.parametrize("model,compute,B,lanes", [("rawnet2", "bf16", 48, 3), ("rawnet2", "f32", 50, 3), ("rawnet2", "f16", 50, 3), ("rawnet2", "f32x3", 50, 3),
-                                                   ("ecapa", "bf16", 64, 2), ("ecapa", "f32", 70, 2)])
+                                                   ("ecapa", "bf16", 64, 2), ("ecapa", "f32", 70, 2), ("rawnet2", "f32x3", 128, 4), ("rawnet2", "f32", 128, 4)])
 def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, lanes, monkeypatch):
     """SVHIP_LANES slices a batch over up to four streams (offsets into every per-utterance workspace buffer, lane
     streams and events); no test or bench set it.  On fp32 handles the sliced forward must return the same bits as the
@@ -369,7 +369,14 @@ def test_batch_slices_on_several_streams_are_bit_identical(model, compute, B, la
         outs[n] = eng.embed_wave(wav).reshape(B, -1)
         eng.close()
     assert np.isfinite(outs[1]).all()
-    if compute == "f32":
+    if B == 128:
+        # B = 128 on ONE lane takes the full-batch kernels (AFMS gate and small linears on their MFMA forms, B > 64), on four
+        # lanes every lane's 32 utterances take the small-batch ones: another summation order, fp32 round-off — the bound of
+        # test_an_utterance_embeds_alike_on_both_sides_of_the_batch_size_switches (f32x3 1e-5, f32 3e-5 of the embedding scale)
+        d = float(np.abs(outs[1] - outs[lanes]).max() / np.abs(outs[1]).max())
+        print(f"rawnet2 {compute}: B = 128 on 1 lane against 4 lanes, max difference {d:.2e} of the embedding scale")
+        assert d <= (1e-5 if compute == "f32x3" else 3e-5)
+    elif compute == "f32":
         assert np.array_equal(outs[1], outs[lanes])
     else:
         a, b = outs[1], outs[lanes]
