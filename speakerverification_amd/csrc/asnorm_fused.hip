@@ -525,10 +525,13 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
     };
 
     float second[2] = {0.0f, 0.0f}, tau[2] = {0.0f, 0.0f};
-    int cnt[2] = {0, 0};
-    uint32_t coff[2];
+    uint32_t coff[2], pos[2], lim[2];       // a lane's list: first element, BYTE offset of the next free slot, byte offset of the last slot
 #pragma unroll
-    for (int eg = 0; eg < 2; ++eg) coff[eg] = (uint32_t)(((valid[eg] ? row0 + 16 * eg : 0) * 4 + q) * CAPQ);
+    for (int eg = 0; eg < 2; ++eg) {
+        coff[eg] = (uint32_t)(((valid[eg] ? row0 + 16 * eg : 0) * 4 + q) * CAPQ);
+        pos[eg] = coff[eg] << 2;
+        lim[eg] = (coff[eg] + (uint32_t)(CAPQ - 1)) << 2;
+    }
     auto process = [&](const acc_t& a, int b) {
         if (b < NP - 1) {               // rows of M: (M e)_i . e_i, i = 32 b + 16 rg + 4 q + e
 #pragma unroll
@@ -568,12 +571,16 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                             const float v = a[rg][eg][u];
                             bool hit = v > tau[eg];
                             if (decltype(bounded)::value) hit = hit && (kb0 + 4 * q + 16 * rg + u < p.K);
-                            if (hit) {
-                                uint32_t off = (coff[eg] + (uint32_t)min(cnt[eg], CAPQ - 1)) << 2;
-                                asm volatile("" : "+v"(off));      // (keeps the zero-extension out of the address: scalar base + 32-bit vector offset)
-                                *reinterpret_cast<float*>(cbase + off) = v;
-                            }
-                            if (hit) ++cnt[eg];
+                            // branch-free: the slot address is formed for every lane, the store runs under the hit mask as EXEC (written
+                            // as `if (hit)` the compiler adds an s_cbranch_execz per score and lays the two paths out alternately:
+                            // a taken branch on most of the 32 scores of a block)
+                            // (the list position is kept as a BYTE offset: clamp, store, advance by 4 on a hit — four vector instructions per score)
+                            const uint32_t off = min(pos[eg], lim[eg]);
+                            const unsigned long long mask = __ballot(hit);
+                            unsigned long long saved;
+                            asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, %4\n\ts_mov_b64 exec, %0"
+                                         : "=&s"(saved) : "s"(mask), "v"(off), "v"(v), "s"(cbase) : "memory");
+                            pos[eg] += hit ? 4u : 0u;
                         }
             };
             if (kb0 + 32 <= p.K) select(std::false_type{});     // (wave-uniform)
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
 #pragma unroll
     for (int eg = 0; eg < 2; ++eg)
         if (valid[eg]) {
-            p.cnt[(row0 + 16 * eg) * 4 + q] = cnt[eg];
+            p.cnt[(row0 + 16 * eg) * 4 + q] = (int32_t)((pos[eg] - (coff[eg] << 2)) >> 2);      // every hit counted, stored or not
             if (q == 0 && p.rowscale) p.rowscale[row0 + 16 * eg] = unscale[eg];
         }
 }
