@@ -444,3 +444,54 @@ def test_bench_headline_is_one_compact_parsable_line(tmp_path, capsys):
     lines = [json.loads(ln) for ln in open(tmp_path / "r.jsonl")]
     assert [ln["record"] for ln in lines] == ["kernels", "rawnet2"] and len(lines[0]["kernels"]) == 60
     assert [json.loads(ln)["record"] for ln in cap.err.strip().splitlines()] == ["kernels", "rawnet2"]
+
+
+def test_persistent_gemm_item_walk_covers_every_tile_once():
+    """The work list of the persistent GEMM (csrc/gemm_pw3.hip: `item_tile`, `pw3_grid`, round 5) restated in Python: for any tile count and
+    grid cap, the items that the G workgroups walk (item w, w + G, w + 2 G ...) cover every tile exactly once — as one whole item, or as its
+    two column halves when the last partial round holds at most G / 2 tiles (and for grids of at most cap / 2 tiles: halves only) — and no
+    workgroup walks more than ceil-many items.  A host-side guard for index arithmetic that otherwise only GPU parity tests exercise."""
+    def grid_of(ntiles, cap, tail_split=True):
+        if ntiles >= cap:
+            return cap
+        return 2 * ntiles if (tail_split and 2 * ntiles <= cap) else ntiles
+
+    def walk(ntiles, G, tail_split=True):
+        qfull = (ntiles // G) * G
+        rtail = ntiles - qfull
+        split = tail_split and rtail > 0 and 2 * rtail <= G
+        nitems = qfull + 2 * rtail if split else ntiles
+        seen = {}
+        per_wg = []
+        for wg in range(G):
+            n = 0
+            w = wg
+            while w < nitems:
+                if not split or w < qfull:
+                    tile, hsel = w, 0
+                else:
+                    tile, hsel = qfull + ((w - qfull) >> 1), 1 + ((w - qfull) & 1)
+                seen.setdefault(tile, []).append(hsel)
+                n += 1
+                w += G
+            per_wg.append(n)
+        return seen, per_wg, split
+
+    rng = np.random.Generator(np.random.PCG64(5))
+    cases = [(1604, 256), (4812, 256), (384, 256), (128, 256), (26, 5), (16, 3), (40, 8), (1, 256), (2, 3), (129, 256), (255, 256)]
+    cases += [(int(rng.integers(1, 6000)), int(rng.integers(1, 300))) for _ in range(300)]
+    for ntiles, cap in cases:
+        for ts in (True, False):
+            G = grid_of(ntiles, cap, ts)
+            assert 1 <= G <= max(cap, 1) and G <= 2 * ntiles
+            seen, per_wg, split = walk(ntiles, G, ts)
+            assert sorted(seen) == list(range(ntiles)), (ntiles, cap)
+            for tile, hs in seen.items():
+                assert sorted(hs) in ([0], [1, 2]), (ntiles, cap, tile, hs)
+            assert max(per_wg) - min(per_wg) <= 1
+            if not ts:
+                assert not split and all(hs == [0] for hs in seen.values())
+    # the shapes DESIGN.md quotes: 1 604 tiles on 256 CUs = 6 whole rounds + 136 halves; 128 tiles = 256 halves; mfa's 4 812 tiles are not split
+    seen, per_wg, split = walk(1604, 256)
+    assert split and sum(1 for hs in seen.values() if hs != [0]) == 68 and max(per_wg) == 7 and per_wg.count(7) == 136
+    assert grid_of(128, 256) == 256 and walk(128, 256)[2] and not walk(4812, 256)[2]
