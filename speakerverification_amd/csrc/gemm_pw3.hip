@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
             for (int jp = 0; jp < 2; ++jp) {
                 // a column half: the wave's first 32 channels only (the sums below are formed for all four j; the stores of j >= 2 are masked)
                 if (half && jp == 1) break;
-                                f32x4 sc[2], sh[2];
+                f32x4 sc[2], sh[2];
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int nl = wn * 64 + (2 * jp + jj) * 16 + 4 * q4e;
