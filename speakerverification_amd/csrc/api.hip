@@ -860,6 +860,10 @@ int alloc_workspace(svhip_handle* h) {
         if (tf < 1) SV_FAIL(h, SVHIP_ERR_INVALID, "utterance too short for RawNet2 (%d samples)", c.samples);
         if ((rc = dev_alloc(h, &h->rn_logits, B * (size_t)tf * 512))) return rc;
         if ((rc = dev_alloc(h, &h->rn_pooled, B * 1024))) return rc;
+        if (h->bf16) {          // K-slice partials of fc (K = 1 024: four slices of 256) at full batches, 16-bit handles
+            h->lin_part_per_utt = (size_t)4 * (size_t)std::max(128, c.embed_dim);
+            if ((rc = dev_alloc(h, &h->d_lin_part, B * h->lin_part_per_utt))) return rc;
+        }
     }
     if (c.model == SVHIP_MODEL_ECAPA) {
         char* p;
@@ -1468,7 +1472,9 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
     if ((rc = conv_gemm(h, "rn_gemm", h->rn_att3, hb, 128, rn_logits, 512, M, ACT_NONE, ACT_NONE, nullptr, 0, nullptr, 0, true))) return rc;
     if ((rc = run(h, "rn_attn_pool", 0, [&]() { return launch_rn_attn_pool(rn_logits, pre, dt, B, T, 512, rn_pooled, st); }))) return rc;
     if ((rc = run(h, "rn_fc", 2.0 * B * h->rn_fc.N * h->rn_fc.K, [&]() {
-             return launch_rowvec_linear(rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st);
+             // (16-bit handles, full batches: the K-split MFMA form — fp32-grade handles keep ONE kernel for every batch size here)
+             return launch_rowvec_linear(rn_pooled, 1024, h->rn_fc.W, h->rn_fc.bias, d_emb, c.embed_dim, B, c.embed_dim, 1024, ACT_NONE, st,
+                                         h->bf16 && h->d_lin_part ? h->d_lin_part + (size_t)b0 * h->lin_part_per_utt : nullptr, true);
          }))) return rc;
     return SVHIP_OK;
 }

@@ -231,7 +231,9 @@ __global__ __launch_bounds__(1024) void rowvec_linear_small_kernel(const float* 
 // tile over a K slice of LIN_KS = 384 — its four waves take 96 k each, a lane's 16-byte load supplies four MFMA steps (the k order inside a
 // dot product is permuted the same way for both operands) — and writes its partial tile to a scratch; a second launch adds the slices in a
 // fixed order, the bias and the activation.  Deterministic; a row's sums do not depend on the batch it rides in.
-constexpr int LIN_KS = 384;
+// LIN_KS: the K slice of a workgroup — 384 for the long rows (ECAPA's fc / asp_ctx, K = 6 144: 16 slices), 256 for rows that are a multiple
+// of 256 but not of 384 (RawNet2's fc, K = 1 024: 4 slices; round 5)
+template <int LIN_KS>
 __global__ __launch_bounds__(256) void rowvec_linear_mfma_part_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ W,
                                                                       float* __restrict__ part, int B, int N, int K) {
     __shared__ float red[3][16][64];                   // partial tiles of waves 1 - 3: [wave][register][lane]
@@ -664,15 +666,19 @@ hipError_t launch_emb_out(const float* src, float* dst, int n, uint32_t* status,
     return hipGetLastError();
 }
 
-size_t rowvec_linear_scratch_bytes(int B, int N, int K) { return (K % LIN_KS == 0 && K >= 8 * LIN_KS) ? (size_t)(K / LIN_KS) * B * N * sizeof(float) : 0; }
+// (short_rows: the caller opts into the 256-wide slices for rows that are not a multiple of 384 — RawNet2's fc on 16-bit handles; the ECAPA
+//  layers keep round 4's rule, so that an fp32-grade handle takes the same kernel on either side of B = 64 for K < 3 072)
+static int rowvec_linear_slice(int K, bool short_rows) { return (K % 384 == 0 && K >= 8 * 384) ? 384 : (short_rows && K % 256 == 0 && K >= 4 * 256) ? 256 : 0; }
+size_t rowvec_linear_scratch_bytes(int B, int N, int K, bool short_rows) { const int ks = rowvec_linear_slice(K, short_rows); return ks ? (size_t)(K / ks) * B * N * sizeof(float) : 0; }
 
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
-                                int B, int N, int K, int act, hipStream_t stream, float* part) {
+                                int B, int N, int K, int act, hipStream_t stream, float* part, bool short_rows) {
     if (K <= 0 || N <= 0 || B <= 0 || K % 4 != 0 || ld_in % 4 != 0) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(W)) & 15) return hipErrorInvalidValue;
-    if (part && B > 64 && N % 4 == 0 && rowvec_linear_scratch_bytes(B, N, K) > 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
-        const int ns = K / LIN_KS;
-        hipLaunchKernelGGL(rowvec_linear_mfma_part_kernel, dim3((N + 31) / 32, (B + 31) / 32, ns), dim3(256), 0, stream, in, ld_in, W, part, B, N, K);
+    if (part && B > 64 && N % 4 == 0 && rowvec_linear_scratch_bytes(B, N, K, short_rows) > 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+        const int ks = rowvec_linear_slice(K, short_rows), ns = K / ks;
+        if (ks == 384) hipLaunchKernelGGL(rowvec_linear_mfma_part_kernel<384>, dim3((N + 31) / 32, (B + 31) / 32, ns), dim3(256), 0, stream, in, ld_in, W, part, B, N, K);
+        else hipLaunchKernelGGL(rowvec_linear_mfma_part_kernel<256>, dim3((N + 31) / 32, (B + 31) / 32, ns), dim3(256), 0, stream, in, ld_in, W, part, B, N, K);
         hipLaunchKernelGGL(rowvec_linear_mfma_sum_kernel, dim3((B * N + 255) / 256), dim3(256), 0, stream, part, ns, bias, out, ld_out, B, N, act);
         return hipGetLastError();
     }

@@ -228,9 +228,10 @@ hipError_t launch_colstats(const void* X, bool bf16, int ldx, int B, int T, int 
 // out[b, n] = act( bias[n] + sum_k W[n, k] * in[b, k] ), all fp32 (small-M linear layers)
 // `part` (optional, rowvec_linear_scratch_bytes(B, N, K) > 0 bytes): full batches (B > 64) of long rows (K a multiple of 384, >= 3 072) run on the
 // exact fp32 MFMA with K split over workgroups and the slices added in a fixed order
-size_t rowvec_linear_scratch_bytes(int B, int N, int K);
+// `short_rows`: also rows that are a multiple of 256 (>= 1 024) but not of 384, on slices of 256 (RawNet2's fc, 16-bit handles)
+size_t rowvec_linear_scratch_bytes(int B, int N, int K, bool short_rows = false);
 hipError_t launch_rowvec_linear(const float* in, int ld_in, const float* W, const float* bias, float* out, int ld_out,
-                                int B, int N, int K, int act, hipStream_t stream, float* part = nullptr);
+                                int B, int N, int K, int act, hipStream_t stream, float* part = nullptr, bool short_rows = false);
 // the embeddings leave the workspace (dst == src: no copy) and the call's numeric status is recorded: a non-finite value raises bit 0 of
 // status[0], is counted in status[1] and sets *host_flag (mapped pinned memory).  SVHIP_STATUS_* bits: api.hip
 hipError_t launch_emb_out(const float* src, float* dst, int n, uint32_t* status, uint32_t* host_flag, hipStream_t stream);
