@@ -105,6 +105,103 @@ __global__ __launch_bounds__(256) void rn_ln_stats_kernel(const float* __restric
     }
 }
 
+// The same, with the utterance held in REGISTERS (round 5): 1 024 threads, thread t owns the 8-sample units t, t + 1024, ... (NU of them: L <= 8 192 NU),
+// so the waveform is read from memory ONCE (the kernel above walks it three times — mean, variance, output — with four waves on one CU:
+// three dependent 128 KB passes, 34 us at B = 256, a launch that is pure latency) and sixteen waves keep its loads in flight.
+// Same formulas; the sums are formed per thread, per wave, then over the sixteen waves in order (another order than above: fp32 round-off).
+template <typename H, bool LO, int NU>
+__global__ __launch_bounds__(1024) void rn_ln_stats_reg_kernel(const float* __restrict__ x, int L, float* __restrict__ stats,
+                                                               H* __restrict__ xn, int Lp, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ p = x + (int64_t)b * L;
+    const f32x4* __restrict__ p4 = reinterpret_cast<const f32x4*>(p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nunits = L >> 3;                                  // (L % 8 == 0, rows 16-byte aligned: host check)
+    f32x4 r[NU][2];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = threadIdx.x + 1024 * k;
+        if (u < nunits) {
+            r[k][0] = p4[2 * u];
+            r[k][1] = p4[2 * u + 1];
+        } else {
+            r[k][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            r[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) s += ((r[k][0][0] + r[k][0][1]) + (r[k][0][2] + r[k][0][3])) + ((r[k][1][0] + r[k][1][1]) + (r[k][1][2] + r[k][1][3]));
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float mean = tot / (float)L;
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        if (threadIdx.x + 1024 * k < nunits) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = r[k][h2][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float var = tot / (float)(L - 1);                      // torch.std: unbiased
+    const float inv = 1.0f / (sqrtf(var) + 1e-6f);
+    if (threadIdx.x == 0) {
+        stats[2 * b] = mean;
+        stats[2 * b + 1] = inv;
+    }
+    if (xn) {
+        H* __restrict__ o0 = xn + (int64_t)b * (LO ? 4 : 2) * Lp;
+        H* __restrict__ o1 = o0 + Lp;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int u = threadIdx.x + 1024 * k;
+            const int j0 = 8 * u;
+            if (j0 >= Lp) continue;
+            float v[9];
+            if (u < nunits) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + j0), g1 = *reinterpret_cast<const f32x4*>(gamma + j0 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + j0), b1 = *reinterpret_cast<const f32x4*>(beta + j0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = g0[e] * (r[k][0][e] - mean) * inv + b0[e];
+                    v[4 + e] = g1[e] * (r[k][1][e] - mean) * inv + b1[e];
+                }
+                v[8] = j0 + 8 < L ? gamma[j0 + 8] * (p[j0 + 8] - mean) * inv + beta[j0 + 8] : 0.0f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) v[e] = 0.0f;
+            }
+            Vec16<H> a, c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a.set(e, v[e]); c.set(e, v[e + 1]); }
+            *reinterpret_cast<Vec16<H>*>(o0 + j0) = a;
+            *reinterpret_cast<Vec16<H>*>(o1 + j0) = c;
+            if (LO) {
+                Vec16<H> al, cl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { al.set(e, v[e] - a.get(e)); cl.set(e, v[e + 1] - c.get(e)); }
+                *reinterpret_cast<Vec16<H>*>(o0 + 2 * Lp + j0) = al;
+                *reinterpret_cast<Vec16<H>*>(o1 + 2 * Lp + j0) = cl;
+            }
+        }
+    }
+}
+
 constexpr int SINC_PT = 64;                 // pooled frames per iteration
 constexpr int SINC_SAMPLES = 464;           // >= 3 * SINC_PT conv positions + 255 + 8, multiple of 8
 
@@ -890,6 +987,22 @@ inline int grid_for(int64_t items) {
 hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipStream_t stream, void* xn, int Lp, const float* gamma,
                               const float* beta, int xn_dt, bool xn_lo) {
     if (xn && (Lp < L + RN_XN_TAIL || Lp % 64 != 0 || !gamma || !beta)) return hipErrorInvalidValue;
+    // the register-resident form: whole 8-sample units, 16-byte aligned rows and vectors, the padded row within 8 192 NU samples
+    const int span = xn ? Lp : L;
+    const bool reg_ok = L % 8 == 0 && L >= 8 && ((reinterpret_cast<uintptr_t>(wav) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
+                                                   reinterpret_cast<uintptr_t>(xn)) & 15) == 0 && (!xn || Lp % 8 == 0) && span <= 8192 * 8;
+    if (reg_ok) {
+#define SV_LN(HH, LOO)                                                                                                                        \
+        {                                                                                                                                     \
+            if (span <= 8192 * 4) hipLaunchKernelGGL((rn_ln_stats_reg_kernel<HH, LOO, 4>), dim3(B), dim3(1024), 0, stream, wav, L, stats, reinterpret_cast<HH*>(xn), Lp, gamma, beta); \
+            else hipLaunchKernelGGL((rn_ln_stats_reg_kernel<HH, LOO, 8>), dim3(B), dim3(1024), 0, stream, wav, L, stats, reinterpret_cast<HH*>(xn), Lp, gamma, beta);            \
+            return hipGetLastError();                                                                                                         \
+        }
+        if (xn_lo) SV_LN(f16_t, true)
+        if (xn_dt == DT_F16) SV_LN(f16_t, false)
+        SV_LN(bf16_t, false)
+#undef SV_LN
+    }
     if (xn_lo) hipLaunchKernelGGL((rn_ln_stats_kernel<f16_t, true>), dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
     else if (xn_dt == DT_F16) hipLaunchKernelGGL(rn_ln_stats_kernel<f16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<f16_t*>(xn), Lp, gamma, beta);
     else hipLaunchKernelGGL(rn_ln_stats_kernel<bf16_t>, dim3(B), dim3(256), 0, stream, wav, L, stats, reinterpret_cast<bf16_t*>(xn), Lp, gamma, beta);
