@@ -266,7 +266,7 @@ double svhip_workload_flops(const svhip_handle* h);
 /* Developer / test options (not part of the reference's surface).  The SVHIP_<NAME> environment variables are read ONCE, by
  * svhip_create, as a new handle's defaults; afterwards only this call changes them — no getenv on the hot path.  Names:
  * "pw3_cus" (cap of the persistent GEMM grids; 0: off), "rn_unfused", "rn_stop", "rn_snap", "asp_v1", "r2_big", "x3_keep_f32",
- * "asnorm_slab", "asnorm_f32mfma", "asnorm_x6", "asnorm_w32", "score_f32mfma", "score_tiled", "fbank32", "cv_off", "pw3_tail_off", "n128_off", "r2_slices", "rn_tail_big", "rn_sinc_f32", "rn_step_off", "rn_pool_off", "layer_labels".  Unknown names: SVHIP_ERR_INVALID. */
+ * "asnorm_slab", "asnorm_f32mfma", "asnorm_x6", "asnorm_2s", "asnorm_w32", "score_f32mfma", "score_tiled", "fbank32", "cv_off", "pw3_tail_off", "n128_off", "r2_slices", "rn_tail_big", "rn_sinc_f32", "rn_step_off", "rn_pool_off", "layer_labels".  Unknown names: SVHIP_ERR_INVALID. */
 int svhip_set_option(svhip_handle* h, const char* name, int32_t value);
 /* Free the scoring / metrics scratch slots of the handle (grown on demand, otherwise kept until svhip_destroy). */
 int svhip_trim_scratch(svhip_handle* h);
