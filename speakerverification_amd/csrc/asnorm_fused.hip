@@ -525,12 +525,16 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
     };
 
     float second[2] = {0.0f, 0.0f}, tau[2] = {0.0f, 0.0f};
-    uint32_t coff[2], pos[2], lim[2];       // a lane's list: first element, BYTE offset of the next free slot, byte offset of the last slot
+    // A lane's candidate list.  The four lists of an embedding (one per q) are INTERLEAVED in its 4 * CAPQ-float region: element k of list q at
+    // float k * 4 + q — the four lanes fill neighbouring dwords at about the same pace (16-byte groups complete within a block or two instead of
+    // a lane's own eight-element sector over ten), and the statistics kernel finds the region dense up to 4 * (shortest list) and can stop its
+    // search registers there.  pos = BYTE offset of the next free slot (16 bytes per element), lim = byte offset of the last slot.
+    uint32_t coff[2], pos[2], lim[2];
 #pragma unroll
     for (int eg = 0; eg < 2; ++eg) {
-        coff[eg] = (uint32_t)(((valid[eg] ? row0 + 16 * eg : 0) * 4 + q) * CAPQ);
+        coff[eg] = (uint32_t)((valid[eg] ? row0 + 16 * eg : 0) * 4 * CAPQ + q);
         pos[eg] = coff[eg] << 2;
-        lim[eg] = (coff[eg] + (uint32_t)(CAPQ - 1)) << 2;
+        lim[eg] = (coff[eg] + (uint32_t)(CAPQ - 1) * 4u) << 2;
     }
     auto process = [&](const acc_t& a, int b) {
         if (b < NP - 1) {               // rows of M: (M e)_i . e_i, i = 32 b + 16 rg + 4 q + e
@@ -574,13 +578,13 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                             // branch-free: the slot address is formed for every lane, the store runs under the hit mask as EXEC (written
                             // as `if (hit)` the compiler adds an s_cbranch_execz per score and lays the two paths out alternately:
                             // a taken branch on most of the 32 scores of a block)
-                            // (the list position is kept as a BYTE offset: clamp, store, advance by 4 on a hit — four vector instructions per score)
+                            // (the list position is kept as a BYTE offset: clamp, store, advance by one element on a hit — four vector instructions per score)
                             const uint32_t off = min(pos[eg], lim[eg]);
                             const unsigned long long mask = __ballot(hit);
                             unsigned long long saved;
                             asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, %4\n\ts_mov_b64 exec, %0"
                                          : "=&s"(saved) : "s"(mask), "v"(off), "v"(v), "s"(cbase) : "memory");
-                            pos[eg] += hit ? 4u : 0u;
+                            pos[eg] += hit ? 16u : 0u;
                         }
             };
             if (kb0 + 32 <= p.K) select(std::false_type{});     // (wave-uniform)
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
 #pragma unroll
     for (int eg = 0; eg < 2; ++eg)
         if (valid[eg]) {
-            p.cnt[(row0 + 16 * eg) * 4 + q] = (int32_t)((pos[eg] - (coff[eg] << 2)) >> 2);      // every hit counted, stored or not
+            p.cnt[(row0 + 16 * eg) * 4 + q] = (int32_t)((pos[eg] - (coff[eg] << 2)) >> 4);      // every hit counted, stored or not
             if (q == 0 && p.rowscale) p.rowscale[row0 + 16 * eg] = unscale[eg];
         }
 }
@@ -824,17 +828,41 @@ __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __r
         if (lane == 0) flagged[atomicAdd(nflag, 1)] = (int32_t)(row_base + row);
         return;
     }
+    int nq = 2 * AF_CAPL / 64;
+    if (NL == 4) {
+        // the 16-wide kernel interleaves its four lists: float p of the region = element p >> 2 of list p & 3 — dense up to 4 * (shortest
+        // list), empty past 4 * (longest): the search registers past that are skipped (typically 5 of 8)
+        const int cl = (lane & 3) == 0 ? cn[0] : (lane & 3) == 1 ? cn[1] : (lane & 3) == 2 ? cn[2 % NL] : cn[3 % NL];
+        int cmax = 0;
 #pragma unroll
-    for (int q = 0; q < 2 * AF_CAPL / 64; ++q) {
-        const int pos = lane + 64 * q, l = pos / CAP, idx = pos - l * CAP;
-        int cl = 0;
+        for (int k = 0; k < NL; ++k) cmax = max(cmax, cn[k]);
+        nq = min(nq, __builtin_amdgcn_readfirstlane((4 * cmax + 63) >> 6));
 #pragma unroll
-        for (int k = 0; k < NL; ++k) cl = l == k ? cn[k] : cl;
-        ck[q] = idx < cl ? fkey(cv[q]) : 0u;
+        for (int q = 0; q < 2 * AF_CAPL / 64; ++q) ck[q] = ((lane >> 2) + 16 * q) < cl ? fkey(cv[q]) : 0u;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2 * AF_CAPL / 64; ++q) {
+            const int pos = lane + 64 * q, l = pos / CAP, idx = pos - l * CAP;
+            int cl = 0;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) cl = l == k ? cn[k] : cl;
+            ck[q] = idx < cl ? fkey(cv[q]) : 0u;
+        }
     }
     float m, sd;
-    // (total >= top populated keys was checked above: the search may start below the bits they share)
-    select_stats<2 * AF_CAPL / 64>(ck, top, m, sd, 2 * AF_CAPL / 64, true);
+    // (total >= top populated keys was checked above: the search may start below the bits they share.  The register count of the search is a
+    //  compile-time constant per case: with a run-time bound inside select_stats the eight ballot chains of a step sit behind eight uniform
+    //  branches and no longer interleave — the guarded form measured 25 % SLOWER than searching all eight registers)
+    auto run = [&](auto nreg) {
+        constexpr int NR = decltype(nreg)::value;
+        uint32_t c[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) c[j] = ck[j];
+        select_stats<NR>(c, top, m, sd, NR, true);
+    };
+    if (nq <= 5) run(std::integral_constant<int, 5>{});
+    else if (nq == 6) run(std::integral_constant<int, 6>{});
+    else run(std::integral_constant<int, 2 * AF_CAPL / 64>{});
     // (candidates of the scaled kernels are stored in the scaled domain: mean and deviation are linear in the scale, a power of two)
     const float rs = rowscale ? rowscale[row] : 1.0f;
     if (lane == 0) { mu[row_base + row] = m * rs; sigma[row_base + row] = sd * rs; }
