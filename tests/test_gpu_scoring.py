@@ -315,8 +315,9 @@ def test_whole_trial_scoring_modes(eng, n_files, n_crops, D, P):
         eng.score_trials(F, np.array([n_files], np.int32), np.array([0], np.int32), "cosine")      # index out of range
 
 
-@pytest.mark.parametrize("sa,sb", [(1.0, 1.0), (3.0e5, 1.0), (1.0e-6, 1.0e-6), (7.0e6, 2.0e-7), (40.0, 1.0e5)])
-def test_half_plane_score_kernels_take_operands_of_any_magnitude(sa, sb):
+@pytest.mark.parametrize("sa,sb,D", [(1.0, 1.0, 192), (3.0e5, 1.0, 192), (1.0e-6, 1.0e-6, 192), (7.0e6, 2.0e-7, 192), (40.0, 1.0e5, 192),
+                                      (3.0e5, 1.0e-3, 256), (1.0e-6, 1.0, 256)])
+def test_half_plane_score_kernels_take_operands_of_any_magnitude(sa, sb, D):
     """since round 4 the dense score GEMMs and the AS-norm kernel carry their operands as IEEE-half hi | lo planes — on
     every handle, the 'exact' scoring handle included — and the reference scores RAW embeddings when `normalize` is off.  Round 4 clamped
     |x| > 65504 silently and lost the low bits of components below 2^-3.  Round 5 scales every operand by an exact power of two first
@@ -325,7 +326,7 @@ def test_half_plane_score_kernels_take_operands_of_any_magnitude(sa, sb):
     component 2^-20 of its largest (it must not vanish), one is all zeros."""
     eng = Engine(model="none", max_batch=1)
     rng = np.random.Generator(np.random.PCG64(77))
-    Na, Nb, D, K, top = 300, 517, 192, 5994, 200      # (K = 5994: the fused AS-norm kernel; smaller cohorts take the slab path)
+    Na, Nb, K, top = 300, 517, 5994, 200      # (K = 5994: the fused AS-norm kernel; smaller cohorts take the slab path)
     A = rng.standard_normal((Na, D)).astype(np.float32); A /= np.linalg.norm(A, axis=1, keepdims=True)
     B = rng.standard_normal((Nb, D)).astype(np.float32); B /= np.linalg.norm(B, axis=1, keepdims=True)
     A[7, 1:] *= np.float32(2.0 ** -20)                                  # one dominant component, the rest 2^-20 of it
