@@ -503,3 +503,31 @@ def test_column_halves_of_the_persistent_gemm_are_bit_identical_to_whole_tiles(c
     eng.close()
     assert ("gemm_pw3" in labels) or ("gemm_pw3x3" in labels), labels          # the persistent kernel did run
     assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f32", "f32x3"])
+def test_ecapa_reports_a_nonfinite_input(compute):
+    """The status word of svhip.h v4 on ECAPA handles: a NaN in one utterance's features makes that utterance's embedding NaN (the SE
+    squeeze and the statistics pooling spread it over the whole utterance, as they do in the reference); the call says so
+    (SVHIP_ERR_NONFINITE; on an f32x3 handle the range guard of the prologue names the input first: SVHIP_ERR_RANGE), the other rows are the
+    bits they are without it, and the next clean call is clean."""
+    from speakerverification_amd import _lib
+    C, T, B = 64, 50, 3
+    eng = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80, on_numeric="ignore")
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=3))
+    eng.finalize()
+    mel = np.abs(synth.synth_mel(B, 80, T, seed=13)).astype(np.float32) + np.float32(0.01)
+    clean = eng.embed_features(mel).copy()
+    assert eng.numeric_status() == 0
+    bad = mel.copy()
+    bad[1, 7, 20] = np.nan
+    got = np.empty_like(clean)
+    rc = eng.lib.svhip_embed_features(eng.h, bad.ctypes.data, B, T, got.ctypes.data, 0)
+    assert rc == (_lib.ERR_RANGE if compute == "f32x3" else _lib.ERR_NONFINITE), (rc, eng.lib.svhip_last_error(eng.h))
+    assert not np.isfinite(got[1]).any()
+    if compute != "bf16":                     # (a bf16 row moves by round-off with its neighbours' column sums; the fp32-grade rows do not)
+        assert np.array_equal(got[[0, 2]], clean[[0, 2]])
+    else:
+        assert np.isfinite(got[[0, 2]]).all()
+    assert eng.lib.svhip_embed_features(eng.h, mel.ctypes.data, B, T, got.ctypes.data, 0) == 0 and np.array_equal(got, clean)
+    eng.close()
