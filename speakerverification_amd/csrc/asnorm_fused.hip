@@ -358,9 +358,12 @@ __device__ __forceinline__ float pow2_scale_of_bits(uint32_t bits) {      // s =
     const int se = min(253, max(1, 260 - e));                             // biased exponent of s = 127 + 6 - (e - 127)
     return __uint_as_float((uint32_t)se << 23);
 }
+// |x| as ordered bits for the max-|x| searches; inf / NaN count as 0: a non-finite element must not set the scale of the
+// FINITE elements around it (exponent 255 would give 2^-122 and flush a whole matrix to zero) — it stays inf / NaN in its own row or column
+__device__ __forceinline__ uint32_t finite_abs_bits(uint32_t w) { const uint32_t a = w & 0x7fffffffu; return a < 0x7f800000u ? a : 0u; }
 __device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }      // s = 2^k, biased k in [1, 253]
 
-// max |x| of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer; a NaN ranks above everything): ABSMAX_WGS
+// max |x| over the FINITE elements of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer): ABSMAX_WGS
 // workgroups leave one partial each in part[0 .. ABSMAX_WGS) (no atomics, no zero-fill launch); the consumer's first kernel folds them
 // (absmax_fold: 256 loads per workgroup) and its workgroup 0 publishes the result in part[-1] = *pscale for the kernels after it
 constexpr int ABSMAX_WGS = 256;
@@ -371,9 +374,9 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
     const u32x4* __restrict__ X4 = reinterpret_cast<const u32x4*>(X);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const u32x4 v = X4[i];
-        m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu));
+        m = max(max(m, finite_abs_bits(v[0])), max(max(finite_abs_bits(v[1]), finite_abs_bits(v[2])), finite_abs_bits(v[3])));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(X[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, finite_abs_bits(__float_as_uint(X[(n4 << 2) + threadIdx.x])));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                 const u32x4 w0 = *reinterpret_cast<const u32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q);
                 const u32x4 w1 = *reinterpret_cast<const u32x4*>(p.E + eoff[eg] + 32 * s_ + 8 * q + 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) m = max(m, max(w0[u] & 0x7fffffffu, w1[u] & 0x7fffffffu));
+                for (int u = 0; u < 4; ++u) m = max(m, max(finite_abs_bits(w0[u]), finite_abs_bits(w1[u])));
             }
             m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
             m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                             const unsigned long long mask = __ballot(hit);
                             unsigned long long saved;
                             asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, %4\n\ts_mov_b64 exec, %0"
-                                         : "=&s"(saved) : "s"(mask), "v"(off), "v"(v), "s"(cbase) : "memory");
+                                         : "=&s"(saved) : "s"(mask), "v"(off), "v"(v), "s"(cbase) : "memory", "scc");
                             pos[eg] += hit ? 16u : 0u;
                         }
             };
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
                 const u32x4 w0 = *reinterpret_cast<const u32x4*>(src + 32 * s_ + 8 * q);
                 const u32x4 w1 = *reinterpret_cast<const u32x4*>(src + 32 * s_ + 8 * q + 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) m = max(m, max(w0[u] & 0x7fffffffu, w1[u] & 0x7fffffffu));
+                for (int u = 0; u < 4; ++u) m = max(m, max(finite_abs_bits(w0[u]), finite_abs_bits(w1[u])));
             }
             m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
             m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));

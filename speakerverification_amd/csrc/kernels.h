@@ -137,6 +137,9 @@ hipError_t launch_gemm_pw2(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3_supported(const GemmParams& p, bool bf16);
 hipError_t launch_gemm_pw3(const GemmParams& p, hipStream_t stream);
 int pw3_grid_cap(const GemmParams& p);
+// round 6: the same contract on four waves with 128 x 128 wave tiles (gemm_pw4.hip)
+bool gemm_pw4_supported(const GemmParams& p, bool bf16);
+hipError_t launch_gemm_pw4(const GemmParams& p, hipStream_t stream);
 // the X3 form of the persistent kernel (x3 == 2): A (M, K) and W (N, K) in the S32 split layout (per row, per 32 k: 32 hi bf16 |
 // 32 lo bf16), fp32 output, exact GELU + BN affine, optional column sums: the GELU layers of SVHIP_F32X3 handles
 bool gemm_pw3x3_supported(const GemmParams& p);

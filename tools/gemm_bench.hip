@@ -9,6 +9,9 @@
 #include <cmath>
 #include "kernels.h"
 #include "common.h"
+#ifdef GEMM_BENCH_VENDOR
+#include <hipblaslt/hipblaslt.h>
+#endif
 using namespace svhip;
 
 __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
@@ -33,6 +36,52 @@ __global__ void checksum_bf16(const uint16_t* y, size_t n, double* out) {
     atomicAdd(out, s); atomicAdd(out + 1, a);
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+#ifdef GEMM_BENCH_VENDOR
+// Yardstick (round 6): the vendor's plain bf16 GEMM of the same shape on the same random operands, in the same process.
+// Y[M, N] (bf16, row-major) = A[M, K] . W[N, K]^T, fp32 accumulate, no epilogue.  Column-major view: Y^T (N x M) = op_T(W: K x N) . (A^T: K x M).
+// Tools only: nothing of the product links hipBLASLt.
+#define LT(x) do { hipblasStatus_t s_ = (x); if (s_ != HIPBLAS_STATUS_SUCCESS) { printf("hipBLASLt error %d at %s:%d\n", (int)s_, __FILE__, __LINE__); exit(1);} } while (0)
+struct VendorGemm {
+    hipblasLtHandle_t lt = nullptr; void* ws = nullptr; size_t ws_bytes = 256u << 20;
+    hipblasLtMatmulDesc_t desc = nullptr; hipblasLtMatrixLayout_t lw = nullptr, la = nullptr, ly = nullptr;
+    hipblasLtMatmulHeuristicResult_t algo[16]; int nalgo = 0, best = 0;
+    void init() { LT(hipblasLtCreate(&lt)); CK(hipMalloc(&ws, ws_bytes)); }
+    void plan(int M, int N, int K) {
+        if (desc) { hipblasLtMatmulDescDestroy(desc); hipblasLtMatrixLayoutDestroy(lw); hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(ly); }
+        LT(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+        hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+        LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)));
+        LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)));
+        LT(hipblasLtMatrixLayoutCreate(&lw, HIP_R_16BF, K, N, K));
+        LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16BF, K, M, K));
+        LT(hipblasLtMatrixLayoutCreate(&ly, HIP_R_16BF, N, M, N));
+        hipblasLtMatmulPreference_t pref; LT(hipblasLtMatmulPreferenceCreate(&pref));
+        LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)));
+        LT(hipblasLtMatmulAlgoGetHeuristic(lt, desc, lw, la, ly, ly, pref, 16, algo, &nalgo));
+        hipblasLtMatmulPreferenceDestroy(pref);
+        if (nalgo <= 0) { printf("hipBLASLt: no algorithm for %d x %d x %d\n", M, N, K); exit(1); }
+        best = 0;
+    }
+    hipblasStatus_t run(const void* A, const void* W, void* Y, hipStream_t st, int which) {
+        const float one = 1.0f, zero = 0.0f;
+        return hipblasLtMatmul(lt, desc, &one, W, lw, A, la, &zero, Y, ly, Y, ly, &algo[which].algo, ws, ws_bytes, st);
+    }
+    // time every heuristic candidate once (3 launches each) and keep the fastest: the yardstick is the vendor's best, not its first guess
+    void tune(const void* A, const void* W, void* Y, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+        float bt = 1e30f;
+        for (int a = 0; a < nalgo; ++a) {
+            if (run(A, W, Y, st, a) != HIPBLAS_STATUS_SUCCESS) continue;
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < 3; ++i) run(A, W, Y, st, a);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < bt) { bt = ms; best = a; }
+        }
+    }
+};
+#endif
 
 struct Shape { const char* name; int M, N, K, taps, dil, cin; int act1, act2; bool a2; bool out_f32; int T = 0; int pad = PAD_REFLECT; bool resid = false; };
 
@@ -84,6 +133,9 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef GEMM_BENCH_VENDOR
+    VendorGemm vg; vg.init();
+#endif
     for (auto& s : shapes) {
         GemmParams p;
         p.A = A; p.A2 = s.a2 ? A2 : nullptr; p.W = W; p.Y = Y; p.bias = bias; p.scale = scale; p.shift = shift;
@@ -91,17 +143,38 @@ int main(int argc, char** argv) {
         p.lda = s.taps > 1 ? s.cin * (s.a2 ? 8 : 1) : s.K; p.lda2 = p.lda; p.ldy = s.N; p.T = s.T ? s.T : T;
         p.taps = s.taps; p.dil = s.dil; p.cin = s.cin; p.pad_mode = s.pad; p.act1 = s.act1; p.act2 = s.act2; p.out_f32 = s.out_f32; p.debug = 0; p.zero_page = zp;
         if (s.resid) { p.R = A2; p.ldr = s.N; }
+#ifdef GEMM_BENCH_VENDOR
+        bool vplanned = false;
+#endif
         for (int rd = 0; rd < rounds; ++rd)
         for (int debug : debugs) {
+#ifdef GEMM_BENCH_VENDOR
+            if (debug == (1 << 20)) {                    // 1048576: the vendor GEMM of this shape (pointwise bf16 shapes only)
+                if (!bf16 || s.taps != 1 || s.out_f32) continue;
+                if (!vplanned) { vg.plan(s.M, s.N, s.K); vg.tune(A, W, Y, st, e0, e1); vplanned = true; }
+                for (int i = 0; i < 2; ++i) vg.run(A, W, Y, st, vg.best);
+                CK(hipStreamSynchronize(st));
+                const int it = 10;
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < it; ++i) vg.run(A, W, Y, st, vg.best);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+                printf("%-36s vendor     %8.3f ms  %8.1f TFLOP/s  [hipBLASLt algo %d of %d, no epilogue]\n", s.name, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, vg.best, vg.nalgo);
+                continue;
+            }
+#endif
             p.debug = debug;
             p.cv_off = (debug & 32768) ? 1 : 0;            // 32768: conv-gather shapes on the per-tile kernel
             p.tail_split = (debug & 65536) ? 0 : 1;        // 65536: the persistent kernel's last partial round as whole tiles (round 4)
             if (debug & 128) { p.colsum = csum; p.colsum_sq = (debug & 256) ? 1 : 0; p.colsum_stride = csr; } else { p.colsum = nullptr; }
-            for (int i = 0; i < 2; ++i) CK(launch_gemm(p, bf16, st));
+            const bool pw4 = (debug & (1 << 21)) && bf16 && gemm_pw4_supported(p, bf16) && gemm_route(p, bf16) == ROUTE_PW3;      // 2097152: the four-wave kernel
+            auto launch = [&]() { return pw4 ? launch_gemm_pw4(p, st) : launch_gemm(p, bf16, st); };
+            if ((debug & (1 << 21)) && !pw4) continue;
+            for (int i = 0; i < 2; ++i) CK(launch());
             CK(hipStreamSynchronize(st));
             const int it = 10;
             CK(hipEventRecord(e0, st));
-            for (int i = 0; i < it; ++i) CK(launch_gemm(p, bf16, st));
+            for (int i = 0; i < it; ++i) CK(launch());
             CK(hipEventRecord(e1, st));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
@@ -114,7 +187,7 @@ int main(int argc, char** argv) {
                 CK(hipMemcpyAsync(hcs, dcs, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
             }
             printf("%-36s dbg %5d %8.3f ms  %8.1f TFLOP/s  cs %.6e %.6e  [%s]\n", s.name, debug, ms, 2.0 * s.M * s.N * s.K / ms / 1e9, hcs[0], hcs[1],
-                   gemm_route(p, bf16) == ROUTE_PW3 ? "pw3" : gemm_route(p, bf16) == ROUTE_PW3CV ? "pw3cv16" : gemm_route(p, bf16) == ROUTE_PW2 ? "pw2" : "other");
+                   pw4 ? "pw4" : gemm_route(p, bf16) == ROUTE_PW3 ? "pw3" : gemm_route(p, bf16) == ROUTE_PW3CV ? "pw3cv16" : gemm_route(p, bf16) == ROUTE_PW2 ? "pw2" : "other");
             if ((debug & 128) && p.colsum && gemm_pw2_supported(p, bf16)) {
                 // per-utterance column sums from the partials (the arithmetic of colsum_finalize_kernel), as an order-sensitive checksum:
                 // the 8-row-group layout of pw2 and the 2-row-group layout of pw3 must agree to bf16 rounding of the summed values
