@@ -43,7 +43,8 @@ typedef enum svhip_status {
     SVHIP_ERR_NONFINITE = -7,   /* the call completed and wrote its embeddings, but some of them are inf / NaN: an fp16 activation
                                    overflowed (SVHIP_F16 stores activations as IEEE half: 65504), or the input was not finite */
     SVHIP_ERR_RANGE = -8        /* the call completed, but input values left the range the handle's arithmetic represents (SVHIP_F32X3:
-                                   operands travel as IEEE-half hi | lo planes, |x| <= 65504) and were clamped */
+                                   operands travel as IEEE-half hi | lo planes, |x| <= 65504): such values become inf in the planes and the
+                                   embeddings come out non-finite */
 } svhip_status;
 
 enum { SVHIP_MODEL_ECAPA = 0, SVHIP_MODEL_RAWNET2 = 1, SVHIP_MODEL_NONE = 2 /* fbank + scoring only */ };
@@ -57,8 +58,8 @@ typedef struct svhip_config {
                                SVHIP_F32X3: fp32 storage and arithmetic everywhere except the convolution GEMMs, whose products are three
                                fp16 MFMAs on operands split into IEEE-half hi | lo parts (11 + 11 significant bits: 2^-23 relative while
                                |x| >= 2^-3, at most 2^-25 absolute below that): 1e-4 parity at ~3x the fp32 speed.  RANGE CONTRACT: an operand
-                               of such a GEMM must satisfy |x| <= 65504 (hi saturates there; lo carries the remainder up to ~1.3e5, beyond
-                               that the value is clamped).  Activations behind a BatchNorm are O(10); the network INPUT is checked on every
+                               of such a GEMM must satisfy |x| <= 65504 (the conversion to the planes is the plain one: beyond that hi is inf
+                               and the embeddings come out inf / NaN).  Activations behind a BatchNorm are O(10); the network INPUT is checked on every
                                call (SVHIP_ERR_RANGE), the embeddings are checked for inf / NaN on every call (SVHIP_ERR_NONFINITE);
                                SVHIP_F16 (RawNet2 handles only): fp16 storage + fp16 MFMA, fp32 accumulate — the same speed as bf16 with
                                three more mantissa bits (RawNet2's un-normalised residual stack loses two digits to bf16 WEIGHT rounding);
@@ -142,8 +143,11 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
  *                  one crop per row).
  *   score_matrix : out (Na, Nb) = A @ B^T (np.inner, utils.py:150).  On every handle the product runs as three fp16 MFMAs on IEEE-half
  *                  hi | lo planes of the operands (fp32-grade: ~1e-7 of |a||b| from the float64 product); both operands are first scaled
- *                  by exact powers of two on the device (a row of A by its own max |x|, B by its global max |x|), so ANY magnitude is
- *                  served and a NaN stays a NaN in its row.  Option score_f32mfma keeps the exact fp32 MFMA.
+ *                  by exact powers of two on the device (a row of A by its own max |x|, B by its global max |x|), so for D in {192, 256}
+ *                  (the row-streaming kernel; 16-byte aligned operands) ANY finite magnitude is served, and an inf / NaN element stays in
+ *                  its own row or column (non-finite elements are left out of the max |x| searches).  Other widths run a tiled split GEMM
+ *                  without the scaling: |x| <= 65504 there (beyond it the scores come out inf / NaN).  Option score_f32mfma keeps the
+ *                  exact fp32 MFMA (any magnitude, any width).
  *   asnorm_stats : per row of E: S = cohort @ e (utils.py:142), top-`top` largest, population
  *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  For D in {192, 256}, top <= 256 and K >= 4 top the cohort
  *                  scores never reach memory (fused selection in the half-plane MFMA kernel, csrc/asnorm_fused.hip: the same three-MFMA

@@ -161,7 +161,11 @@ def check(handle, rc, on_numeric="raise"):
             return
         if on_numeric == "warn":
             import warnings
-            warnings.warn(f"svhip numeric status {rc}: {text}", RuntimeWarning, stacklevel=3)
+            # (shown for EVERY batch that reports it: the default filter would print a call site's warning once and let later bad
+            #  batches pass silently — ADVICE r5)
+            with warnings.catch_warnings():
+                warnings.simplefilter("always", RuntimeWarning)
+                warnings.warn(f"svhip numeric status {rc}: {text}", RuntimeWarning, stacklevel=3)
             return
         raise SvhipNumericError(rc, text)
     raise SvhipError(rc, text)

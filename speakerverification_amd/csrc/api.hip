@@ -79,6 +79,7 @@ struct svhip_handle {
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
+        int pw4 = 0;              // plain pointwise bf16 layers with more tiles than workgroups on the four-wave kernel (gemm_pw4.hip)
         int pw3_tail_off = 0;     // persistent 16-bit GEMMs: the last partial round as whole tiles (round 4) instead of column halves
         int cv_off = 0;           // 16-bit handles: conv-gather GEMMs on the per-tile kernel instead of the persistent one
         int n128_off = 0;         // bf16: asp.tdnn on gemm_pw instead of gemm_n128
@@ -930,7 +931,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     p.lda = lda; p.lda2 = lda2; p.ldy = ldy; p.ld_bu = ld_bu;
     p.T = T > 0 ? T : h->T; p.taps = L.taps; p.dil = L.dil; p.cin = L.cin; p.pad_mode = pad_mode;
     p.act1 = act1; p.act2 = act2; p.out_f32 = out_f32 ? 1 : 0;
-    p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.tail_split = h->opt.pw3_tail_off ? 0 : 1;
+    p.f16 = h->f16 ? 1 : 0; p.pw3_cus = h->opt.pw3_cus; p.tail_split = h->opt.pw3_tail_off ? 0 : 1; p.pw4 = h->opt.pw4;
     const bool bf = h->bf16;
     hipStream_t st = h->cur;
     (void)label;
@@ -965,7 +966,7 @@ int conv_gemm(svhip_handle* h, const char* label, const ConvLayer& L, const void
     }
     // profile labels name the kernel instance (one label == one kernel symbol in a rocprofv3 trace)
     const GemmRoute route = gemm_route(p, bf);
-    const char* klabel = route == ROUTE_PW3 ? "gemm_pw3" : route == ROUTE_PW3CV ? "gemm_pw3cv16" : route == ROUTE_N128 ? "gemm_n128" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
+    const char* klabel = route == ROUTE_PW3 ? ((p.pw4 && gemm_pw4_supported(p, bf)) ? "gemm_pw4" : "gemm_pw3") : route == ROUTE_PW3CV ? "gemm_pw3cv16" : route == ROUTE_N128 ? "gemm_n128" : route == ROUTE_PW2 ? (L.taps > 1 ? "gemm_pw2_conv" : "gemm_pw2")
                          : L.taps > 1 ? (A2 ? "gemm_conv_add" : "gemm_conv") : (route == ROUTE_GENERIC ? "gemm_generic" : "gemm_pw");
     char shaped[96];
     if (h->opt.layer_labels) {            // developer hook (SVHIP_LAYER_LABELS): one profile row per GEMM shape
@@ -1514,7 +1515,8 @@ int check_ready(svhip_handle* h, int B) {
 }
 
 // The numeric status of the forwards since the last reset (the stream must be idle): the kernels that raise a bit also set the mapped
-// host flag, so the common case costs one host load.  Non-finite embeddings outrank the range warning (they are what it leads to).
+// host flag, so the common case costs one host load.  When both bits are set the RANGE report is the one returned: it names the cause (an input the
+// planes cannot carry ends as inf / NaN embeddings) and carries the count of non-finite embedding values in its text.
 enum { SVHIP_STATUS_NONFINITE = 1, SVHIP_STATUS_RANGE = 2 };
 int numeric_status(svhip_handle* h, bool reset) {
     if (!h->host_flag || !*h->host_flag) return SVHIP_OK;
@@ -1626,7 +1628,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.pw4 = is1("SVHIP_PW4"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2440,7 +2442,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

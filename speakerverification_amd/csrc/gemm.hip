@@ -399,7 +399,7 @@ hipError_t launch_gemm(const GemmParams& p, bool bf16, hipStream_t stream) {
     if (p.A3 && gemm_route(p, bf16) != ROUTE_PW2) return hipErrorInvalidValue;       // (only the 256 x 256 kernel reads a second K segment)
     switch (gemm_route(p, bf16)) {
         case ROUTE_PW2: return launch_gemm_pw2(p, stream);
-        case ROUTE_PW3: return launch_gemm_pw3(p, stream);
+        case ROUTE_PW3: return (p.pw4 && gemm_pw4_supported(p, bf16)) ? launch_gemm_pw4(p, stream) : launch_gemm_pw3(p, stream);
         case ROUTE_PW3CV: return launch_gemm_pw3cv16(p, stream);
         case ROUTE_N128: return launch_gemm_n128(p, stream);
         case ROUTE_PW: return launch_gemm_pw(p, bf16, stream);

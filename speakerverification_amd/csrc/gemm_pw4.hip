@@ -36,6 +36,9 @@ constexpr int PGROUP4_M = 8;
 #ifndef PW4_ABL
 #define PW4_ABL 0
 #endif
+#ifndef PW4_SKEW
+#define PW4_SKEW 0
+#endif
 
 template <int EPI, int CS, typename H>
 __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
@@ -173,9 +176,18 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
 #define PW4_WAIT_BARRIER(MODE)                                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* this wave is done reading `buf` */ \
         /* its DMAs of the next K tile (issued a K tile ago) have landed */                         \
-        if ((MODE) == 1 && stores_behind) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");         \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        if ((MODE) == 1 && stores_behind) {     /* 32 output stores + 16 per kind of column sum (CS = 2: one of the 64 must be back) */ \
+            if (CS == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                          \
+            else if (CS == 1) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                     \
+            else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");                                  \
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
         if (!(PW4_ABL & 2)) __builtin_amdgcn_s_barrier();                                           \
+        /* skew: wave w runs PW4_SKEW cycles behind wave w - 1 until the next barrier, so that the four waves' operand DMAs do not */ \
+        /* reach the CU's one address path in the same cycle */                                     \
+        if (PW4_SKEW > 0) {                                                                         \
+            if (wave & 1) { _Pragma("unroll") for (int z = 0; z < PW4_SKEW / 16; ++z) asm volatile("s_nop 15"); }      \
+            if (wave & 2) { _Pragma("unroll") for (int z = 0; z < PW4_SKEW / 8; ++z) asm volatile("s_nop 15"); }       \
+        }                                                                                           \
         asm volatile("" ::: "memory");                                                              \
         __builtin_amdgcn_sched_barrier(0);
 #if PW4_VARIANT == 3
@@ -277,30 +289,54 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
                 }
             }
             if (CS) {
-                // per-utterance column sums of this wave's 128 frames x 128 channels (gemm_pw3's layout: 2 row groups of 128 rows per tile)
+                // per-utterance column sums of this wave's 128 frames x 128 channels (gemm_pw3's layout: 2 row groups of 128 rows per tile):
+                //   colsum[((tm*2 + wm)*2 + seg) * N + n], seg 0 = the utterance of the tile's first row, seg 1 = the next one
                 const int lo = wm * 128;
-                const int rb = (m0 / p.T + 1) * p.T - m0;
+                const int rb = (m0 / p.T + 1) * p.T - m0;         // first tile row that belongs to the next utterance
                 const int rend = min(256, p.M - m0);
+                const bool whole = (lo + 128 <= rend) && (lo + 128 <= rb || lo >= rb);      // wave-uniform: one segment, every row valid
                 float* csp = p.colsum + ((int64_t)(tm * 2 + wm) * 2) * p.N + n0 + wn * 128 + 4 * q4e;
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                if (whole) {
+                    const int sg = lo >= rb ? 1 : 0;
 #pragma unroll
-                for (int kind = 0; kind < CS; ++kind) {
-                    float* cs = csp + (kind ? p.colsum_stride : 0);
+                    for (int kind = 0; kind < CS; ++kind) {
+                        float* cs = csp + (kind ? p.colsum_stride : 0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+                        for (int j = 0; j < 8; ++j) {
+                            f32x4 sm = zero4;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int row = lo + i * 16 + r16e;
-                            const float w0 = (row < rb && row < rend) ? 1.0f : 0.0f;
-                            const float w1 = (row >= rb && row < rend) ? 1.0f : 0.0f;
-                            const f32x4 v = kind ? acc[i][j] * acc[i][j] : acc[i][j];
-                            s0 += v * w0; s1 += v * w1;
+                            for (int i = 0; i < 8; ++i) sm += kind ? acc[i][j] * acc[i][j] : acc[i][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sm[e] = row16_sum(sm[e]);
+                            if (r16e == 0) {
+                                *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)sg * p.N) = sm;
+                                *reinterpret_cast<f32x4*>(cs + j * 16 + (int64_t)(1 - sg) * p.N) = zero4;
+                            }
                         }
+                    }
+                } else {
+                    // an utterance boundary inside this wave's rows, or rows past M: every row weighted on its own
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s0[e] = row16_sum(s0[e]); s1[e] = row16_sum(s1[e]); }
-                        if (r16e == 0) {
-                            *reinterpret_cast<f32x4*>(cs + j * 16) = s0;
-                            *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
+                    for (int kind = 0; kind < CS; ++kind) {
+                        float* cs = csp + (kind ? p.colsum_stride : 0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            f32x4 s0 = zero4, s1 = zero4;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int row = lo + i * 16 + r16e;
+                                const float w0 = (row < rb && row < rend) ? 1.0f : 0.0f;
+                                const float w1 = (row >= rb && row < rend) ? 1.0f : 0.0f;
+                                const f32x4 v = kind ? acc[i][j] * acc[i][j] : acc[i][j];
+                                s0 += v * w0; s1 += v * w1;
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { s0[e] = row16_sum(s0[e]); s1[e] = row16_sum(s1[e]); }
+                            if (r16e == 0) {
+                                *reinterpret_cast<f32x4*>(cs + j * 16) = s0;
+                                *reinterpret_cast<f32x4*>(cs + j * 16 + p.N) = s1;
+                            }
                         }
                     }
                 }
@@ -309,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (!more) break;
-        stores_behind = CS == 0 && (m0 + 256 <= p.M);       // (a tile with masked rows: some waves issued fewer stores — the strict count is used)
+        stores_behind = m0 + 256 <= p.M;       // (a tile with masked rows: some waves issued fewer stores — the strict count is used)
         w = w_next; tm = tm_n; tn = tn_n;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the last tile's two surplus K tiles
@@ -329,7 +365,11 @@ hipError_t launch_inst4(const GemmParams& p, hipStream_t stream) {
 
 // the shapes gemm_pw3's plain pointwise form takes (bf16 or fp16 operands, N % 256 == 0, an even count of 64-wide K tiles, no residual)
 bool gemm_pw4_supported(const GemmParams& p, bool bf16) {
-    return gemm_pw3_supported(p, bf16);
+    if (!gemm_pw3_supported(p, bf16) || p.f16 || p.Kp < 256) return false;
+    const int epi_ok = p.act1 == ACT_GELU || ((p.act1 == ACT_NONE || p.act1 == ACT_RELU) && !p.colsum);
+    const int ntiles = ((p.M + 255) / 256) * (p.N / 256);
+    // whole tiles only: a grid that does not fill the chip stays on gemm_pw3 (its column halves put every CU to work)
+    return epi_ok && ntiles > pw3_grid_cap(p);
 }
 
 hipError_t launch_gemm_pw4(const GemmParams& p, hipStream_t stream) {

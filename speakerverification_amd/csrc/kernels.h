@@ -88,6 +88,7 @@ struct GemmParams {
     int cv_off = 0;                 // developer option cv_off: 16-bit conv-gather GEMMs stay on the per-tile kernel
     int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
                                     // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
+    int pw4 = 0;                    // option pw4: plain pointwise bf16 layers with more tiles than workgroups run on the four-wave kernel (gemm_pw4.hip)
     int tail_split = 1;             // persistent 16-bit GEMMs: a last partial round of <= G / 2 tiles is walked as column halves (gemm_pw3.hip)
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
     int M = 0, N = 0, K = 0, Kp = 0;

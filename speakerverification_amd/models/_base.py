@@ -131,10 +131,11 @@ class HipModule:
             while len(self._engines) >= self.ENGINE_CACHE:
                 victim = next((k for k in self._engines if k[0] != self._primary), next(iter(self._engines)))
                 self._engines.pop(victim).close()
-            # numeric status (SVHIP_ERR_NONFINITE / _RANGE): a 16-bit handle that reports it has produced something the reference would
-            # not have (an fp16 overflow): raise; an fp32-grade handle hands back what it computed, as the reference does, with a warning
+            # numeric status (SVHIP_ERR_NONFINITE / _RANGE): an fp16 handle that reports it may have produced something the reference would
+            # not have (an fp16 overflow): raise; every other handle (bf16 has fp32's exponent range: a non-finite embedding there means a
+            # non-finite input or weights) hands back what it computed, as the reference does, with a warning per batch
             kw = dict(self._engine_kwargs)
-            kw.setdefault("on_numeric", "warn" if self._compute in ("f32", "fp32", "f32x3") else "raise")
+            kw.setdefault("on_numeric", "raise" if self._is_f16_handle() else "warn")
             eng = Engine(model=self.model_kind, compute=self._compute, max_batch=mb, samples=samples,
                          device=self._device, stream=stream, **kw)
             eng.load_state_dict(self._sd)
@@ -143,6 +144,10 @@ class HipModule:
         else:
             self._engines.move_to_end(key)
         return eng
+
+    def _is_f16_handle(self):
+        """the handle stores activations as IEEE half (RawNet2's 16-bit mode: compute 'f16', or 'half' on a RawNet2 model)"""
+        return self._compute in ("f16", "fp16") or (self._compute == "half" and self.model_kind == "rawnet2")
 
     @staticmethod
     def _squeeze(out):

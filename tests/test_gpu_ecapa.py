@@ -204,6 +204,42 @@ def test_persistent_gemm_matches_the_per_tile_kernel(C, B, cus, monkeypatch):
         assert abs(float(np.abs(x).sum()) - float(np.abs(y).sum())) <= 1e-3 * float(np.abs(x).sum()), n
 
 
+@pytest.mark.parametrize("C,B,cus", [(512, 8, 5), (1024, 6, 8), (512, 5, 3)])
+def test_four_wave_gemm_matches_the_eight_wave_kernel(C, B, cus, monkeypatch):
+    """Round 6: option pw4 routes the plain pointwise bf16 layers with more tiles than workgroups (tdnn1 / tdnn2 / mfa) to gemm_pw4
+    (256 x 256 tiles on FOUR waves, 128 x 128 per wave, one barrier per K tile) instead of gemm_pw3.  Same products in the same k order;
+    the bias joins after the last product instead of before the first, so an output may differ by one rounding of the fp32 sum before it
+    is rounded to bf16.  SVHIP_PW3_CUS caps the grid so that a small batch walks several tiles per workgroup (both constant strips, the
+    relaxed store counts of all three column-sum forms, a masked last M-tile, utterance boundaries inside a wave's 128 rows)."""
+    T = 401
+    mel = synth.synth_mel(B, 80, T, seed=31)
+    monkeypatch.setenv("SVHIP_PW3_CUS", str(cus))
+    eng, _ = make_engine(C, T, B, "bf16", 7)
+    outs, stages, launches = {}, {}, {}
+    for mode in (0, 1):
+        eng.set_option("pw4", mode)
+        eng.profile(True)
+        outs[mode] = eng.embed_features(mel)
+        launches[mode] = eng.profile_results()
+        stages[mode] = {n: stage_cf(eng, n, B, T).astype(np.float32) for n in STAGES}
+        eng.profile(False)
+    again = eng.embed_features(mel)
+    eng.close()
+    assert "gemm_pw4" not in launches[0] and launches[0]["gemm_pw3"]["launches"] >= 6
+    assert launches[1]["gemm_pw4"]["launches"] >= 6, launches[1].keys()
+    assert np.array_equal(again, outs[1])                                   # run to run: bitwise
+    a, b = outs[0], outs[1]
+    assert np.isfinite(b).all()
+    cos = np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    print(f"pw4 vs pw3, C = {C}: cos >= {cos.min():.7f}, max |d| = {np.abs(a - b).max() / np.abs(a).max():.2e} of the scale")
+    assert float(cos.min()) >= 0.99999, cos
+    assert float(np.abs(a - b).max()) <= 5e-3 * float(np.abs(a).max())
+    for n in STAGES:
+        x, y = stages[0][n], stages[1][n]
+        assert float(np.abs(x - y).max()) <= 2e-2 * max(1.0, float(np.abs(x).max())), n
+        assert abs(float(np.abs(x).sum()) - float(np.abs(y).sum())) <= 1e-3 * float(np.abs(x).sum()), n
+
+
 @pytest.mark.parametrize("C,cus", [(512, 3), (1024, 3), (256, 2)])
 def test_f32x3_persistent_gemm_matches_reference(golden_dir, C, cus, monkeypatch):
     """SVHIP_F32X3 handles run tdnn1 / tdnn2 / mfa on the persistent 256 x 256 kernel in its X3 form (operands in the S32 split

@@ -358,6 +358,21 @@ def test_half_plane_score_kernels_take_operands_of_any_magnitude(sa, sb, D):
     A2 = A.copy(); A2[3, 5] = np.nan
     g2 = eng.score_matrix(A2, B)
     assert np.isnan(g2[3]).all() and np.array_equal(np.delete(g2, 3, axis=0), np.delete(got, 3, axis=0))
+    # a non-finite element of the STREAMED operand (B, the cohort) must not set the scale of the finite elements
+    # around it (exponent 255 gave 2^-122: every finite score came back 0).  np.inner gives NaN / inf in that column only.
+    for bad in (np.nan, np.inf):
+        B2 = B.copy(); B2[11, 2] = bad
+        g3 = eng.score_matrix(A, B2)
+        assert not np.isfinite(np.delete(g3[:, 11], 9)).any(), bad              # (row 9 of A is all zeros: 0 * inf = NaN, 0 * NaN = NaN either way)
+        assert np.array_equal(np.delete(g3, 11, axis=1), np.delete(got, 11, axis=1)), bad
+    C2 = C.copy(); C2[123, 7] = np.nan
+    mu3, sd3 = eng.asnorm_stats(E, C2, top)
+    # a NaN cohort score poisons the statistics of every embedding, as sorting NaNs does in the reference; it must NOT come back as finite zeros
+    assert not ((mu3 == 0).all() and (sd3 == 0).all())
+    C3 = C.copy(); C3[123] = np.float32(0.0); C3[123, 0] = np.float32(sb) * np.float32(1e-3)      # a tiny but finite row: statistics as before
+    mu4, sd4 = eng.asnorm_stats(E, C3, top)
+    rmu4, rsd4 = o_scoring.asnorm_stats(E.astype(np.float64), C3.astype(np.float64), top)
+    assert float(np.max(np.abs(mu4 - rmu4) / scale)) <= 2e-7 and float(np.max(np.abs(sd4 - rsd4) / scale)) <= 2e-6
     eng.close()
 
 
