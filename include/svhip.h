@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SVHIP_ABI_VERSION 4
+#define SVHIP_ABI_VERSION 5
 
 typedef struct svhip_handle svhip_handle;
 
@@ -152,7 +152,8 @@ int svhip_crop_pcm16(svhip_handle* h, const int16_t* pcm, int64_t n_samples, con
  *                  mean / std (utils.py:143-146) -> mu[N], sigma[N].  For D in {192, 256}, top <= 256 and K >= 4 top the cohort
  *                  scores never reach memory (fused selection in the half-plane MFMA kernel, csrc/asnorm_fused.hip: the same three-MFMA
  *                  products and the same power-of-two operand scaling as score_matrix; option asnorm_f32mfma: exact fp32 MFMA); otherwise, and for
- *                  the embeddings that kernel cannot decide, they exist only as <= 2 GiB slabs.  svhip_asnorm_last_fallback():
+ *                  the embeddings that kernel cannot decide even with a threshold re-derived from its own counts (up to three more passes over those
+ *                  embeddings only: svhip_asnorm_last_refit()), they exist only as <= 2 GiB slabs.  svhip_asnorm_last_fallback():
  *                  how many embeddings of the last call took the slab path after the fused kernel (-1: the whole call did).
  *   asnorm_pairs : out[p] = 0.5*((s-mu[a])/sd[a] + (s-mu[b])/sd[b]), s = E[a].E[b] (utils.py:148-160).
  * Pointers follow `flags` (indices are int32, device or host like the other inputs). */
@@ -167,6 +168,9 @@ int svhip_asnorm_pairs(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                        const float* sigma, const int32_t* ia, const int32_t* ib, int64_t P,
                        float* out, int32_t flags);
 int64_t svhip_asnorm_last_fallback(const svhip_handle* h);
+/* ABI v5: embeddings of the last svhip_asnorm_stats call whose threshold the fused kernel re-derived from its own counts (cohort scores that
+ * are not normally distributed: clustered speaker centroids) and decided in `*passes` extra passes (NULL: not wanted) instead of the slab path. */
+int64_t svhip_asnorm_last_refit(const svhip_handle* h, int32_t* passes);
 
 /* Whole-trial scores over the crops of two files (what ModelHandling.evaluateFromList needs per trial, src/model.py:413-448):
  * F is the (n_files, n_crops, D) embedding block, ia / ib index files, out[p] is

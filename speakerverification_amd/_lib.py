@@ -69,6 +69,7 @@ _SIGNATURES = {
     "svhip_asnorm_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32]),
     "svhip_asnorm_pairs": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_asnorm_last_fallback": (C.c_int64, [_P]),
+    "svhip_asnorm_last_refit": (C.c_int64, [_P, C.POINTER(C.c_int32)]),
     "svhip_score_trials": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),
     "svhip_mean_crops": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32]),
     "svhip_score_trials_pnorm": (C.c_int, [_P, C.c_float, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P, C.c_int32]),

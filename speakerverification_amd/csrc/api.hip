@@ -75,6 +75,7 @@ struct svhip_handle {
         int score_f32mfma = 0;    // dense score GEMMs (svhip_score_matrix, the slab path's cohort GEMM) on the exact fp32 MFMA instead of the split form
         int score_tiled = 0;      // dense score GEMMs on the tiled split kernel (gemm_pw) instead of the row-streaming one (score_h3w)
         int asnorm_w32 = 0;       // AS-norm two-half-plane kernel on the 32-wide MFMA (round 4's first form) instead of 16x16x32
+        int asnorm_norefit = 0;   // AS-norm: embeddings the normal-quantile threshold does not fit go straight to the slab path (round 5's behaviour)
         int asnorm_2s = 0;        // AS-norm split forms: candidate statistics of chunk c on a second stream under the matrix kernel of chunk c + 1
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
@@ -202,6 +203,8 @@ struct svhip_handle {
     size_t scr_cap[SCR_COUNT] = {};
     hipStream_t aux_stream = nullptr;         // second stream of the scoring entry points (candidate statistics under the next MFMA launch)
     hipEvent_t aux_ev[4] = {};
+    int64_t last_asnorm_refit = 0;            // embeddings of the last call that the refit passes of the fused kernel decided (round 6)
+    int last_asnorm_refit_passes = 0;
     int last_asnorm_flagged = -1;             // embeddings the fused AS-norm kernel handed to the slab path in the last call (-1: slab path)
     struct CropSlot { char* host = nullptr; char* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
     CropSlot crop_slot[4];
@@ -2197,7 +2200,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         if ((rc = scratch(h, svhip_handle::SCR_MB, mb_bytes + mom_bytes + (x6 ? asnorm_planes_bytes(D, K) : 0), &mb))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CAND, cand_elems * 4 * nbuf, &cand))) return rc;
         if ((rc = scratch(h, svhip_handle::SCR_CNT, (cnt_elems + (size_t)chunk) * 4 * nbuf, &cnt))) return rc;      // per buffer: [counts (chunk, 4) | row factors (chunk)]
-        if ((rc = scratch(h, svhip_handle::SCR_FLAG, (size_t)(N + 1) * 4, &flag))) return rc;
+        if ((rc = scratch(h, svhip_handle::SCR_FLAG, (size_t)(2 * N + 1) * 4, &flag))) return rc;        // [count | flagged ids (N) | their candidate counts (N)]
         if (nbuf == 2 && !h->aux_stream) {
             SV_HIP(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
             for (int i = 0; i < 4; ++i) SV_HIP(h, hipEventCreateWithFlags(&h->aux_ev[i], hipEventDisableTiming));
@@ -2237,7 +2240,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             }
             h->cur = st2;
             rc = run(h, "asnorm_cand_stats", 0, [&]() {
-                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2, fp.nlists, fp.rowscale);
+                return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, (float*)dM, (float*)dS, r0, nflag + 1, nflag, st2, fp.nlists, fp.rowscale, nflag + 1 + N);
             });
             h->cur = h->stream;
             if (rc) {           // leave no aux-stream work pending behind a failed call
@@ -2250,9 +2253,105 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
         int32_t nf = 0;
         SV_HIP(h, hipMemcpyAsync(&nf, nflag, 4, hipMemcpyDeviceToHost, h->stream));
         SV_HIP(h, hipStreamSynchronize(h->stream));
+        int64_t refit_rows = 0;
+        int refit_passes = 0;
+        if (nf > 0 && x6 && fp.nlists == 4 && !h->opt.asnorm_norefit) {
+            // REFIT (round 6).  tau = mean + z sd with z the normal quantile fits isotropic embeddings; real cohorts are not isotropic
+            // (speaker centroids cluster by gender / language: bimodal cohort scores), and a row whose threshold passes fewer than `top`
+            // scores, or overflows a list, used to take the slab path — N x K scores through HBM.  Such rows now go through the SAME fused
+            // kernel again with a z of their own, derived from what the last pass counted (next_z below).  At most ASNORM_REFIT_PASSES
+            // passes; what is still undecided after them takes the slab path as before.
+            constexpr int ASNORM_REFIT_PASSES = 3;
+            const float target = fminf(1.6f * (float)top, 0.7f * (float)(2 * ASNORM_CAND_PER_LANE));
+            const float lnT = logf(target);
+            // per row: the last two (z, ln count) measurements and the bracket (zlo passed too many, zhi too few; < -50: none yet)
+            struct RowFit { int32_t id; float z, zp, lcp, zlo, zhi; };
+            std::vector<RowFit> fit((size_t)nf);
+            std::vector<int32_t> ids((size_t)nf), info((size_t)nf);
+            SV_HIP(h, hipMemcpy(ids.data(), nflag + 1, (size_t)nf * 4, hipMemcpyDeviceToHost));
+            SV_HIP(h, hipMemcpy(info.data(), nflag + 1 + N, (size_t)nf * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nf; ++i) fit[i] = RowFit{ids[i], fp.z, -100.f, 0.f, -100.f, -100.f};
+            // The next z of a row from what its last pass counted.  ln(count) against z is locally close to linear; its slope is ~ -(z + 1 / z)
+            // for a Gaussian tail and several times steeper when the threshold sits on the flank of a narrow mode (clustered centroids), so
+            // the FIRST step assumes a slope of -5 (it lands near the target on clustered data and short of it on Gaussian tails) and every
+            // later step is the secant through the last two measurements, kept inside the bracket once both sides have been seen.
+            auto next_z = [&](RowFit& r, int32_t inf) {
+                const float c = (float)(inf & ((1 << 30) - 1));
+                const bool many = ((inf >> 30) & 1) || c > target;       // (a flagged row with enough candidates overflowed a list)
+                const float lc = logf(fmaxf(many ? fmaxf(c, 1.25f * target) : c, 0.5f));
+                if (many) r.zlo = r.zlo > -50.f ? fmaxf(r.zlo, r.z) : r.z; else r.zhi = r.zhi > -50.f ? fminf(r.zhi, r.z) : r.z;
+                float slope = -5.0f;
+                if (r.zp > -50.f && fabsf(r.z - r.zp) > 1e-3f) slope = fminf(-1.0f, fmaxf(-12.0f, (lc - r.lcp) / (r.z - r.zp)));
+                float z = r.z + fminf(0.6f, fmaxf(-0.6f, (lnT - lc) / slope));
+                if (many) z = fmaxf(z, r.z + 0.02f); else z = fminf(z, r.z - 0.02f);
+                if (r.zlo > -50.f && r.zhi > -50.f) {
+                    const float w = r.zhi - r.zlo;
+                    z = fminf(r.zhi - 0.1f * w, fmaxf(r.zlo + 0.1f * w, z));
+                }
+                r.zp = r.z; r.lcp = lc;
+                r.z = fminf(12.0f, fmaxf(-2.0f, z));
+            };
+            for (int i = 0; i < nf; ++i) next_z(fit[i], info[i]);
+            int cur = nf;
+            while (cur > 0 && refit_passes < ASNORM_REFIT_PASSES) {
+                ++refit_passes;
+                void* g;
+                // [gathered rows | mu | sigma | z | ids | flagged ids (1 + cur) | flagged info]
+                const size_t gbytes = (size_t)cur * D * 4 + (size_t)cur * 4 * 6 + 256;
+                if ((rc = scratch(h, svhip_handle::SCR_GATHER, gbytes, &g))) return rc;
+                float* gE = (float*)g;
+                float* gM = gE + (size_t)cur * D;
+                float* gS = gM + cur;
+                float* gZ = gS + cur;
+                int32_t* gI = (int32_t*)(gZ + cur);
+                int32_t* gF = gI + cur;                      // [0] = count, [1 ..] positions within the gathered list
+                int32_t* gInfo = gF + 1 + cur;
+                std::vector<float> zs((size_t)cur);
+                for (int i = 0; i < cur; ++i) { ids[i] = fit[i].id; zs[i] = fit[i].z; }
+                SV_HIP(h, hipMemcpyAsync(gI, ids.data(), (size_t)cur * 4, hipMemcpyHostToDevice, h->stream));
+                SV_HIP(h, hipMemcpyAsync(gZ, zs.data(), (size_t)cur * 4, hipMemcpyHostToDevice, h->stream));
+                SV_HIP(h, hipMemsetAsync(gF, 0, 4, h->stream));
+                if ((rc = run(h, "asnorm_gather", 0, [&]() { return launch_gather_rows((const float*)dE, gI, cur, D, gE, h->stream); }))) return rc;
+                for (int64_t r0 = 0; r0 < cur; r0 += chunk) {
+                    const int64_t rows = std::min<int64_t>(chunk, cur - r0);
+                    fp.E = gE + r0 * D; fp.N = rows; fp.zrow = gZ + r0;
+                    fp.cand = (float*)cand; fp.cnt = (int32_t*)cnt;
+                    fp.rowscale = fp.pscale ? reinterpret_cast<float*>(fp.cnt + cnt_elems) : nullptr;
+                    if ((rc = run(h, "asnorm_fused_refit", 2.0 * rows * K * D, [&]() { return launch_asnorm_fused(fp, D, h->stream); }))) return rc;
+                    if ((rc = run(h, "asnorm_cand_stats", 0, [&]() {
+                            return launch_asnorm_cand_stats(fp.cand, fp.cnt, rows, top, gM, gS, r0, gF + 1, gF, h->stream, fp.nlists, fp.rowscale, gInfo);
+                        }))) return rc;
+                }
+                fp.zrow = nullptr;
+                // (rows that are still undecided scatter whatever their slots hold: a later pass or the slab path overwrites them)
+                if ((rc = run(h, "asnorm_scatter", 0, [&]() { return launch_scatter_stats(gM, gS, gI, cur, (float*)dM, (float*)dS, h->stream); }))) return rc;
+                int32_t left = 0;
+                SV_HIP(h, hipMemcpyAsync(&left, gF, 4, hipMemcpyDeviceToHost, h->stream));
+                SV_HIP(h, hipStreamSynchronize(h->stream));
+                refit_rows += cur - left;
+                if (left > 0) {
+                    std::vector<int32_t> pos((size_t)left), inf2((size_t)left);
+                    SV_HIP(h, hipMemcpy(pos.data(), gF + 1, (size_t)left * 4, hipMemcpyDeviceToHost));
+                    SV_HIP(h, hipMemcpy(inf2.data(), gInfo, (size_t)left * 4, hipMemcpyDeviceToHost));
+                    std::vector<RowFit> nxt((size_t)left);
+                    for (int i = 0; i < left; ++i) { nxt[i] = fit[pos[i]]; next_z(nxt[i], inf2[i]); }
+                    // (the flag order is whatever the atomics gave; a row's result does not depend on where it sits in the gathered list)
+                    fit.swap(nxt);
+                }
+                cur = left;
+            }
+            // what the refit passes could not decide: back into the flag list for the slab path
+            nf = cur;
+            if (nf > 0) {
+                for (int i = 0; i < nf; ++i) ids[i] = fit[i].id;
+                SV_HIP(h, hipMemcpy(nflag + 1, ids.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
+            }
+        }
+        h->last_asnorm_refit = refit_rows;
+        h->last_asnorm_refit_passes = refit_passes;
         if (nf > 0) {
-            // cohort scores too far from normal for the threshold (fewer than `top` candidates, or a list overflowed): these embeddings
-            // are gathered and take the slab path; results are scattered back
+            // cohort scores too far from normal for the threshold (fewer than `top` candidates, or a list overflowed) even after the refit
+            // passes: these embeddings are gathered and take the slab path; results are scattered back
             void* g;
             const size_t gbytes = (size_t)nf * D * 4 + 2 * (size_t)nf * 4 + 64;
             if ((rc = scratch(h, svhip_handle::SCR_GATHER, gbytes, &g))) return rc;
@@ -2267,6 +2366,7 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
     } else {
         if ((rc = asnorm_stats_slab(h, (const float*)dE, N, D, (const float*)dC, K, top, (float*)dM, (float*)dS))) return rc;
         h->last_asnorm_flagged = -1;
+        h->last_asnorm_refit = 0; h->last_asnorm_refit_passes = 0;
     }
     if (!dout) {
         SV_HIP(h, hipMemcpyAsync(mu, dM, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2280,6 +2380,10 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
 }
 
 int64_t svhip_asnorm_last_fallback(const svhip_handle* h) { return h ? h->last_asnorm_flagged : -1; }
+int64_t svhip_asnorm_last_refit(const svhip_handle* h, int32_t* passes) {
+    if (passes) *passes = h ? h->last_asnorm_refit_passes : 0;
+    return h ? h->last_asnorm_refit : 0;
+}
 
 // ---- introspection ---------------------------------------------------------------------------------------
 // ---- verification metrics (metrics.hip) ------------------------------------------------------------------------------------
@@ -2442,7 +2546,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_norefit", &o.asnorm_norefit}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

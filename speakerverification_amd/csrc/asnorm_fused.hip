@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused_kernel(AsnormFusedParams 
         } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of the h = 0 lanes
             const float m = __shfl(a[0], j, 64);
             const float sec = second + __shfl_xor(second, 32, 64);
-            tau = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+            tau = m + (p.zrow ? p.zrow[valid ? row : 0] : p.z) * sqrtf(fmaxf(sec - m * m, 0.0f));
         } else {
             const int kb = (b - NP) * 32 + 4 * h;
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
         } else if (b == NP - 1) {       // row 0 of the last pseudo block is cbar: the mean lives in register 0 of the h = 0 lanes
             const float m = __shfl(a[0], j, 64);
             const float sec = second + __shfl_xor(second, 32, 64);
-            tau = m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f));
+            tau = m + (p.zrow ? p.zrow[valid ? row : 0] : p.z) * sqrtf(fmaxf(sec - m * m, 0.0f));
         } else {
             const int kb = (b - NP) * 32 + 4 * h;
 #pragma unroll
@@ -557,7 +557,8 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
                 sec += __shfl_xor(sec, 16, 64);
                 sec += __shfl_xor(sec, 32, 64);
                 // (rows past N never hit: no separate validity test in the selection below)
-                tau[eg] = valid[eg] ? m + p.z * sqrtf(fmaxf(sec - m * m, 0.0f)) : __builtin_inff();
+                const float zz = p.zrow ? p.zrow[valid[eg] ? row0 + 16 * eg : 0] : p.z;
+                tau[eg] = valid[eg] ? m + zz * sqrtf(fmaxf(sec - m * m, 0.0f)) : __builtin_inff();
             }
         } else {
             // The selection, 32 scores per lane per block.  It issues for the whole wave whenever ONE lane hits (4.7 % of the scores pass:
@@ -810,7 +811,7 @@ template <int NL>
 __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __restrict__ cand, const int32_t* __restrict__ cnt, int64_t rows,
                                                                 int top, float* __restrict__ mu, float* __restrict__ sigma,
                                                                 int64_t row_base, int32_t* __restrict__ flagged, int32_t* __restrict__ nflag,
-                                                                const float* __restrict__ rowscale) {
+                                                                const float* __restrict__ rowscale, int32_t* __restrict__ finfo) {
     constexpr int CAP = 2 * AF_CAPL / NL;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -828,7 +829,11 @@ __global__ __launch_bounds__(256) void asnorm_cand_stats_kernel(const float* __r
 #pragma unroll
     for (int l = 0; l < NL; ++l) { cn[l] = cnt[row * NL + l]; total += cn[l]; over |= cn[l] > CAP; }
     if (total < top || over) {
-        if (lane == 0) flagged[atomicAdd(nflag, 1)] = (int32_t)(row_base + row);
+        if (lane == 0) {
+            const int slot = atomicAdd(nflag, 1);
+            flagged[slot] = (int32_t)(row_base + row);
+            if (finfo) finfo[slot] = min(total, (1 << 30) - 1) | (over ? (1 << 30) : 0);       // what the refit pass starts from
+        }
         return;
     }
     int nq = 2 * AF_CAPL / 64;
@@ -1013,14 +1018,14 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
 }
 
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
-                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists, const float* rowscale) {
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists, const float* rowscale, int32_t* finfo) {
     if (rows <= 0) return hipSuccess;
     if (nlists == 4)
         hipLaunchKernelGGL(asnorm_cand_stats_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
-                           flagged, nflag, rowscale);
+                           flagged, nflag, rowscale, finfo);
     else if (nlists == 2)
         hipLaunchKernelGGL(asnorm_cand_stats_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
-                           flagged, nflag, rowscale);
+                           flagged, nflag, rowscale, finfo);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -391,6 +391,8 @@ struct AsnormFusedParams {
     int K = 0;
     const float* MB = nullptr;      // (D + 32, D): rows of M = C^T C / K, then the cohort mean, then zeros (launch_cohort_moments)
     float z = 0.0f;                 // threshold = row mean + z * row std (asnorm_tail_z)
+    const float* zrow = nullptr;    // optional (N): a z of its own per embedding — the refit passes over the embeddings whose cohort scores the
+                                    // normal quantile did not fit (round 6)
     float* cand = nullptr;          // (N, 2, ASNORM_CAND_PER_LANE) candidate scores
     int32_t* cnt = nullptr;         // (N, 2) scores above the threshold seen by each of the two lanes (may exceed the list size)
     const void* planes = nullptr;   // optional: [nplanes][D + 32 + K][D] 16-bit parts of [MB ; cohort] (launch_asnorm_planes): the split forms
@@ -427,8 +429,9 @@ size_t cohort_moments_scratch_bytes(int D);
 hipError_t launch_cohort_moments(const float* cohort, int K, int D, float* MB, float* part, hipStream_t stream);
 hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t stream);
 // mu / sigma [row_base + r] for r < rows; embeddings that cannot be decided from their candidates: flagged[atomicAdd(nflag, 1)] = index
+// (finfo, optional, parallel to `flagged`: the candidate count of a flagged embedding, bit 30 = one of its lists overflowed)
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
-                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists = 2, const float* rowscale = nullptr);
+                                    int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists = 2, const float* rowscale = nullptr, int32_t* finfo = nullptr);
 hipError_t launch_gather_rows(const float* E, const int32_t* ids, int n, int D, float* out, hipStream_t stream);
 hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* ids, int n, float* mu, float* sigma, hipStream_t stream);
 

@@ -455,6 +455,15 @@ class Engine:
         """embeddings of the last asnorm_stats call that took the slab path after the fused kernel (-1: the whole call did)"""
         return int(self.lib.svhip_asnorm_last_fallback(self.h))
 
+    @property
+    def asnorm_last_refit(self):
+        """(rows, passes): embeddings of the last asnorm_stats call that the fused kernel decided with a threshold re-derived from its own
+        counts (non-Gaussian cohort scores), and the extra passes over them that took"""
+        import ctypes
+        n = ctypes.c_int32(0)
+        rows = int(self.lib.svhip_asnorm_last_refit(self.h, ctypes.byref(n)))
+        return rows, int(n.value)
+
     def asnorm_pairs(self, E, mu, sigma, ia, ib, out=None):
         N, D = E.shape
         P = int(ia.shape[0])

@@ -180,6 +180,30 @@ def synth_mel(batch, n_mels=80, frames=401, seed=11):
     return x.astype(np.float32)
 
 
+def synth_speaker_embeddings(n, n_speakers=5994, dim=192, seed=2, same_cos=(0.5, 0.8), n_groups=1, group_cos=0.35):
+    """Embeddings with the structure trained speaker embeddings have: `n_speakers` unit centroids, embedding i =
+    a c_s(i) + sqrt(1 - a^2) v_i with v_i a random unit direction and a^2 ~ U(same_cos), so that two embeddings of one speaker have cosine
+    a a' in same_cos (the regime of tests/golden/e2e_speakers.npz) and an embedding scores ~a against its own centroid.  n_groups > 1 puts
+    the centroids themselves into groups (gender / language): c_s = sqrt(group_cos) g_k(s) + sqrt(1 - group_cos) u_s, so centroids of one group
+    have cosine ~group_cos and the cohort scores of an embedding are BIMODAL — what the normal-quantile threshold of the fused AS-norm
+    kernel does not fit.  Returns (embeddings (n, dim), centroids (n_speakers, dim), speaker of each embedding), all fp32 / int32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    def unit(shape):
+        x = rng.standard_normal(shape, dtype=np.float32)
+        return x / np.linalg.norm(x, axis=-1, keepdims=True)
+    cent = unit((n_speakers, dim))
+    if n_groups > 1:
+        g = unit((n_groups, dim))
+        grp = np.arange(n_speakers) % n_groups
+        cent = np.float32(np.sqrt(group_cos)) * g[grp] + np.float32(np.sqrt(1.0 - group_cos)) * cent
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    spk = rng.integers(0, n_speakers, n).astype(np.int32)
+    a = np.sqrt(rng.uniform(same_cos[0], same_cos[1], n)).astype(np.float32)[:, None]
+    e = a * cent[spk] + np.sqrt(1.0 - a * a) * unit((n, dim))
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    return e.astype(np.float32), cent.astype(np.float32), spk
+
+
 def synth_embeddings(n, dim=192, seed=2, normalize=True):
     """l2norm(standard_normal((n, dim)))."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.svhip_abi_version() == 4
+    assert lib.svhip_abi_version() == 5
 
 
 def test_default_config_matches_reference_defaults():
