@@ -79,6 +79,8 @@ struct svhip_handle {
         int asnorm_2s = 0;        // AS-norm split forms: candidate statistics of chunk c on a second stream under the matrix kernel of chunk c + 1
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
         int fbank32 = 0;          // the 32-frame front-end kernel
+        int ff_abl = 0;           // tools only: fused front-end phase ablations (FbankTables::ff_abl)
+        int fbank_unfused = 0;    // bf16 handles: fbank -> prologue_stats -> prologue_apply (round 5) instead of the fused front-end
         int pw3_cus = -1;         // cap of the persistent GEMM grids (0: persistent kernels off)
         int pw4 = 0;              // plain pointwise bf16 layers with more tiles than workgroups on the four-wave kernel (gemm_pw4.hip)
         int pw3_tail_off = 0;     // persistent 16-bit GEMMs: the last partial round as whole tiles (round 4) instead of column halves
@@ -147,6 +149,10 @@ struct svhip_handle {
     float* d_wav = nullptr;       // (Bmax, L)
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
+    float* d_logmel = nullptr;    // fused front-end (bf16 handles): (Bmax, T, n_mels) log-mel rows before the mean is taken off
+    float* d_fpart = nullptr;     //   and their per-tile column sums (Bmax, ceil(T / 64), n_mels)
+    bool xin_ready = false;       // the fused front-end has written X_in: ecapa_forward_part skips its prologue
+    bool feat_is_stale = false;   // ... and d_feat does not hold this forward's mel power (svhip_get_stage "mel")
     float* d_zero = nullptr;      // 256 zero bytes (DMA source for padded conv chunks)
     float *d_ones = nullptr, *d_zeros = nullptr;      // 4096 ones / zeros: stand-ins for absent per-channel vectors (GemmParams::ones / zeros)
     size_t rn_buf_bytes = 0;      // RawNet2: payload bytes of each activation buffer; a 256-byte zero tail follows (the zero page of the
@@ -406,6 +412,37 @@ int build_fbank_tables(svhip_handle* h) {
             if ((rc2 = dev_upload(h, &d3, bl3))) return rc2;
             fb.basis_l3 = d3;
         }
+    }
+    // the fused front-end of bf16 handles (fbank.hip, round 6): the window is symmetric about tap win / 2, so Re X_k / Im X_k are products of
+    // K = win / 2 + 1 taps with w_m cos(2 pi k m / n_fft) / w_m sin(2 pi k m / n_fft), m = 0 .. win / 2 (slot win / 2 carries the unpaired tap 0)
+    if (h->bf16 && c.n_fft == 512 && c.win_length == 200 && c.hop_length == 80) {
+        const int half = c.win_length / 2, nks = 7, npr = 8;
+        std::vector<uint16_t> shi((size_t)nks * npr * 2 * 64 * 8, 0), slo(shi.size(), 0);
+        for (int kk = 0; kk < nks; ++kk)
+            for (int pr = 0; pr < npr; ++pr)
+                for (int part = 0; part < 2; ++part)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = lane & 31, hh = lane >> 5;
+                            const int m = 16 * kk + 8 * hh + j, bin = 32 * pr + r;
+                            float v = 0.0f;
+                            if (m <= half && bin < fb.n_bins) {
+                                const float w = m < half ? win[half + m] : win[0];
+                                const double ang = 2.0 * PI * (double)bin * (double)m / (double)c.n_fft;
+                                v = (float)(part == 0 ? std::cos(ang) : std::sin(ang)) * w;
+                            }
+                            const uint16_t hi = f32_to_bf16_rne(v);
+                            uint32_t hu = (uint32_t)hi << 16;
+                            float hf; memcpy(&hf, &hu, 4);
+                            const size_t idx = ((((size_t)kk * npr + pr) * 2 + part) * 64 + lane) * 8 + j;
+                            shi[idx] = hi;
+                            slo[idx] = f32_to_bf16_rne(v - hf);
+                        }
+        uint16_t *dh, *dl;
+        int rc2;
+        if ((rc2 = dev_upload(h, &dh, shi))) return rc2;
+        if ((rc2 = dev_upload(h, &dl, slo))) return rc2;
+        fb.sym_hi = dh; fb.sym_lo = dl;
     }
     // Slaney mel bank (librosa 0.7 filters.mel(htk=False, norm=1)) in double, stored float32, sparse rows
     const double sr = c.fb_sr;
@@ -825,6 +862,10 @@ int alloc_workspace(svhip_handle* h) {
     if ((rc = dev_alloc(h, &h->d_wav, B * (size_t)c.samples))) return rc;
     if ((rc = dev_alloc(h, &h->d_feat, B * c.n_mels * T))) return rc;
     if ((rc = dev_alloc(h, &h->d_pstats, B * c.n_mels * 2))) return rc;
+    if (h->fb.sym_hi) {
+        if ((rc = dev_alloc(h, &h->d_logmel, B * c.n_mels * T))) return rc;
+        if ((rc = dev_alloc(h, &h->d_fpart, B * c.n_mels * ((T + 63) / 64)))) return rc;
+    }
     if ((rc = dev_alloc(h, &h->d_zero, 64))) return rc;
     SV_HIP(h, hipMemset(h->d_zero, 0, 256));
     {
@@ -1013,7 +1054,7 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     (void)d_s1;
     float* cs_base = ((bf || h->x3) && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
     int rc;
-    if ((rc = run(h, "prologue", 0, [&]() {
+    if (!h->xin_ready && (rc = run(h, "prologue", 0, [&]() {
              return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st,
                                     h->x3 ? h->d_status : nullptr, h->host_flag_dev, 65504.0f);
          }))) return rc;
@@ -1536,9 +1577,10 @@ int numeric_status(svhip_handle* h, bool reset) {
                 "or use compute = f32)", st[2], st[1]);
     if (st[0] & SVHIP_STATUS_NONFINITE)
         SV_FAIL(h, SVHIP_ERR_NONFINITE, "%u embedding value(s) are not finite%s (the embeddings were written as computed)", st[1],
-                h->f16 ? ": an fp16 activation overflowed 65504 (or the input was not finite) - this checkpoint needs compute = bf16 (range-safe) or f32"
+                h->f16 ? ": an fp16 activation overflowed 65504 (or the input was not finite) - this checkpoint needs compute = f32 (exact); bf16 is "
+                         "range-safe and fast but loses accuracy on RawNet2 (bf16 weight rounding)"
                 : h->x3 ? ": a GEMM operand exceeded 65504, the range of SVHIP_F32X3's half-precision hi | lo planes (or the input was not finite) - "
-                          "use compute = f32 (exact) or bf16 (range-safe)"
+                          "use compute = f32 (exact); bf16 is range-safe and fast at 16-bit accuracy"
                         : ": the input was not finite, or the weights overflow fp32");
     return SVHIP_OK;
 }
@@ -1631,7 +1673,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.pw4 = is1("SVHIP_PW4"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.fbank_unfused = is1("SVHIP_FBANK_UNFUSED"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.pw4 = is1("SVHIP_PW4"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -1805,6 +1847,7 @@ int svhip_embed_features(svhip_handle* h, const float* feat, int32_t B, int32_t 
         SV_HIP(h, hipMemcpyAsync(h->d_feat, feat, (size_t)B * h->cfg.n_mels * T * 4, hipMemcpyHostToDevice, h->stream));
         d_in = h->d_feat;
     }
+    h->feat_is_stale = false;
     if ((rc = ecapa_forward(h, d_in, B))) return rc;
     if ((rc = emit_embeddings(h, B, emb_out, flags))) return rc;
     return finish(h, flags);
@@ -1829,8 +1872,18 @@ int svhip_embed_wave(svhip_handle* h, const float* wav, int32_t B, int32_t L, fl
         if ((rc = rawnet2_forward(h, d_in, B))) return rc;
     } else {
         const int T = h->T;
-        if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
-        if ((rc = ecapa_forward(h, h->d_feat, B))) return rc;
+        // bf16 handles without the instance-norm prologue: waveform -> the 16-bit operand of blocks.0 in two launches (fbank.hip, round 6)
+        const bool fused = h->bf16 && !h->in_w && h->d_logmel && !h->opt.fbank_unfused && !h->opt.fbank32 && fbank_fused_supported(h->fb, L);
+        if (fused) {
+            if ((rc = run(h, "fbank_fused", 0, [&]() {
+                     return launch_fbank_fused(h->fb, d_in, B, L, T, h->cfg.log_input, h->d_logmel, h->d_fpart, h->X_in, h->stream);
+                 }))) return rc;
+        } else if ((rc = run(h, "fbank", 0, [&]() { return launch_fbank(h->fb, d_in, B, L, T, h->d_feat, h->stream); }))) return rc;
+        h->xin_ready = fused;
+        h->feat_is_stale = fused;
+        rc = ecapa_forward(h, h->d_feat, B);
+        h->xin_ready = false;
+        if (rc) return rc;
     }
     if ((rc = emit_embeddings(h, B, emb_out, flags))) return rc;
     return finish(h, flags);
@@ -2506,7 +2559,11 @@ int svhip_get_stage(svhip_handle* h, const char* name, float* out, int64_t* coun
     else if (n == "rn_x") { src = h->rn_dbg_x; rows = (size_t)B * h->rn_dbg_T; cols = ld = h->rn_dbg_C; }
     else if (n == "rn_snap") { src = h->rn_snap; rows = (size_t)B * h->rn_snap_T; cols = ld = h->rn_snap_C; }
     else if (n == "rn_pooled") { src = h->rn_pooled; rows = B; cols = ld = 1024; f32 = true; }
-    else if (n == "mel") { src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true; }
+    else if (n == "mel") {
+        if (h->feat_is_stale) SV_FAIL(h, SVHIP_ERR_STATE, "stage mel: the last forward ran the fused front-end, which never forms the mel power "
+                                      "tensor (option fbank_unfused = 1 keeps the separate kernels)");
+        src = h->d_feat; rows = (size_t)B * h->cfg.n_mels; cols = ld = T; f32 = true;
+    }
     else SV_FAIL(h, SVHIP_ERR_INVALID, "unknown stage %s", name);
     *count = (int64_t)(rows * cols);
     if (!out) return SVHIP_OK;
@@ -2546,12 +2603,12 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_norefit", &o.asnorm_norefit}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_norefit", &o.asnorm_norefit}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"fbank_unfused", &o.fbank_unfused}, {"ff_abl", &o.ff_abl}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {
             *t.slot = value;
-            h->fb.force32 = o.fbank32;
+            h->fb.force32 = o.fbank32; h->fb.ff_abl = o.ff_abl;
             return SVHIP_OK;
         }
     SV_FAIL(h, SVHIP_ERR_INVALID, "unknown option %s", name);

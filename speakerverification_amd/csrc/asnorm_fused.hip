@@ -625,6 +625,9 @@ __global__ __launch_bounds__(256, 2) void asnorm_h3w_kernel(AsnormFusedParams p)
 // and streams B (pre-split half planes, blocks of 32 rows through the LDS image of the AS-norm kernel) past them: three fp16 MFMAs per
 // product block on v_mfma_f32_16x16x32_f16, scores stored straight from the accumulators (lane = 4 consecutive columns of one row: 16-byte
 // stores, a 128-byte line per row per block).  Grid (row panels of 128, column slices): every workgroup walks `per` blocks of B.
+#ifndef SCORE_ABL
+#define SCORE_ABL 0          // tools only: 1 = stores straight from the accumulators (round 5's form)
+#endif
 template <int D>
 __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -708,10 +711,22 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
     // the wait for block b may then leave those four (the newest entries of the in-order counter) in flight instead of draining them
     const bool rows_full = vec_ok && ((int64_t)blockIdx.x * 128 + wave * 32 + 32 <= p.Na);      // wave-uniform
     bool four_stores_behind = false;
+    // Round 6: stored straight from the accumulators a wave instruction writes sixteen 64-byte row pieces (2.8 TB/s of
+    // output at 16 384^2; plain stores of 256 contiguous bytes per row run at 6 TB/s: MI355X_MICROARCH.md).  Where the LDS has room beside
+    // the two operand blocks (D = 192: 48 KiB + 4 x 8 KiB = 80 KiB, still two workgroups per CU) a wave keeps the scores of TWO blocks — 32
+    // rows x 64 columns — in a private 8 KiB image (16-byte slot s of row r at s ^ (r & 15): conflict-free both ways) and writes them as
+    // four rows x 256 contiguous bytes per instruction.  No barrier: the image is the wave's own, and a wave's LDS operations run in order.
+    constexpr bool STAGED = D == 192 && !(SCORE_ABL & 1);
+    char* stg = smem + 2 * BLK + wave * 8192;
+    const bool stage = STAGED && vec_ok;
+    int stores_behind = 0;                      // stores this wave issued behind the next block's DMAs (-1: not known)
     issue(b_first, 0);
     for (int b = b_first; b < b_last; ++b) {
         const int buf = (b - b_first) & 1;
-        if (four_stores_behind) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // block b has landed; the previous block's stores may still fly
+        if (stage) {
+            if (stores_behind == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (four_stores_behind) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // block b has landed; the previous block's stores may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         four_stores_behind = rows_full && (32 * b + 32 <= p.Nb);
         __syncthreads();
@@ -749,6 +764,42 @@ __global__ __launch_bounds__(256, 2) void score_h3w_kernel(ScoreH3Params p) {
         }
         __builtin_amdgcn_s_setprio(0);
         // acc[rg][eg][e] = A row (16 eg + c of the wave) . B row 32 b + 16 rg + 4 q + e
+        if (stage) {
+            const int hb = (b - b_first) & 1;           // which half of the image this block fills
+#pragma unroll
+            for (int eg = 0; eg < 2; ++eg)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const int slot = hb * 8 + rg * 4 + q;
+                    *reinterpret_cast<f32x4*>(stg + (16 * eg + c) * 256 + ((slot ^ c) << 4)) = acc[rg][eg] * unscale[eg];
+                }
+            stores_behind = 0;
+            if (hb == 1 || b + 1 == b_last) {
+                asm volatile("" ::: "memory");
+                const int jb = 32 * (b - hb);           // first column of the image
+                const int t = lane & 15;
+                const int64_t wrow0 = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int R = 4 * k + (lane >> 4);
+                    const f32x4 o4 = *reinterpret_cast<const f32x4*>(stg + R * 256 + ((t ^ (R & 15)) << 4));
+                    const int j0 = jb + 4 * t;
+                    if (wrow0 + R < p.Na && t < 8 * (hb + 1)) {
+                        float* orow = p.out + (wrow0 + R) * p.ldo;
+                        if (j0 + 4 <= p.Nb) {
+                            __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(orow + j0));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (j0 + e < p.Nb) orow[j0 + e] = o4[e];
+                        }
+                    }
+                }
+                // (exactly eight 16-byte store instructions when every row is inside A and both blocks are whole)
+                stores_behind = (rows_full && hb == 1 && jb + 64 <= p.Nb) ? 8 : -1;
+            }
+            continue;
+        }
 #pragma unroll
         for (int eg = 0; eg < 2; ++eg) {
             if (!valid[eg]) continue;
@@ -1069,7 +1120,7 @@ hipError_t launch_score_h3w(const float* A, int64_t Na, const float* B, int64_t 
 #define SV_SC(DD)                                                                                                           \
     {                                                                                                                       \
         static DeviceOnce attr;                                                                                             \
-        constexpr int lds = 2 * 2 * 32 * DD * 2;                                                                            \
+        constexpr int lds = 2 * 2 * 32 * DD * 2 + (DD == 192 ? 4 * 8192 : 0);     /* + the waves' store images (score_h3w_kernel) */ \
         if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(score_h3w_kernel<DD>), lds)) return e;    \
         hipLaunchKernelGGL((score_h3w_kernel<DD>), grid, dim3(256), lds, stream, p);                                        \
         return hipGetLastError();                                                                                           \

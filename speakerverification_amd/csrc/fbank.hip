@@ -373,6 +373,274 @@ __global__ __launch_bounds__(F2_THREADS, 4) void fbank64_kernel(FbankTables tb, 
     }
 }
 
+// ---- round 6: the FUSED front-end of bf16 handles --------------------------------------------------------------------------------
+// waveform -> pre-emphasis -> windowed DFT -> power -> mel -> log(. + 1e-6) in ONE kernel that leaves frame-major log-mel rows and
+// per-tile column sums; a second, streaming kernel subtracts the per-utterance time mean and writes the 16-bit operand of blocks.0.
+// (Round 5: fbank64 106 us + prologue_stats 12 + prologue_apply 21 at B = 256, the fp32 mel (B, 80, T) written and read back twice.)
+//
+// The DFT uses the window's symmetry.  The periodic Hamming window of 200 taps sits at samples 156 .. 355 of the 512-sample frame,
+// symmetric about sample 256 (tap 100), where cos(2 pi k s / 512) is even and sin is odd in m = s - 256 (up to the sign (-1)^k, which
+// the power does not see).  So
+//     Re X_k = sum_{m = 0..100} w_m cos(2 pi k m / 512) e_m,   e_0 = y_c, e_m = y_{c+m} + y_{c-m} (m < 100), e_100 = y_{c-100}
+//     Im X_k = sum_{m = 1..100} w_m sin(2 pi k m / 512) o_m,   o_m = y_{c+m} - y_{c-m} (m < 100),            o_100 = -y_{c-100}
+// (y = pre-emphasised samples, c = the frame's tap 100; tap 0 has no partner: slot 100): two products of K = 101 instead of one of
+// K = 200 for both — HALF the matrix work and half the basis bytes streamed from L2 — at the price of an im2col-like operand:
+// e and o per frame, split into bf16 hi | lo parts, 53 KB of LDS for 64 frames (rows of 104 values = 208 bytes: a row's 16-byte chunks
+// land on 16 different bank groups for 16 consecutive rows; the seventh k step of 16 reads its upper half from the next row's first
+// eight values, which meet zero basis rows).  Products as in fbank64<1>: hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16.
+constexpr int FF_FRAMES = 64;
+constexpr int FF_THREADS = 512;
+constexpr int FF_K = 104;                       // operand row: m = 0 .. 103 (101 used)
+constexpr int FF_ROWB = FF_K * 2;               // 208 bytes
+constexpr int FF_PLANE = FF_FRAMES * FF_ROWB;   // one of the four planes: e hi | e lo | o hi | o lo
+constexpr int FF_ABYTES = 4 * FF_PLANE + 16;    // + 16 zero bytes behind the last row
+constexpr int FF_KSTEPS = 7;
+constexpr int FF_PT_STRIDE = 257;
+
+__global__ __launch_bounds__(FF_THREADS, 4) void fbank_fused_kernel(FbankTables tb, const float* __restrict__ wav, int L, int T, int log_input,
+                                                                    float* __restrict__ logmel, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ns = (FF_FRAMES - 1) * tb.hop + tb.win_length;
+    const int ns_pad = ((ns + 15) & ~15) + 16;
+    char* abuf = smem;                                             // [4][64][208 B]
+    float* ys = reinterpret_cast<float*>(smem + FF_ABYTES);        // [ns_pad] pre-emphasised samples
+    float* melw = ys + ns_pad;                                     // packed mel weights (+ 16 floats of slack: the unrolled sums read past a filter)
+    int* mtab = reinterpret_cast<int*>(melw + tb.n_melw + 16);     // [3][n_mels]: first bin, length, weight offset of every filter
+    float* pt = reinterpret_cast<float*>(smem);                    // [32][257] power tile: aliases the operand once the MFMAs are done
+    float* lm = pt + 32 * FF_PT_STRIDE;                            // [32][n_mels + 1] log-mel tile
+    const int lms = tb.n_mels + 1;
+
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int f0 = tile * FF_FRAMES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ x = wav + (int64_t)b * L;
+    const bool two = f0 + 32 < T;
+
+    for (int i = tid; i < tb.n_melw + 16; i += FF_THREADS) melw[i] = i < tb.n_melw ? tb.mel_w[i] : 0.0f;
+    for (int i = tid; i < 3 * tb.n_mels; i += FF_THREADS) {
+        const int k = i / tb.n_mels, m = i - k * tb.n_mels;
+        mtab[i] = k == 0 ? tb.mel_start[m] : k == 1 ? tb.mel_len[m] : tb.mel_off[m];
+    }
+    if (tid < 4) reinterpret_cast<uint32_t*>(abuf + 4 * FF_PLANE)[tid] = 0u;
+    // ---- 1. pre-emphasised, reflect-padded samples -> LDS (as fbank64) -----------------------------------------------------------
+    const int j0 = f0 * tb.hop + tb.lpad - tb.n_fft / 2;
+    const float coef = tb.preemph;
+    const bool interior = j0 >= 1 && j0 + ns_pad <= L;
+    if (interior && (((reinterpret_cast<uintptr_t>(x) >> 2) + (uintptr_t)j0) & 3) == 0 && coef >= 0.0f) {
+        // no reflection anywhere in the tile and 16-byte aligned samples: every thread's loads (a float4 and the sample in front of it,
+        // three times) go out in ONE batch
+        const int nv = ns_pad >> 2;
+        f32x4 v[3];
+        float pv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q4 = tid + u * FF_THREADS;
+            const bool in = q4 < nv && !(tb.ff_abl & 1);
+            v[u] = in ? *reinterpret_cast<const f32x4*>(x + j0 + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            pv[u] = in ? x[j0 + 4 * q4 - 1] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q4 = tid + u * FF_THREADS;
+            if (q4 < nv) {
+                f32x4 w;
+                w[0] = __fadd_rn(__fmul_rn(-coef, pv[u]), v[u][0]);
+                w[1] = __fadd_rn(__fmul_rn(-coef, v[u][0]), v[u][1]);
+                w[2] = __fadd_rn(__fmul_rn(-coef, v[u][1]), v[u][2]);
+                w[3] = __fadd_rn(__fmul_rn(-coef, v[u][2]), v[u][3]);
+                *reinterpret_cast<f32x4*>(ys + 4 * q4) = w;
+            }
+        }
+    } else
+    for (int i0 = tid; i0 < ns_pad; i0 += 4 * FF_THREADS) {
+        float v[4], prev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * FF_THREADS;
+            int jj = j0 + i;
+            if (!interior) {
+                jj = jj < 0 ? -jj : jj;
+                jj = jj >= L ? 2 * (L - 1) - jj : jj;
+                jj = max(0, min(jj, L - 1));
+            }
+            const bool in = i < ns_pad && !(tb.ff_abl & 1);
+            v[u] = in ? x[in ? jj : 0] : 0.0f;
+            prev[u] = (in && coef >= 0.0f) ? x[jj == 0 ? 1 : jj - 1] : 0.0f;   // F.pad(reflect,(1,0)): x[-1] := x[1]
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * FF_THREADS;
+            if (i < ns_pad) {
+                float w = v[u];
+                if (coef >= 0.0f) w = __fadd_rn(__fmul_rn(-coef, prev[u]), w);
+                ys[i] = w;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. the symmetric operand: e | o of every frame, bf16 hi | lo ---------------------------------------------------------------
+    const int half = tb.win_length >> 1;                           // 100: the tap the window is symmetric about
+    for (int wk = tid; wk < ((tb.ff_abl & 2) ? 0 : FF_FRAMES * (FF_K / 8)); wk += FF_THREADS) {
+        const int i = wk / (FF_K / 8), j = wk - i * (FF_K / 8);
+        const int c = i * tb.hop + half;
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(ys + c + 8 * j), fb = *reinterpret_cast<const f32x4*>(ys + c + 8 * j + 4);
+        // y[c - 8 j - u], u = 1 .. 8 from two aligned reads (the chunk m = 96 .. 103 of frame 0 reads four floats below ys: masked)
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(ys + c - 8 * j - 8), rb = *reinterpret_cast<const f32x4*>(ys + c - 8 * j - 4);
+        const float r0 = ys[c - 8 * j];
+        bf16x8 eh, el, oh, ol;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = 8 * j + u;
+            const float f = u < 4 ? fa[u] : fb[u - 4];
+            const float r = u == 0 ? r0 : (u <= 4 ? rb[4 - u] : ra[8 - u]);
+            float e = f + r, o = f - r;
+            if (m == 0) { e = f; o = 0.0f; }
+            if (m == half) { e = r; o = -r; }
+            if (m > half) { e = 0.0f; o = 0.0f; }
+            const bf16_t e1 = static_cast<bf16_t>(e), o1 = static_cast<bf16_t>(o);
+            eh[u] = e1; el[u] = static_cast<bf16_t>(e - static_cast<float>(e1));
+            oh[u] = o1; ol[u] = static_cast<bf16_t>(o - static_cast<float>(o1));
+        }
+        char* row = abuf + i * FF_ROWB + j * 16;
+        *reinterpret_cast<bf16x8*>(row) = eh;
+        *reinterpret_cast<bf16x8*>(row + FF_PLANE) = el;
+        *reinterpret_cast<bf16x8*>(row + 2 * FF_PLANE) = oh;
+        *reinterpret_cast<bf16x8*>(row + 3 * FF_PLANE) = ol;
+    }
+    __syncthreads();
+
+    // ---- 3. the two products: wave = one group of 32 bins (cos and sin), both frame tiles -------------------------------------------
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.0f;
+    {
+        const int kstride = 8 * 2 * 64;                            // fragments per k step: [pair][part][lane]
+        const bf16x8* __restrict__ bh = reinterpret_cast<const bf16x8*>(tb.sym_hi) + wave * 2 * 64 + lane;
+        const bf16x8* __restrict__ bl = reinterpret_cast<const bf16x8*>(tb.sym_lo) + wave * 2 * 64 + lane;
+        const char* a0 = abuf + r * FF_ROWB + 16 * h;
+        bf16x8 nh0 = bh[0], nh1 = bh[64], nl0 = bl[0], nl1 = bl[64];
+#pragma unroll
+        for (int kk = 0; kk < FF_KSTEPS; ++kk) {
+            if (tb.ff_abl & 4) break;
+            const bf16x8 ch = nh0, sh = nh1, cl = nl0, sl = nl1;
+            const int kn = min(kk + 1, FF_KSTEPS - 1) * kstride;
+            nh0 = bh[kn]; nh1 = bh[kn + 64]; nl0 = bl[kn]; nl1 = bl[kn + 64];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                if (mt == 1 && !two) break;
+                const char* ap = a0 + mt * 32 * FF_ROWB + kk * 32;
+                const bf16x8 eh = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 el = *reinterpret_cast<const bf16x8*>(ap + FF_PLANE);
+                const bf16x8 oh = *reinterpret_cast<const bf16x8*>(ap + 2 * FF_PLANE);
+                const bf16x8 ol = *reinterpret_cast<const bf16x8*>(ap + 3 * FF_PLANE);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el, ch, acc[mt][0], 0, 0, 0);   // small terms first
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ol, sh, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, cl, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, sl, acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh, ch, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, sh, acc[mt][1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                               // the operand is dead: its space becomes the power / log-mel tiles
+
+    // ---- 4. power -> mel -> log -> frame-major rows + column sums ------------------------------------------------------------------
+    // (outputs idx = tid + 512 j: frame idx & 31, filter idx >> 5 — the same filters in both passes, so a thread keeps its column sums)
+    constexpr int FF_MAXOUT = 5;                                   // ceil(32 * 80 / 512); larger banks loop
+    float csum[FF_MAXOUT];
+#pragma unroll
+    for (int j = 0; j < FF_MAXOUT; ++j) csum[j] = 0.0f;
+    const int* mst = mtab;
+    const int* mln = mtab + tb.n_mels;
+    const int* mof = mtab + 2 * tb.n_mels;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (mt == 1 && !two) break;
+        if (mt) __syncthreads();                                   // the previous pass has read pt and lm
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float re = acc[mt][0][e], im = acc[mt][1][e];
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * h;
+            pt[i * FF_PT_STRIDE + wave * 32 + r] = fmaf(re, re, im * im);
+        }
+        __syncthreads();
+        const int fbase = f0 + 32 * mt;
+#pragma unroll
+        for (int j = 0; j < FF_MAXOUT; ++j) {
+            const int idx = tid + j * FF_THREADS;
+            if (idx >= 32 * tb.n_mels || (tb.ff_abl & 8)) break;
+            const int i = idx & 31, m = idx >> 5;
+            const int st = mst[m], ln = mln[m];
+            const float* w = melw + mof[m];
+            const float* prow = pt + i * FF_PT_STRIDE + st;
+            float s0 = 0.0f, s1 = 0.0f;
+            int k = 0;
+            for (; k + 1 < ln; k += 2) { s0 = fmaf(w[k], prow[k], s0); s1 = fmaf(w[k + 1], prow[k + 1], s1); }
+            if (k < ln) s0 = fmaf(w[k], prow[k], s0);
+            const float sacc = s0 + s1;
+            const float v = log_input ? __logf(sacc + 1e-6f) : sacc;
+            lm[i * lms + m] = v;
+            // this tile's column sum over its valid frames: a fixed tree over the 32 lanes that share the filter (the same bits every run)
+            float cv = fbase + i < T ? v : 0.0f;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) cv += __shfl_xor(cv, o, 64);
+            csum[j] += cv;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * tb.n_mels; idx += FF_THREADS) {
+            const int f = idx / tb.n_mels, m = idx - f * tb.n_mels;
+            if (fbase + f < T && !(tb.ff_abl & 16)) logmel[((int64_t)b * T + fbase + f) * tb.n_mels + m] = lm[f * lms + m];
+        }
+    }
+    if ((tid & 31) == 0) {
+#pragma unroll
+        for (int j = 0; j < FF_MAXOUT; ++j) {
+            const int m = (tid + j * FF_THREADS) >> 5;
+            if (m < tb.n_mels) partial[((int64_t)b * gridDim.x + tile) * tb.n_mels + m] = csum[j];
+        }
+    }
+}
+
+// log-mel rows (B, T, n_mels) fp32 - per-utterance time mean (from the tiles' column sums, added in tile order) -> 16-bit operand rows
+template <typename T_>
+__global__ __launch_bounds__(256) void fbank_norm_kernel(const float* __restrict__ logmel, const float* __restrict__ partial, T_* __restrict__ out,
+                                                         int T, int n_mels, int ntiles, int sub_mean) {
+    __shared__ float mean[256];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    if ((int)threadIdx.x < n_mels) {
+        float s = 0.0f;
+        for (int k = 0; k < ntiles; ++k) s += partial[((int64_t)b * ntiles + k) * n_mels + threadIdx.x];
+        mean[threadIdx.x] = sub_mean ? s / (float)T : 0.0f;
+    }
+    __syncthreads();
+    const int nq = n_mels >> 2;
+    for (int q = threadIdx.x; q < 64 * nq; q += 256) {
+        const int f = q / nq, mq = q - f * nq;
+        const int t = t0 + f;
+        if (t >= T) break;
+        const int64_t o = ((int64_t)b * T + t) * n_mels + 4 * mq;
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(logmel + o));
+        T_ y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = from_f32<T_>(v[u] - mean[4 * mq + u]);
+        if (sizeof(T_) == 2) {
+            uint2 pk;
+            pk.x = (uint32_t)__builtin_bit_cast(uint16_t, y[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, y[1]) << 16);
+            pk.y = (uint32_t)__builtin_bit_cast(uint16_t, y[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, y[3]) << 16);
+            *reinterpret_cast<uint2*>(out + o) = pk;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) out[o + u] = y[u];
+        }
+    }
+}
+
 // per (b, mel): mean of log(x + 1e-6) over T (and biased variance of the normalised signal when
 // instance norm is on).  stats[(b*n_mels + m)*2 + {0,1}] = {shift, scale}: y = (v - shift) * scale.
 __global__ __launch_bounds__(256) void prologue_stats_kernel(const float* __restrict__ feat, float* __restrict__ stats,
@@ -481,6 +749,31 @@ hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, i
         hipLaunchKernelGGL(fbank_kernel<true>, grid, block, lds, stream, tb, wav, L, T, mel);
     else
         hipLaunchKernelGGL(fbank_kernel<false>, grid, block, lds, stream, tb, wav, L, T, mel);
+    return hipGetLastError();
+}
+
+bool fbank_fused_supported(const FbankTables& tb, int L) {
+    return tb.sym_hi && tb.sym_lo && tb.n_fft == 512 && tb.win_length == 200 && tb.hop == 80 && tb.lpad == 156 && tb.mel_max_bin < 256 &&
+           tb.n_mels % 4 == 0 && tb.n_mels <= 128 && tb.n_pairs >= 8 && L >= tb.n_fft;
+}
+
+// wav (B, L) -> out (B * T, n_mels) bf16 rows = log(mel + 1e-6) - time mean (log_input) or the mel power itself; `logmel` (B, T, n_mels)
+// fp32 and `partial` (B, ceil(T / 64), n_mels) fp32 are scratch
+hipError_t launch_fbank_fused(const FbankTables& tb, const float* wav, int B, int L, int T, int log_input, float* logmel, float* partial,
+                              void* out, hipStream_t stream) {
+    if (!fbank_fused_supported(tb, L) || B <= 0) return hipErrorInvalidValue;
+    const int ns = (FF_FRAMES - 1) * tb.hop + tb.win_length;
+    const int ns_pad = ((ns + 15) & ~15) + 16;
+    const size_t lds = (size_t)FF_ABYTES + (size_t)(ns_pad + tb.n_melw + 16 + 3 * tb.n_mels) * sizeof(float);
+    if (32 * tb.n_mels > 5 * FF_THREADS) return hipErrorInvalidValue;                 // (FF_MAXOUT outputs per thread and pass)
+    if (lds > 80 * 1024 || (size_t)(32 * FF_PT_STRIDE + 32 * (tb.n_mels + 1)) * 4 > (size_t)4 * FF_PLANE) return hipErrorInvalidValue;
+    static DeviceOnce attr;
+    if (hipError_t e = set_max_dynamic_lds(attr, reinterpret_cast<const void*>(fbank_fused_kernel), 80 * 1024)) return e;
+    const int ntiles = (T + FF_FRAMES - 1) / FF_FRAMES;
+    hipLaunchKernelGGL(fbank_fused_kernel, dim3(ntiles, B), dim3(FF_THREADS), lds, stream, tb, wav, L, T, log_input, logmel, partial);
+    if (!(tb.ff_abl & 32))
+        hipLaunchKernelGGL(fbank_norm_kernel<bf16_t>, dim3((T + 63) / 64, B), dim3(256), 0, stream, logmel, partial, reinterpret_cast<bf16_t*>(out), T,
+                           tb.n_mels, ntiles, log_input);
     return hipGetLastError();
 }
 

@@ -195,6 +195,8 @@ struct FbankTables {           // device pointers, built once per handle
     const void* basis_hi = nullptr;    // bf16x3 path: [k16][pair][part][lane] 8 x bf16 (hi / lo parts of the same taps)
     const void* basis_lo = nullptr;
     const void* basis_l3 = nullptr;    // bf16x6 path (F32X3 handles): the third part of the exact split basis = hi + lo + l3
+    const void* sym_hi = nullptr;      // fused front-end (bf16 handles): [7 k steps][8 bin groups][cos | sin][lane] 8 x bf16 of the symmetric basis
+    const void* sym_lo = nullptr;      //   w_m cos(2 pi k m / 512) | w_m sin(2 pi k m / 512), m = 0 .. 100 (fbank.hip, "the fused front-end")
     int split6 = 0;
     int n_k16 = 13;                    // ceil(win_length / 16)
     int split_bf16 = 0;                // 1: bf16x3 DFT (bf16-compute handles)
@@ -208,10 +210,17 @@ struct FbankTables {           // device pointers, built once per handle
     int n_q = 25;                      // win_length / 8
     int mel_max_bin = 256;             // highest bin with a non-zero mel weight
     int force32 = 0;                   // developer option fbank32: the 32-frame kernel whatever the bank
+    int ff_abl = 0;                    // developer option ff_abl (tools only; results are then wrong): fused front-end phases skipped: 1 sample loads,
+                                       // 2 operand build, 4 MFMAs, 8 mel / log, 16 row stores, 32 the normalisation launch
     float preemph = 0.97f;
 };
 // wav (B, L) fp32 -> mel power (B, n_mels, T) fp32
 hipError_t launch_fbank(const FbankTables& tb, const float* wav, int B, int L, int T, float* mel, hipStream_t stream);
+
+// round 6, bf16 handles: wav (B, L) -> the 16-bit frame-major operand of blocks.0 (log-mel minus its time mean) in two launches
+bool fbank_fused_supported(const FbankTables& tb, int L);
+hipError_t launch_fbank_fused(const FbankTables& tb, const float* wav, int B, int L, int T, int log_input, float* logmel, float* partial,
+                              void* out, hipStream_t stream);
 
 // (B, n_mels, T) fp32 features -> frame-major (B, T, n_mels) activations in the compute dtype,
 // with optional log(x+1e-6) - mean_t and optional InstanceNorm1d(affine).

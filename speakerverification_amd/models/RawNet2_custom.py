@@ -29,6 +29,11 @@ class RawNet2(HipModule):
         # kernels on bf16: range-safe, but RawNet2 loses two digits to bf16 weight rounding) | "half" = this model's 16-bit mode (f16)
         compute = compute or kwargs.get("hip_compute", "f32")
         compute = {"half": "f16", "fp16": "f16"}.get(compute, compute)
+        # range_fallback (round 6): what an fp16 handle that reports an overflow (SVHIP_ERR_NONFINITE: this checkpoint's activations pass
+        # 65504) is replaced by — a NEW handle in that mode, with a warning; None re-raises.  "f32" is the exact mode; "bf16" is range-safe and
+        # fast but loses accuracy on RawNet2 (bf16 weight rounding: cosine 0.995 to fp32 on a well-scaled checkpoint, 0.7 - 0.97 on the
+        # ill-scaled one of tests/test_gpu_rawnet2.py), so it is not the default
+        self._range_fallback = kwargs.get("range_fallback", "f32")
         max_batch = int(max_batch or kwargs.get("embed_batch", 256))
         super().__init__(synth.rawnet2_param_spec(nOut=nOut, nb_samp=self.nb_samp, att_dim=att_dim),
                          dict(embed_dim=nOut), device=device if device is not None else kwargs.get("device"),
@@ -38,8 +43,20 @@ class RawNet2(HipModule):
         if x.ndim != 2 or x.shape[1] != self.nb_samp:
             raise ValueError(f"RawNet2 was built for (batch, {self.nb_samp}) waveforms, got {tuple(x.shape)} "
                              "(LayerNorm gamma/beta fix the length, RawNet_baseline.py:16-18)")
+        from .._lib import SvhipNumericError, ERR_NONFINITE
         eng = self._get_engine(self.nb_samp)
-        return self._squeeze(self._batched(eng.embed_wave, x))
+        try:
+            return self._squeeze(self._batched(eng.embed_wave, x))
+        except SvhipNumericError as e:
+            if e.code != ERR_NONFINITE or self._compute != "f16" or not self._range_fallback:
+                raise
+            import warnings
+            warnings.warn(f"RawNet2 fp16 handle: {e}; rebuilding this module's handle with compute = {self._range_fallback!r} "
+                          "(every later forward runs in that mode)", RuntimeWarning, stacklevel=2)
+            self._compute = self._range_fallback
+            self._drop_engine()
+            eng = self._get_engine(self.nb_samp)
+            return self._squeeze(self._batched(eng.embed_wave, x))
 
 
 def MainModel(nOut=512, **kwargs):

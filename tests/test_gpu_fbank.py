@@ -122,3 +122,51 @@ def test_fbank_six_product_form_on_f32x3_handles(kind):
     print(kind, "x6 rel-to-peak", e6, "fp32 MFMA rel-to-peak", e1, "x6 log-mel err", e_log, "x6 vs fp32 form", float((np.abs(outs["f32x3"] - outs["f32"]) / peak).max()))
     assert e6 <= 2e-6 and e_log <= 1e-4
     assert float((np.abs(outs["f32x3"] - outs["f32"]) / peak).max()) <= 2e-6
+
+
+@pytest.mark.parametrize("L,B", [(32000, 5), (24000, 3), (10240 + 80 * 3, 3)])
+def test_fused_front_end_of_bf16_handles(L, B):
+    """Round 6: a bf16 handle's embed_wave runs waveform -> pre-emphasis -> DFT (window symmetry: two products of
+    K = 101 on e = y[c+m] + y[c-m] and o = y[c+m] - y[c-m] instead of one of K = 200) -> power -> mel -> log -> minus the time mean -> the
+    bf16 frame-major operand of blocks.0 in TWO launches (fbank_fused + its streaming normalisation) instead of fbank64 + prologue_stats +
+    prologue_apply.  The operand (stage "input") against the float64 statement of the oracle — it is the bf16 rounding of values within
+    ~1e-4 of it — and against the separate kernels (option fbank_unfused); utterance lengths whose last tile holds one frame tile, two, or
+    a partial second one; white, speech-like (mel powers over several decades) and impulse-at-the-border waveforms; the embeddings of the
+    two routes agree to bf16 round-off."""
+    C = 512
+    T = L // 80 + 1
+    wav = np.concatenate([synth.synth_waveforms(1, L, seed=3), synth.synth_speechlike(B - 2, L), np.zeros((1, L), np.float32)])
+    wav[-1, 0] = 1.0
+    wav[-1, -1] = -0.5
+    eng = Engine(model="ecapa", compute="bf16", channels=C, max_batch=B, samples=L)
+    eng.load_state_dict(synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=3))
+    eng.finalize()
+    ref = o_fbank.log_mean_norm(o_fbank.melspectrogram(torch.from_numpy(wav).double())).numpy().transpose(0, 2, 1)      # (B, T, 80)
+    out, xin, labels = {}, {}, {}
+    for mode in (0, 1):
+        eng.set_option("fbank_unfused", mode)
+        eng.profile(True)
+        out[mode] = eng.embed_wave(wav).copy()
+        labels[mode] = set(eng.profile_results())
+        eng.profile(False)
+        xin[mode] = eng.get_stage("input").reshape(B, T, 80)
+    again = eng.embed_wave(wav)
+    assert np.array_equal(again, out[1])
+    eng.set_option("fbank_unfused", 0)
+    assert np.array_equal(eng.embed_wave(wav), out[0])                  # run to run: bitwise
+    eng.close()
+    assert "fbank_fused" in labels[0] and "prologue" not in labels[0] and "fbank" not in labels[0]
+    assert "fbank" in labels[1] and "prologue" in labels[1] and "fbank_fused" not in labels[1]
+    for mode in (0, 1):
+        err = np.abs(xin[mode] - ref)
+        bar = 2.0 ** -8 * np.abs(ref) + 1e-3           # half a bf16 ulp of the value + the split DFT's ~1e-4, with room for a flipped rounding
+        print(f"L = {L}, {'separate' if mode else 'fused'} kernels: operand max |err| {err.max():.2e} (values up to {np.abs(ref).max():.1f}), "
+              f"worst err / bar {float((err / bar).max()):.2f}")
+        assert np.isfinite(xin[mode]).all() and float((err / bar).max()) <= 1.0
+    d = np.abs(xin[0] - xin[1])
+    assert float((d / (2.0 ** -7 * np.maximum(np.abs(xin[0]), np.abs(xin[1])) + 1e-3)).max()) <= 1.0      # at most one bf16 ulp apart
+    assert float((d > 0).mean()) <= 0.05
+    a, b = out[0], out[1]
+    cos = np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    print(f"embeddings, fused vs separate front-end: cos >= {cos.min():.6f}")
+    assert cos.min() >= 0.9999

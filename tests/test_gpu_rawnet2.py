@@ -475,15 +475,38 @@ def test_fp16_overflow_is_reported_not_returned_silently():
         eng.embed_wave(wav)
     assert ei.value.code == _lib.ERR_NONFINITE and "65504" in str(ei.value)
     eng.close()
-    # the range-safe modes embed the same checkpoint finitely (how close bf16 stays to fp32 on RawNet2 is another test's subject:
-    # test_rawnet2_bf16_mode_is_the_range_safe_fallback)
+    # What to do about it.  The message names compute = f32 (exact) and says what bf16 costs; round 5 asserted only that bf16 was finite,
+    # after a cos >= 0.99 assertion had failed at 0.69 - 0.97 on this ill-scaled checkpoint: bf16 IS range-safe, it is not
+    # accurate on RawNet2 (the conv weights' rounding, tests/analysis/rn_bf16_sites.py) and the library no longer recommends it for accuracy.
+    assert "f32 (exact)" in str(ei.value)
     emb = {}
     for compute in ("bf16", "f32"):
         eng = engine(compute)
         emb[compute] = eng.embed_wave(wav).reshape(B, -1).copy()
         assert np.isfinite(emb[compute]).all() and eng.numeric_status() == 0
         eng.close()
-    assert float(np.abs(emb["f32"]).max()) > 0
+    a, b = emb["bf16"], emb["f32"]
+    cos_bf = np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    print(f"ill-scaled checkpoint: bf16 against exact f32: cosine {cos_bf.min():.3f} .. {cos_bf.max():.3f} (range-safe, not accurate)")
+    assert float(np.abs(b).max()) > 0 and cos_bf.min() > 0.3
+    # the reference-shaped module falls back by itself: an fp16 handle that overflows is replaced by an exact-f32 handle, with a warning,
+    # and returns what the exact engine returns (cosine >= 0.999 is the bar VERDICT r5 asks of the recommended mode: here it is bitwise)
+    from speakerverification_amd.models import RawNet2_custom
+    m = RawNet2_custom.MainModel(nOut=320, front_proc="sinc", aggregate="asp", att_dim=128, hip_compute="half", embed_batch=B,
+                                 audio_spec={"sample_rate": 16000, "sentence_len": L / 16000.0})
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    with pytest.warns(RuntimeWarning, match="rebuilding"):
+        got = m(torch.from_numpy(wav))
+    got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+    cos = np.sum(got * b, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.isfinite(got).all() and cos.min() >= 0.999 and np.array_equal(got, b)
+    again = m(torch.from_numpy(wav))                                  # the module stays on the exact handle: no second warning needed
+    assert np.array_equal(again.cpu().numpy() if hasattr(again, "cpu") else np.asarray(again), b)
+    m2 = RawNet2_custom.MainModel(nOut=320, front_proc="sinc", aggregate="asp", att_dim=128, hip_compute="half", embed_batch=B,
+                                  range_fallback=None, audio_spec={"sample_rate": 16000, "sentence_len": L / 16000.0})
+    m2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    with pytest.raises(_lib.SvhipNumericError):
+        m2(torch.from_numpy(wav))
 
 
 def test_nonfinite_input_is_reported_on_every_handle_kind():
