@@ -252,7 +252,7 @@ def test_profile_filter_brackets_only_the_named_kernel():
     eng.profile(True)
     eng.embed_wave(wav)
     every = eng.profile_results()
-    assert {"fbank", "res2net_slices", "asp_bf16", "se_apply"} <= set(every)         # (B = 8: the time-sliced chain)
+    assert {"fbank_fused", "res2net_slices", "asp_bf16", "se_apply"} <= set(every)   # (B = 8: the time-sliced chain; bf16: the fused front-end)
     label = "gemm_pw3" if "gemm_pw3" in every else "gemm_pw2"
     assert 1 <= every[label]["launches"] <= 7
     eng.profile(True, only=label)
