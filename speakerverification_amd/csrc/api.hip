@@ -31,6 +31,7 @@ struct ConvLayer {            // one conv1d as a GEMM operand set (device pointe
     int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, dil = 1, cin = 0;
     void* W = nullptr;        // packed [Np][Kp] in the compute dtype
     void* Wsplit = nullptr;   // SVHIP_F32X3 handles: the same matrix as (hi bf16 << 16 | lo bf16) words, for gemm_pw's split path
+    float cv_wscale = 1.0f;   // ... whose planes hold cv_wscale * W (an exact power of two; 1 unless max |w| lies outside [2^-8, 2^13))
     void* Wcv = nullptr;      // SVHIP_F32X3 handles, odd-tap convolutions with N % 256 == 0 (blocks.0): [N][cv_Kp] S32, k = tap * cv_cin + c with the
     int cv_cin = 0, cv_Kp = 0; // input channels zero-padded to cv_cin (a multiple of 32) and cv_Kp = taps * cv_cin rounded up to 64: gemm_pw3's CV form
     void* Ws32 = nullptr;     // SVHIP_F32X3 handles, pointwise layers with N % 256 == 0 and K % 64 == 0: the S32 split layout (per row, per
@@ -149,6 +150,7 @@ struct svhip_handle {
     float* d_wav = nullptr;       // (Bmax, L)
     float* d_feat = nullptr;      // (Bmax, n_mels, T) mel power
     float* d_pstats = nullptr;    // (Bmax*n_mels*2)
+    float* d_xscale = nullptr;    // F32X3: [0] = s, [1] = 1 / s of the network input (launch_in_scale), then 256 partial max words
     float* d_logmel = nullptr;    // fused front-end (bf16 handles): (Bmax, T, n_mels) log-mel rows before the mean is taken off
     float* d_fpart = nullptr;     //   and their per-tile column sums (Bmax, ceil(T / 64), n_mels)
     bool xin_ready = false;       // the fused front-end has written X_in: ecapa_forward_part skips its prologue
@@ -626,11 +628,20 @@ int make_conv(svhip_handle* h, ConvLayer& L, const std::string& wname, const std
             }
             if (taps >= 3 && taps <= 7 && (taps & 1) && N % 256 == 0 && N != cin) {      // the conv-gather X3 form (gemm_pw3cv)
                 const int ccv = round_up(cin, 32), kcv = round_up(taps * ccv, 64);
+                // the first convolution of the network meets features of whatever magnitude the checkpoint was trained on: weights fitted to
+                // int16-scaled mel power are ~1e-10 — below the half planes' resolution.  Outside the ordinary range the planes hold sw * W,
+                // sw an exact power of two (max |w| -> [64, 128)); the kernel multiplies back together with the input's scale (GemmParams::in_scale)
+                float wmax = 0.0f;
+                for (int n = 0; n < N; ++n)
+                    for (int k = 0; k < L.K; ++k) { const float a = std::fabs(packed[(size_t)n * L.Kp + k]); if (std::isfinite(a) && a > wmax) wmax = a; }
+                float sw = 1.0f;
+                if (wmax > 0.0f && !(wmax >= 0x1p-8f && wmax < 0x1p13f)) { int e2; (void)std::frexp(wmax, &e2); sw = std::ldexp(1.0f, 7 - e2); }
+                L.cv_wscale = sw;
                 std::vector<uint16_t> s32((size_t)N * kcv * 2, 0);
                 for (int n = 0; n < N; ++n)
                     for (int t = 0; t < taps; ++t)
                         for (int c = 0; c < cin; ++c) {
-                            const uint32_t wv = ws[(size_t)n * L.Kp + t * cin + c];
+                            const uint32_t wv = sw == 1.0f ? ws[(size_t)n * L.Kp + t * cin + c] : x3_split_word(packed[(size_t)n * L.Kp + t * cin + c] * sw);
                             const int k = t * ccv + c;
                             const size_t o = (size_t)n * kcv * 2 + (size_t)(k >> 5) * 64 + (k & 31);
                             s32[o] = (uint16_t)(wv >> 16);
@@ -862,6 +873,7 @@ int alloc_workspace(svhip_handle* h) {
     if ((rc = dev_alloc(h, &h->d_wav, B * (size_t)c.samples))) return rc;
     if ((rc = dev_alloc(h, &h->d_feat, B * c.n_mels * T))) return rc;
     if ((rc = dev_alloc(h, &h->d_pstats, B * c.n_mels * 2))) return rc;
+    if (h->x3 && (rc = dev_alloc(h, &h->d_xscale, 2 * (4 + 256)))) return rc;       // (one set per lane slice)
     if (h->fb.sym_hi) {
         if ((rc = dev_alloc(h, &h->d_logmel, B * c.n_mels * T))) return rc;
         if ((rc = dev_alloc(h, &h->d_fpart, B * c.n_mels * ((T + 63) / 64)))) return rc;
@@ -1054,10 +1066,6 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     (void)d_s1;
     float* cs_base = ((bf || h->x3) && h->d_colsum) ? h->d_colsum + (b0 ? 2 * h->colsum_region : 0) : nullptr;
     int rc;
-    if (!h->xin_ready && (rc = run(h, "prologue", 0, [&]() {
-             return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st,
-                                    h->x3 ? h->d_status : nullptr, h->host_flag_dev, 65504.0f);
-         }))) return rc;
     // F32X3: se_apply also leaves each block output in the S32 split layout (CAT's twin), so tdnn1 of the next block and mfa read
     // their A operand without a conversion pass
     char* cat32 = h->cat_s32 ? static_cast<char*>(h->cat_s32) + r0 * C3 * 4 : nullptr;
@@ -1076,12 +1084,14 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
     const bool s32_only = cat32 && x3_route(h->tdnn1[1], cat32, C3, false) && x3_route(h->tdnn1[2], cat32, C3, false) &&
                           x3_route(h->mfa, cat32, C3, cs_base != nullptr) && !h->opt.x3_keep_f32;
     if (s32_only) h->cat_f32_stale = true;
-    bool b0_done = false, x0_s32 = false;
+    bool b0_done = false, x0_s32 = false, b0_cv = false;
+    GemmParams q0;
+    float* xscale = h->d_xscale ? h->d_xscale + (b0 ? 4 + 256 : 0) : nullptr;
     if (h->x3 && h->blocks0.Wcv && h->s32_buf) {
         // F32X3: blocks.0 on the persistent kernel's conv-gather form: the features go to the S32 layout with rows zero-padded to
         // cv_cin channels (one small pass), the im2col view is formed by the operand DMAs
         const ConvLayer& L = h->blocks0;
-        GemmParams q;
+        GemmParams& q = q0;
         q.A = h->s32_buf; q.lda = L.cv_cin; q.W = L.Wcv; q.Wrows = L.N; q.x3 = 2; q.Y = X0; q.ldy = C;
         q.bias = L.bias; q.scale = L.scale; q.shift = L.shift;
         q.M = M; q.N = L.N; q.K = L.taps * L.cv_cin; q.Kp = L.cv_Kp; q.T = T; q.taps = L.taps; q.dil = L.dil; q.cin = L.cv_cin; q.pad_mode = PAD_REFLECT;
@@ -1089,12 +1099,24 @@ int ecapa_forward_part(svhip_handle* h, const float* d_feat_all, int b0, int B) 
         // (with s32_only and tdnn1 of the first block on the X3 kernel, X0 itself is written in the split layout: no conversion pass,
         //  block 1's residual is read as hi + lo, svhip_get_stage rebuilds the fp32 view)
         q.y_s32 = (s32_only && x3_route(h->tdnn1[0], X0, C, false)) ? 1 : 0;
-        if (gemm_pw3cv_supported(q)) {
-            if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(X_in), c.n_mels, h->s32_buf, M, L.cv_cin, st, L.cv_cin, c.n_mels); }))) return rc;
-            if ((rc = run(h, "gemm_pw3cv", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3cv(q, st); }))) return rc;
-            b0_done = true;
-            x0_s32 = q.y_s32 != 0;
-        }
+        q.in_scale = xscale;
+        b0_cv = gemm_pw3cv_supported(q);
+    }
+    // the prologue's range guard (F32X3: half-precision planes carry |x| <= 65504): with the scaled first convolution only a non-finite
+    // input is reported — a finite one of any magnitude is brought into the planes' range by an exact power of two (round 6)
+    if (!h->xin_ready && (rc = run(h, "prologue", 0, [&]() {
+             return launch_prologue(d_feat, X_in, bf, B, c.n_mels, T, c.log_input, h->in_w, h->in_b, d_pstats, st,
+                                    h->x3 ? h->d_status : nullptr, h->host_flag_dev, (b0_cv && xscale) ? 3.0e38f : 65504.0f);
+         }))) return rc;
+    if (b0_cv) {
+        const ConvLayer& L = h->blocks0;
+        if (xscale && (rc = run(h, "in_scale", 0, [&]() {
+                 return launch_in_scale(static_cast<const float*>(X_in), (int64_t)M * c.n_mels, reinterpret_cast<uint32_t*>(xscale + 4), xscale, st, L.cv_wscale);
+             }))) return rc;
+        if ((rc = run(h, "split_s32", 0, [&]() { return launch_split_s32(static_cast<const float*>(X_in), c.n_mels, h->s32_buf, M, L.cv_cin, st, L.cv_cin, c.n_mels, xscale); }))) return rc;
+        if ((rc = run(h, "gemm_pw3cv", (double)M * L.flops_per_row, [&]() { return launch_gemm_pw3cv(q0, st); }))) return rc;
+        b0_done = true;
+        x0_s32 = q0.y_s32 != 0;
     }
     if (!b0_done && (rc = conv_gemm(h, "gemm_blocks0", h->blocks0, X_in, c.n_mels, X0, C, M, ACT_GELU))) return rc;
     h->x0_is_s32 = x0_s32;
@@ -2312,57 +2334,28 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
             // REFIT (round 6).  tau = mean + z sd with z the normal quantile fits isotropic embeddings; real cohorts are not isotropic
             // (speaker centroids cluster by gender / language: bimodal cohort scores), and a row whose threshold passes fewer than `top`
             // scores, or overflows a list, used to take the slab path — N x K scores through HBM.  Such rows now go through the SAME fused
-            // kernel again with a z of their own, derived from what the last pass counted (next_z below).  At most ASNORM_REFIT_PASSES
+            // kernel again with a z of their own, derived from what the last pass counted (refit_next_z, asnorm_fused.hip).  At most ASNORM_REFIT_PASSES
             // passes; what is still undecided after them takes the slab path as before.
             constexpr int ASNORM_REFIT_PASSES = 3;
             const float target = fminf(1.6f * (float)top, 0.7f * (float)(2 * ASNORM_CAND_PER_LANE));
-            const float lnT = logf(target);
-            // per row: the last two (z, ln count) measurements and the bracket (zlo passed too many, zhi too few; < -50: none yet)
-            struct RowFit { int32_t id; float z, zp, lcp, zlo, zhi; };
-            std::vector<RowFit> fit((size_t)nf);
-            std::vector<int32_t> ids((size_t)nf), info((size_t)nf);
-            SV_HIP(h, hipMemcpy(ids.data(), nflag + 1, (size_t)nf * 4, hipMemcpyDeviceToHost));
-            SV_HIP(h, hipMemcpy(info.data(), nflag + 1 + N, (size_t)nf * 4, hipMemcpyDeviceToHost));
-            for (int i = 0; i < nf; ++i) fit[i] = RowFit{ids[i], fp.z, -100.f, 0.f, -100.f, -100.f};
-            // The next z of a row from what its last pass counted.  ln(count) against z is locally close to linear; its slope is ~ -(z + 1 / z)
-            // for a Gaussian tail and several times steeper when the threshold sits on the flank of a narrow mode (clustered centroids), so
-            // the FIRST step assumes a slope of -5 (it lands near the target on clustered data and short of it on Gaussian tails) and every
-            // later step is the secant through the last two measurements, kept inside the bracket once both sides have been seen.
-            auto next_z = [&](RowFit& r, int32_t inf) {
-                const float c = (float)(inf & ((1 << 30) - 1));
-                const bool many = ((inf >> 30) & 1) || c > target;       // (a flagged row with enough candidates overflowed a list)
-                const float lc = logf(fmaxf(many ? fmaxf(c, 1.25f * target) : c, 0.5f));
-                if (many) r.zlo = r.zlo > -50.f ? fmaxf(r.zlo, r.z) : r.z; else r.zhi = r.zhi > -50.f ? fminf(r.zhi, r.z) : r.z;
-                float slope = -5.0f;
-                if (r.zp > -50.f && fabsf(r.z - r.zp) > 1e-3f) slope = fminf(-1.0f, fmaxf(-12.0f, (lc - r.lcp) / (r.z - r.zp)));
-                float z = r.z + fminf(0.6f, fmaxf(-0.6f, (lnT - lc) / slope));
-                if (many) z = fmaxf(z, r.z + 0.02f); else z = fminf(z, r.z - 0.02f);
-                if (r.zlo > -50.f && r.zhi > -50.f) {
-                    const float w = r.zhi - r.zlo;
-                    z = fminf(r.zhi - 0.1f * w, fmaxf(r.zlo + 0.1f * w, z));
-                }
-                r.zp = r.z; r.lcp = lc;
-                r.z = fminf(12.0f, fmaxf(-2.0f, z));
-            };
-            for (int i = 0; i < nf; ++i) next_z(fit[i], info[i]);
-            int cur = nf;
+            // everything lives on the device: the state of the undecided rows (asnorm_fused.hip, "refit state": ids, z, the last measurement, the
+            // bracket), the gathered rows, their statistics and the flag list of the pass; the host reads ONE word per pass (how many are left)
+            void* g;
+            const size_t cap = (size_t)nf;
+            const size_t gbytes = cap * D * 4 + cap * 4 * (2 + 6 + 6 + 2) + 256;
+            if ((rc = scratch(h, svhip_handle::SCR_GATHER, gbytes, &g))) return rc;
+            float* gE = (float*)g;
+            float* gM = gE + cap * D;
+            float* gS = gM + cap;
+            float* soa[2] = {gS + cap, gS + cap + 6 * cap};
+            int32_t* gF = (int32_t*)(soa[1] + 6 * cap);      // [0] = count, [1 ..] positions within the gathered list
+            int32_t* gInfo = gF + 1 + cap;                   // (gbytes: + 256 covers the counter word)
+            if ((rc = run(h, "asnorm_refit_state", 0, [&]() { return launch_asnorm_refit_init(nflag + 1, nflag + 1 + N, nf, fp.z, target, soa[0], h->stream); }))) return rc;
+            int cur = nf, a = 0;
             while (cur > 0 && refit_passes < ASNORM_REFIT_PASSES) {
                 ++refit_passes;
-                void* g;
-                // [gathered rows | mu | sigma | z | ids | flagged ids (1 + cur) | flagged info]
-                const size_t gbytes = (size_t)cur * D * 4 + (size_t)cur * 4 * 6 + 256;
-                if ((rc = scratch(h, svhip_handle::SCR_GATHER, gbytes, &g))) return rc;
-                float* gE = (float*)g;
-                float* gM = gE + (size_t)cur * D;
-                float* gS = gM + cur;
-                float* gZ = gS + cur;
-                int32_t* gI = (int32_t*)(gZ + cur);
-                int32_t* gF = gI + cur;                      // [0] = count, [1 ..] positions within the gathered list
-                int32_t* gInfo = gF + 1 + cur;
-                std::vector<float> zs((size_t)cur);
-                for (int i = 0; i < cur; ++i) { ids[i] = fit[i].id; zs[i] = fit[i].z; }
-                SV_HIP(h, hipMemcpyAsync(gI, ids.data(), (size_t)cur * 4, hipMemcpyHostToDevice, h->stream));
-                SV_HIP(h, hipMemcpyAsync(gZ, zs.data(), (size_t)cur * 4, hipMemcpyHostToDevice, h->stream));
+                const int32_t* gI = reinterpret_cast<const int32_t*>(soa[a]);
+                const float* gZ = soa[a] + cur;
                 SV_HIP(h, hipMemsetAsync(gF, 0, 4, h->stream));
                 if ((rc = run(h, "asnorm_gather", 0, [&]() { return launch_gather_rows((const float*)dE, gI, cur, D, gE, h->stream); }))) return rc;
                 for (int64_t r0 = 0; r0 < cur; r0 += chunk) {
@@ -2382,23 +2375,16 @@ int svhip_asnorm_stats(svhip_handle* h, const float* E, int64_t N, int32_t D, co
                 SV_HIP(h, hipMemcpyAsync(&left, gF, 4, hipMemcpyDeviceToHost, h->stream));
                 SV_HIP(h, hipStreamSynchronize(h->stream));
                 refit_rows += cur - left;
-                if (left > 0) {
-                    std::vector<int32_t> pos((size_t)left), inf2((size_t)left);
-                    SV_HIP(h, hipMemcpy(pos.data(), gF + 1, (size_t)left * 4, hipMemcpyDeviceToHost));
-                    SV_HIP(h, hipMemcpy(inf2.data(), gInfo, (size_t)left * 4, hipMemcpyDeviceToHost));
-                    std::vector<RowFit> nxt((size_t)left);
-                    for (int i = 0; i < left; ++i) { nxt[i] = fit[pos[i]]; next_z(nxt[i], inf2[i]); }
-                    // (the flag order is whatever the atomics gave; a row's result does not depend on where it sits in the gathered list)
-                    fit.swap(nxt);
-                }
+                // (the flag order is whatever the atomics gave; a row's result does not depend on where it sits in the gathered list)
+                if (left > 0 && (rc = run(h, "asnorm_refit_state", 0, [&]() {
+                                     return launch_asnorm_refit_next(soa[a], cur, gF + 1, gInfo, left, target, soa[a ^ 1], h->stream);
+                                 }))) return rc;
+                a ^= 1;
                 cur = left;
             }
             // what the refit passes could not decide: back into the flag list for the slab path
             nf = cur;
-            if (nf > 0) {
-                for (int i = 0; i < nf; ++i) ids[i] = fit[i].id;
-                SV_HIP(h, hipMemcpy(nflag + 1, ids.data(), (size_t)nf * 4, hipMemcpyHostToDevice));
-            }
+            if (nf > 0) SV_HIP(h, hipMemcpyAsync(nflag + 1, soa[a], (size_t)nf * 4, hipMemcpyDeviceToDevice, h->stream));
         }
         h->last_asnorm_refit = refit_rows;
         h->last_asnorm_refit_passes = refit_passes;

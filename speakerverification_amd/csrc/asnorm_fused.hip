@@ -352,17 +352,7 @@ __global__ __launch_bounds__(256, 2) void asnorm_fused6_kernel(AsnormFusedParams
 // to 11 bits and lo a normal half for every component down to 2^-10 of the largest; squares (the AS-norm moment rows) stay below 2^14.
 // Products and sums are formed on the scaled values — binary floating point is scale-invariant, so the fp32 accumulation rounds exactly
 // as it would have — and the result is multiplied back by the exact inverse.  Zero rows keep scale 1; inf / NaN stay inf / NaN.
-__device__ __forceinline__ float pow2_scale_of_bits(uint32_t bits) {      // s = 2^k with (max |x|) * s in [64, 128)
-    const int e = (int)((bits >> 23) & 255u);
-    if (e == 0) return 1.0f;                                              // zero (or subnormal) row: nothing to scale
-    const int se = min(253, max(1, 260 - e));                             // biased exponent of s = 127 + 6 - (e - 127)
-    return __uint_as_float((uint32_t)se << 23);
-}
-// |x| as ordered bits for the max-|x| searches; inf / NaN count as 0: a non-finite element must not set the scale of the
-// FINITE elements around it (exponent 255 would give 2^-122 and flush a whole matrix to zero) — it stays inf / NaN in its own row or column
-__device__ __forceinline__ uint32_t finite_abs_bits(uint32_t w) { const uint32_t a = w & 0x7fffffffu; return a < 0x7f800000u ? a : 0u; }
-__device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }      // s = 2^k, biased k in [1, 253]
-
+// (pow2_scale_of_bits, pow2_inverse, finite_abs_bits: common.h — round 6: the F32X3 network input uses them too)
 // max |x| over the FINITE elements of a matrix as the bit pattern of a non-negative float (ordered like an unsigned integer): ABSMAX_WGS
 // workgroups leave one partial each in part[0 .. ABSMAX_WGS) (no atomics, no zero-fill launch); the consumer's first kernel folds them
 // (absmax_fold: 256 loads per workgroup) and its workgroup 0 publishes the result in part[-1] = *pscale for the kernels after it
@@ -1078,6 +1068,59 @@ hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64
         hipLaunchKernelGGL(asnorm_cand_stats_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, cand, cnt, rows, top, mu, sigma, row_base,
                            flagged, nflag, rowscale, finfo);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- refit state of the embeddings the normal-quantile threshold did not fit (round 6) -------------------------------------------------
+// Structure of arrays, stride = the number of rows: [id (int bits) | z | z of the pass before | ln(count) of the pass before | zlo | zhi]
+// (zlo: the largest z that passed too many, zhi: the smallest that passed too few; <= -50: none yet).  A row's next z from what its last pass
+// counted: ln(count) against z is locally close to linear — slope ~ -(z + 1 / z) for a Gaussian tail, several times steeper when the
+// threshold sits on the flank of a narrow mode (clustered speaker centroids) — so the FIRST step assumes a slope of -5 and every later step
+// is the secant through the last two measurements, kept inside the bracket once both sides have been seen.
+__device__ __forceinline__ void refit_next_z(float& z, float& zp, float& lcp, float& zlo, float& zhi, int32_t inf, float target) {
+    const float lnT = __logf(target);
+    const float c = (float)(inf & ((1 << 30) - 1));
+    const bool many = ((inf >> 30) & 1) || c > target;       // (a flagged row with enough candidates overflowed a list)
+    const float lc = __logf(fmaxf(many ? fmaxf(c, 1.25f * target) : c, 0.5f));
+    if (many) zlo = zlo > -50.f ? fmaxf(zlo, z) : z; else zhi = zhi > -50.f ? fminf(zhi, z) : z;
+    float slope = -5.0f;
+    if (zp > -50.f && fabsf(z - zp) > 1e-3f) slope = fminf(-1.0f, fmaxf(-12.0f, (lc - lcp) / (z - zp)));
+    float zn = z + fminf(0.6f, fmaxf(-0.6f, (lnT - lc) / slope));
+    if (many) zn = fmaxf(zn, z + 0.02f); else zn = fminf(zn, z - 0.02f);
+    if (zlo > -50.f && zhi > -50.f) {
+        const float w = zhi - zlo;
+        zn = fminf(zhi - 0.1f * w, fmaxf(zlo + 0.1f * w, zn));
+    }
+    zp = z; lcp = lc;
+    z = fminf(12.0f, fmaxf(-2.0f, zn));
+}
+__global__ __launch_bounds__(256) void refit_init_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ info, int n, float z0, float target,
+                                                         float* __restrict__ soa) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float z = z0, zp = -100.f, lcp = 0.f, zlo = -100.f, zhi = -100.f;
+    refit_next_z(z, zp, lcp, zlo, zhi, info[i], target);
+    reinterpret_cast<int32_t*>(soa)[i] = ids[i];
+    soa[n + i] = z; soa[2 * (size_t)n + i] = zp; soa[3 * (size_t)n + i] = lcp; soa[4 * (size_t)n + i] = zlo; soa[5 * (size_t)n + i] = zhi;
+}
+__global__ __launch_bounds__(256) void refit_next_kernel(const float* __restrict__ in, int n_in, const int32_t* __restrict__ pos, const int32_t* __restrict__ info,
+                                                         int left, float target, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= left) return;
+    const int j = pos[i];
+    float z = in[n_in + j], zp = in[2 * (size_t)n_in + j], lcp = in[3 * (size_t)n_in + j], zlo = in[4 * (size_t)n_in + j], zhi = in[5 * (size_t)n_in + j];
+    refit_next_z(z, zp, lcp, zlo, zhi, info[i], target);
+    reinterpret_cast<int32_t*>(out)[i] = reinterpret_cast<const int32_t*>(in)[j];
+    out[left + i] = z; out[2 * (size_t)left + i] = zp; out[3 * (size_t)left + i] = lcp; out[4 * (size_t)left + i] = zlo; out[5 * (size_t)left + i] = zhi;
+}
+hipError_t launch_asnorm_refit_init(const int32_t* ids, const int32_t* info, int n, float z0, float target, float* soa, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(refit_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, info, n, z0, target, soa);
+    return hipGetLastError();
+}
+hipError_t launch_asnorm_refit_next(const float* in, int n_in, const int32_t* pos, const int32_t* info, int left, float target, float* out, hipStream_t stream) {
+    if (left <= 0) return hipSuccess;
+    hipLaunchKernelGGL(refit_next_kernel, dim3((left + 255) / 256), dim3(256), 0, stream, in, n_in, pos, info, left, target, out);
     return hipGetLastError();
 }
 

@@ -160,4 +160,18 @@ __device__ __forceinline__ void x3_split2(float a, float b, uint32_t& hd, uint32
     ld = __builtin_bit_cast(uint32_t, x3x2_t{x3_lo(a, ha), x3_lo(b, hb)});
 }
 
+// ---- exact power-of-two operand scaling of the half-plane forms (asnorm_fused.hip "operand scaling"; elementwise.hip / gemm_pw3.hip: the
+// network input of F32X3 handles, round 6) ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow2_scale_of_bits(uint32_t bits) {      // s = 2^k with (max |x|) * s in [64, 128)
+    const int e = (int)((bits >> 23) & 255u);
+    if (e == 0) return 1.0f;                                              // zero (or subnormal) row: nothing to scale
+    const int se = min(253, max(1, 260 - e));                             // biased exponent of s = 127 + 6 - (e - 127)
+    return __uint_as_float((uint32_t)se << 23);
+}
+// |x| as ordered bits for the max-|x| searches; inf / NaN count as 0: a non-finite element must not set the scale of the
+// FINITE elements around it (exponent 255 would give 2^-122 and flush a whole matrix to zero) — it stays inf / NaN in its own row or column
+__device__ __forceinline__ uint32_t finite_abs_bits(uint32_t w) { const uint32_t a = w & 0x7fffffffu; return a < 0x7f800000u ? a : 0u; }
+__device__ __forceinline__ float pow2_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }      // s = 2^k, biased k in [1, 253]
+
+
 }  // namespace svhip

@@ -706,7 +706,11 @@ __global__ __launch_bounds__(256) void split_words_kernel(const float* __restric
 
 // fp32 rows -> the S32 split layout of gemm_pw3's X3 form: per row, per block of 32 k: 32 hi bf16 | 32 lo bf16 (128 bytes).
 // One thread = 8 consecutive k: 32 bytes in, 16 + 16 bytes out.
-__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K, int ldd, int kvalid) {
+// `scale` (optional, device: [0] = s, an exact power of two): every value is multiplied by s before it is split (the network input of an
+// F32X3 handle: in_scale_kernel below)
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ src, int ld, char* __restrict__ dst, int64_t M, int K, int ldd, int kvalid,
+                                                        const float* __restrict__ scale) {
+    const float sc = scale ? scale[0] : 1.0f;
     const int per_row = K >> 3;
     const int64_t n = M * per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict_
         x3x8_t hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float v = e < 4 ? a[e] : b[e - 4];
+            const float v = (e < 4 ? a[e] : b[e - 4]) * sc;
             const x3_t h = x3_hi(v);
             hi[e] = h;
             lo[e] = x3_lo(v, h);
@@ -731,12 +735,53 @@ __global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict_
     }
 }
 
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd, int kvalid) {
+// max |x| over the finite elements of X (256 partial words), then the scale of an F32X3 network input:
+//   scale[0] = s, scale[1] = 1 / (s sw), scale[2] = s sw (sw: the weight planes' own scale, ConvLayer::cv_wscale), s = 1 while 2^-8 <= max |x| < 2^13 (the planes carry such values as they are: the arithmetic of rounds 4 - 5,
+//   bit for bit), else the power of two that brings max |x| into [64, 128) — features of ANY finite magnitude (log_input = 0: mel power of
+//   int16-scaled waveforms is ~1e9) reach the first convolution instead of overflowing its half-precision planes
+__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ X, int64_t n, uint32_t* __restrict__ part) {
+    __shared__ uint32_t wm[4];
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, finite_abs_bits(__float_as_uint(X[i])));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+__global__ __launch_bounds__(256) void in_scale_kernel(const uint32_t* __restrict__ part, float* __restrict__ scale, float wscale) {
+    __shared__ uint32_t wm[4];
+    uint32_t m = part[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bits = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        const int e = (int)(bits >> 23);                      // biased exponent of max |x|
+        const float s = (e == 0 || (e >= 127 - 8 && e < 127 + 13)) ? 1.0f : pow2_scale_of_bits(bits);
+        // [0]: what the split pass multiplies the input by; [1]: 1 / (s sw), what the GEMM's epilogue multiplies its accumulators by; [2]: s sw,
+        // what its accumulators' start value (the bias) is multiplied by.  (s and sw are powers of two: the products and the inverse are exact
+        // while they stay inside fp32's exponent range — 2^-122 <= s, sw <= 2^126 each — which the clamp below keeps)
+        const float ssw = fminf(fmaxf(s * wscale, 0x1p-120f), 0x1p120f);
+        scale[0] = s;
+        scale[1] = 1.0f / ssw;
+        scale[2] = ssw;
+    }
+}
+hipError_t launch_in_scale(const float* X, int64_t n, uint32_t* part256, float* scale, hipStream_t stream, float wscale) {
+    if (!X || !part256 || !scale || n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(absmax_part_kernel, dim3(256), dim3(256), 0, stream, X, n, part256);
+    hipLaunchKernelGGL(in_scale_kernel, dim3(1), dim3(256), 0, stream, part256, scale, wscale);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd, int kvalid, const float* scale) {
     if (ldd == 0) ldd = K;
     if (kvalid == 0) kvalid = K;
     if (!src || !dst || M <= 0 || K <= 0 || K % 32 != 0 || ld % 4 != 0 || ldd % 32 != 0 || ldd < K || kvalid % 8 != 0 || kvalid > K) return hipErrorInvalidValue;
     const int64_t g = (M * (K / 8) + 255) / 256;
-    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K, ldd, kvalid);
+    hipLaunchKernelGGL(split_s32_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, stream, src, ld, reinterpret_cast<char*>(dst), M, K, ldd, kvalid, scale);
     return hipGetLastError();
 }
 

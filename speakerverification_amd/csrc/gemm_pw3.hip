@@ -262,6 +262,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
     };
 
     const int nkt = p.Kp * ESZ / 128;             // 128-byte K tiles per row: >= 4 and even (host check)
+    // X3 conv-gather form (the first convolution of an F32X3 handle): A holds s * x, s an exact power of two chosen on the device from the
+    // input's max |x| (GemmParams::in_scale); the convolution is linear, so the accumulators start at s * bias and are multiplied back
+    float s_in = 1.0f, inv_in = 1.0f;
+    if (X3 && CV && p.in_scale) { s_in = p.in_scale[2]; inv_in = p.in_scale[1]; }
 
     unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;      // debug builds: cycles in {tile-start wait, K loop, next-tile issue, epilogue}
 #define PW3_STAMP(i) if (DBG3 && (p.debug & 16384) && p.ts) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; }
@@ -314,7 +318,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
         f32x4 acc16[8][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(cb + (wn * 64 + j * 16 + 4 * q4) * 4);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(cb + (wn * 64 + j * 16 + 4 * q4) * 4);
+            if (X3 && CV) b0 *= s_in;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc16[i][j] = b0;
         }
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pw3_kernel(GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc16[i][j][e];
+                        if (X3 && CV) t *= inv_in;
                         if (!(ABL & 4)) {
                             t = apply_act(t, EPI == EPI_GELU ? ACT_GELU : EPI == EPI_RELU ? ACT_RELU : ACT_NONE);     // nn.GELU() exact form
                             t = fmaf(t, sc[e], sh[e]);

@@ -88,6 +88,8 @@ struct GemmParams {
     int cv_off = 0;                 // developer option cv_off: 16-bit conv-gather GEMMs stay on the per-tile kernel
     int pw3_cus = -1;               // developer option pw3_cus (svhip_set_option / SVHIP_PW3_CUS at create): the persistent kernels launch at most this
                                     // many workgroups, so that a small test problem walks several tiles per workgroup; 0: persistent kernels off
+    const float* in_scale = nullptr; // gemm_pw3's X3 conv-gather form: (device) [0] = s, [1] = 1 / (s sw), [2] = s sw — A holds s * x, W holds sw * w (launch_in_scale):
+                                    // the accumulators start at s sw * bias and the epilogue multiplies by 1 / (s sw) before the activation
     int pw4 = 0;                    // option pw4: plain pointwise bf16 layers with more tiles than workgroups run on the four-wave kernel (gemm_pw4.hip)
     int tail_split = 1;             // persistent 16-bit GEMMs: a last partial round of <= G / 2 tiles is walked as column halves (gemm_pw3.hip)
     void* ts = nullptr;             // developer builds (SVHIP_GEMM_DEBUG, debug bit 16384): per-workgroup stage timestamps
@@ -161,7 +163,10 @@ hipError_t launch_gemm_pw3cv16(const GemmParams& p, hipStream_t stream);
 bool gemm_pw3r2_supported(const GemmParams& p);
 hipError_t launch_gemm_pw3r2(const GemmParams& p, hipStream_t stream);
 // fp32 (M, K) rows (stride ld) -> S32 layout, rows of ldd elements (4 bytes each; 0: dense, ldd = K)
-hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0, int kvalid = 0);
+hipError_t launch_split_s32(const float* src, int ld, void* dst, int64_t M, int K, hipStream_t stream, int ldd = 0, int kvalid = 0,
+                            const float* scale = nullptr);      // scale (device, optional): [0] = a power of two every value is multiplied by
+// the input scale of an F32X3 handle's first convolution: scale[0] = s, scale[1] = 1 / s from the max |x| of X (elementwise.hip)
+hipError_t launch_in_scale(const float* X, int64_t n, uint32_t* part256, float* scale, hipStream_t stream, float wscale = 1.0f);
 hipError_t launch_unsplit_s32(const void* src, int lds32, float* dst, int ld, int64_t M, int K, hipStream_t stream);   // v = hi + lo
 // row groups per 256-row tile in the column-sum partials the routed kernel writes (8: pw2, 2: pw3)
 int gemm_colsum_groups(const GemmParams& p, bool bf16);
@@ -442,6 +447,9 @@ hipError_t launch_asnorm_fused(const AsnormFusedParams& p, int D, hipStream_t st
 hipError_t launch_asnorm_cand_stats(const float* cand, const int32_t* cnt, int64_t rows, int top, float* mu, float* sigma, int64_t row_base,
                                     int32_t* flagged, int32_t* nflag, hipStream_t stream, int nlists = 2, const float* rowscale = nullptr, int32_t* finfo = nullptr);
 hipError_t launch_gather_rows(const float* E, const int32_t* ids, int n, int D, float* out, hipStream_t stream);
+// refit state of flagged embeddings (asnorm_fused.hip): structure of arrays [id | z | zp | lcp | zlo | zhi], stride = the row count
+hipError_t launch_asnorm_refit_init(const int32_t* ids, const int32_t* info, int n, float z0, float target, float* soa, hipStream_t stream);
+hipError_t launch_asnorm_refit_next(const float* in, int n_in, const int32_t* pos, const int32_t* info, int left, float target, float* out, hipStream_t stream);
 hipError_t launch_scatter_stats(const float* m, const float* s, const int32_t* ids, int n, float* mu, float* sigma, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -513,6 +513,38 @@ def test_f32x3_input_range_guard():
         e.close()
 
 
+@pytest.mark.parametrize("mag", [1.0e7, 3.0e-9, 1.0])
+def test_f32x3_first_convolution_takes_input_of_any_magnitude(mag):
+    """Round 6: at the real channel counts (C % 256 == 0) blocks.0 of an F32X3 handle runs on the persistent conv-gather
+    kernel, whose A operand is now s * x with s an exact power of two chosen ON THE DEVICE from the input's max |x| (s = 1 in the ordinary
+    range: the arithmetic of rounds 4 - 5 bit for bit); the accumulators start at s * bias and are multiplied back before the activation.
+    Non-log features a million times beyond the half-precision planes' 65504 (mel power of int16-scaled audio), or far below their
+    resolution, embed as on the exact-fp32 handle instead of ending in SVHIP_ERR_RANGE — given a first layer whose weights fit such
+    features (here: scaled by 1 / mag, as training on them would have)."""
+    C, T, B = 512, 50, 3
+    sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=3)
+    sd["blocks.0.conv.conv.weight"] = (sd["blocks.0.conv.conv.weight"].astype(np.float64) / mag).astype(np.float32)
+    mel = ((np.abs(synth.synth_mel(B, 80, T, seed=13)) + 0.01) * mag).astype(np.float32)
+    out = {}
+    for compute in ("f32x3", "f32"):
+        e = Engine(model="ecapa", compute=compute, channels=C, max_batch=B, samples=(T - 1) * 80, log_input=False)
+        e.load_state_dict(sd)
+        e.finalize()
+        e.profile(True)
+        out[compute] = e.embed_features(mel).copy()
+        labels = set(e.profile_results())
+        assert e.numeric_status() == 0
+        if compute == "f32x3":
+            assert {"gemm_pw3cv", "in_scale", "split_s32"} <= labels, labels
+            again = e.embed_features(mel)
+            assert np.array_equal(again, out[compute])
+        e.close()
+    a, b = out["f32x3"], out["f32"]
+    err = float(np.abs(a - b).max() / np.abs(b).max())
+    print(f"input magnitude {mag:g}: f32x3 against exact f32: {err:.2e} of the embedding scale")
+    assert np.isfinite(a).all() and err <= 1e-4
+
+
 # (cases in which every big GEMM is on the persistent kernel in BOTH runs: a 16-bit layer whose tile count lies in (CUs / 2, CUs] takes the
 #  per-tile kernel by default, whose column sums are cut into other row groups)
 @pytest.mark.parametrize("compute,C,L,B", [("bf16", 1024, 32000, 5), ("bf16", 512, 32000, 10), ("f32x3", 1024, 32000, 5),
