@@ -185,6 +185,7 @@ struct Res2Params {
     const float* scale[7] = {};
     const float* shift[7] = {};
     int debug = 0;               // tools/res2_bench ablations (only read in -DSVHIP_GEMM_DEBUG builds)
+    unsigned long long* ts = nullptr;   // the same builds, debug bit 64: per workgroup [8 stages][4] cycle totals {taps, epilogue, row pass, -}
     int slices = 1;              // > 1: every utterance is cut into this many time slices, one workgroup each (res2net_chain_slices)
     int Tc = 0;                  // filled by the launcher: core frames per slice
 };

@@ -134,6 +134,12 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
     }
     wstore();
     __syncthreads();
+    // debug builds, bit 64: wave 0 stamps the end of each phase of each stage (s_memtime; the phases end in barriers, so its clock is the workgroup's)
+    const bool stamp = R2DBG && (p.debug & 64) && p.ts && tid == 0;
+    unsigned long long tprev = 0;
+    if (R2DBG && (p.debug & 64) && p.ts) tprev = __builtin_readcyclecounter();
+    if (stamp) p.ts[(size_t)blockIdx.x * 32 + 3] = tprev;                  // [stage 0][3]: the start (after the init pass)
+#define R2_STAMP(stage, k) if (R2DBG && (p.debug & 64) && p.ts) { const unsigned long long t_ = __builtin_readcyclecounter(); if (stamp) p.ts[(size_t)blockIdx.x * 32 + (stage) * 4 + (k)] = t_ - tprev; tprev = t_; }
 
     for (int s = 1; s < 8; ++s) {
         const int layer = s - 1;
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
             if (tap < 2) { if (!(R2DBG && (p.debug & 4))) wstore(); __syncthreads(); }
         }
 
+        R2_STAMP(s, 0)
         // ---- epilogue: acc[i][4g+e] = (t = (wq + MW*i)*32 + fr, n = wn*32 + 8g + 4fh + e) -> U ------
         int fh_e = fh, fr_e = fr;
         asm volatile("" : "+v"(fh_e), "+v"(fr_e));
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
         }
         if (s < 7 && !(R2DBG && (p.debug & 4))) wstore();      // next layer's tap-0 slab (loaded during tap 2)
         __syncthreads();
+        R2_STAMP(s, 1)
 
         // ---- y_s -> H2 (whole rows), U <- y_s + c_{s+1} -------------------------------------------------
         // seven row chunks per thread at a time: their c_{s+1} loads are all in flight before the first is consumed (one
@@ -280,7 +288,9 @@ __global__ __launch_bounds__(512, 2) void res2net_chain_kernel(Res2Params p) {
             }
         }
         __syncthreads();
+        R2_STAMP(s, 2)
     }
+#undef R2_STAMP
 }
 
 template <int CW, int MIT>

@@ -34,6 +34,24 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
         printf("res2net chain C=%d dbg %3d  %8.3f ms  %7.1f TFLOP/s\n", C, dbg, ms, 2.0 * 7 * B * T * CW * 3.0 * CW / ms / 1e9);
+        if (dbg & 64) {          // stage stamps: cycles per phase of each of the seven stages, mean / max over the workgroups
+            unsigned long long* dts; CK(hipMalloc(&dts, (size_t)B * 32 * 8)); CK(hipMemset(dts, 0, (size_t)B * 32 * 8));
+            p.ts = dts;
+            CK(launch_res2net_chain(p, B, C, st)); CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h((size_t)B * 32);
+            CK(hipMemcpy(h.data(), dts, (size_t)B * 32 * 8, hipMemcpyDeviceToHost));
+            p.ts = nullptr; CK(hipFree(dts));
+            const char* nm[3] = {"3 taps (fragment reads + MFMAs + weight-slab barriers)", "epilogue (bias, ReLU, BN -> U) + barrier", "row pass (y -> HBM, U += c) + barrier"};
+            double tot = 0;
+            for (int s = 1; s < 8; ++s)
+                for (int k = 0; k < 3; ++k) {
+                    double sum = 0, mx = 0;
+                    for (int w = 0; w < B; ++w) { const double v = (double)h[(size_t)w * 32 + s * 4 + k]; sum += v; if (v > mx) mx = v; }
+                    printf("    stage %d  %-58s mean %8.0f cycles  max %8.0f\n", s, nm[k], sum / B, mx);
+                    tot += sum / B;
+                }
+            printf("    sum of the stage means %.0f cycles = %.1f us at the clock the launch held (%.3f ms per launch: %.2f GHz)\n", tot, ms * 1e3, ms, tot / (ms * 1e6));
+        }
     }
     return 0;
 }
