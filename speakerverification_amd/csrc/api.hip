@@ -79,6 +79,7 @@ struct svhip_handle {
         int asnorm_norefit = 0;   // AS-norm: embeddings the normal-quantile threshold does not fit go straight to the slab path (round 5's behaviour)
         int asnorm_2s = 0;        // AS-norm split forms: candidate statistics of chunk c on a second stream under the matrix kernel of chunk c + 1
         int asnorm_x6 = 0;        // AS-norm fused kernel on six bf16 MFMAs (three planes, round 3) instead of three fp16 MFMAs (two planes)
+        int rn_sinc_full = 0;     // RawNet2 fp16 handles: the 251-tap sinc kernel (round 5) instead of the symmetric 126-tap form
         int fbank32 = 0;          // the 32-frame front-end kernel
         int ff_abl = 0;           // tools only: fused front-end phase ablations (FbankTables::ff_abl)
         int fbank_unfused = 0;    // bf16 handles: fbank -> prologue_stats -> prologue_apply (round 5) instead of the fused front-end
@@ -131,6 +132,7 @@ struct svhip_handle {
     RnBlock rn_blocks[8];
     float *rn_gamma = nullptr, *rn_beta = nullptr, *rn_fbn_scale = nullptr, *rn_fbn_shift = nullptr;
     void* rn_filt = nullptr;
+    void* rn_filt_sym = nullptr;              // fp16 handles: [128][128] slot-major table of the symmetric sinc form (round 6)
     void* rn_filt_x3 = nullptr;               // F32X3 handles: [2][128][256] half hi | lo parts of the sinc filters
     float *rn_agg_scale = nullptr, *rn_agg_shift = nullptr;
     ConvLayer rn_att0, rn_att3;
@@ -786,6 +788,23 @@ int bake_sinc(svhip_handle* h) {
         uint16_t* d;
         if ((rc = dev_upload(h, &d, pk))) return rc;
         h->rn_filt = d;
+        if (h->f16) {
+            // the symmetric form (rawnet2.hip, SYM): slot k' = 2 + m carries h[125 + m] (the centre tap halved: its operand is x[c] + x[c]),
+            // slots 0 and 1 are zero; right and left halves of a filter are the same numbers by construction (checked here)
+            bool symmetric = true;
+            for (int f = 0; f < NF && symmetric; ++f)
+                for (int i = 0; i < HALF; ++i) symmetric = symmetric && filt[(size_t)f * KS + i] == filt[(size_t)f * KS + (KS - 1 - i)];
+            if (symmetric) {
+                std::vector<uint16_t> ps((size_t)NF * 128, 0);
+                for (int f = 0; f < NF; ++f) {
+                    ps[(size_t)f * 128 + 2] = to_h16(h, 0.5f * filt[(size_t)f * KS + HALF]);
+                    for (int m = 1; m <= HALF; ++m) ps[(size_t)f * 128 + 2 + m] = to_h16(h, filt[(size_t)f * KS + HALF + m]);
+                }
+                uint16_t* ds;
+                if ((rc = dev_upload(h, &ds, ps))) return rc;
+                h->rn_filt_sym = ds;
+            }
+        }
     } else {
         std::vector<float> pk((size_t)NF * 252, 0.0f);
         for (int f = 0; f < NF; ++f)
@@ -1373,8 +1392,10 @@ int rawnet2_forward_part(svhip_handle* h, const float* d_wav_all, int b0, int B)
              //  separate coalesced rn_bn_act pass: measured 0.85 + 0.29 ms either way)
              if (sinc_x3) return launch_rn_sinc_x3(h->rn_filt_x3, h->rn_fbn_scale, h->rn_fbn_shift, reinterpret_cast<float*>(x), B, L, T, rn_xn, h->rn_Lp, h->num_cu, st,
                                                    sinc_pre ? pre : nullptr, h->rn_blocks[0].bn1_scale, h->rn_blocks[0].bn1_shift);
-             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, dt, B, L, T, st,
-                                   nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu);
+             // fp16 handles: the symmetric form of the sinc convolution (K = 126 instead of 251; option rn_sinc_full keeps round 5's kernel)
+             const bool sym = h->f16 && h->rn_filt_sym && !h->opt.rn_sinc_full;
+             return launch_rn_sinc(d_wav, rn_stats, h->rn_gamma, h->rn_beta, sym ? h->rn_filt_sym : h->rn_filt, h->rn_fbn_scale, h->rn_fbn_shift, x, dt, B, L, T, st,
+                                   nullptr, nullptr, nullptr, rn_xn, h->rn_Lp, h->num_cu, sym);
          }))) return rc;
     h->rn_dbg_x = x; h->rn_dbg_T = T; h->rn_dbg_C = 128;
     if (stop_after == 0) return SVHIP_OK;
@@ -1695,7 +1716,7 @@ int svhip_create(const svhip_config* cfg, svhip_handle** out) {
         o.layer_labels = flag("SVHIP_LAYER_LABELS"); o.x3_keep_f32 = flag("SVHIP_X3_KEEP_F32"); o.r2_big = is1("SVHIP_R2_BIG");
         o.asp_v1 = is1("SVHIP_ASP_V1"); o.rn_stop = num("SVHIP_RN_STOP", -1); o.rn_snap = num("SVHIP_RN_SNAP", -1);
         o.rn_unfused = flag("SVHIP_RN_UNFUSED"); o.asnorm_slab = flag("SVHIP_ASNORM_SLAB"); o.asnorm_f32mfma = flag("SVHIP_ASNORM_F32MFMA"); o.asnorm_x6 = flag("SVHIP_ASNORM_X6"); o.asnorm_w32 = flag("SVHIP_ASNORM_W32"); o.score_tiled = flag("SVHIP_SCORE_TILED"); o.score_f32mfma = flag("SVHIP_SCORE_F32MFMA");
-        o.fbank32 = is1("SVHIP_FBANK32"); o.fbank_unfused = is1("SVHIP_FBANK_UNFUSED"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.pw4 = is1("SVHIP_PW4"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
+        o.fbank32 = is1("SVHIP_FBANK32"); o.rn_sinc_full = is1("SVHIP_RN_SINC_FULL"); o.fbank_unfused = is1("SVHIP_FBANK_UNFUSED"); o.pw3_cus = num("SVHIP_PW3_CUS", -1); o.pw3_tail_off = is1("SVHIP_PW3_TAIL_OFF"); o.pw4 = is1("SVHIP_PW4"); o.asnorm_2s = is1("SVHIP_ASNORM_2S"); o.cv_off = is1("SVHIP_CV_OFF"); o.n128_off = is1("SVHIP_N128_OFF"); o.r2_slices = num("SVHIP_R2_SLICES", -1); o.rn_tail_big = is1("SVHIP_RN_TAIL_BIG"); o.rn_sinc_f32 = is1("SVHIP_RN_SINC_F32"); o.rn_step_off = is1("SVHIP_RN_STEP_OFF"); o.rn_pool_off = is1("SVHIP_RN_POOL_OFF");
     }
     h->esz = h->bf16 ? 2 : 4;
     h->T = cfg->samples / cfg->hop_length + 1;
@@ -2589,7 +2610,7 @@ int svhip_set_option(svhip_handle* h, const char* name, int32_t value) {
     struct { const char* key; int* slot; } table[] = {
         {"layer_labels", &o.layer_labels}, {"x3_keep_f32", &o.x3_keep_f32}, {"r2_big", &o.r2_big}, {"asp_v1", &o.asp_v1},
         {"rn_stop", &o.rn_stop}, {"rn_snap", &o.rn_snap}, {"rn_unfused", &o.rn_unfused}, {"asnorm_slab", &o.asnorm_slab},
-        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_norefit", &o.asnorm_norefit}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"fbank_unfused", &o.fbank_unfused}, {"ff_abl", &o.ff_abl}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
+        {"asnorm_f32mfma", &o.asnorm_f32mfma}, {"asnorm_x6", &o.asnorm_x6}, {"asnorm_2s", &o.asnorm_2s}, {"asnorm_norefit", &o.asnorm_norefit}, {"asnorm_w32", &o.asnorm_w32}, {"score_tiled", &o.score_tiled}, {"score_f32mfma", &o.score_f32mfma}, {"fbank32", &o.fbank32}, {"rn_sinc_full", &o.rn_sinc_full}, {"fbank_unfused", &o.fbank_unfused}, {"ff_abl", &o.ff_abl}, {"pw3_cus", &o.pw3_cus}, {"pw3_tail_off", &o.pw3_tail_off}, {"pw4", &o.pw4}, {"cv_off", &o.cv_off},
         {"r2_slices", &o.r2_slices}, {"rn_tail_big", &o.rn_tail_big}, {"rn_sinc_f32", &o.rn_sinc_f32}, {"rn_step_off", &o.rn_step_off}, {"rn_pool_off", &o.rn_pool_off}, {"n128_off", &o.n128_off}};
     for (auto& t : table)
         if (n == t.key) {

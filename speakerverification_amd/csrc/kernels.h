@@ -331,7 +331,8 @@ hipError_t launch_rn_sinc_x3(const void* filt_planes, const float* bn_scale, con
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,
                           hipStream_t stream, void* pre = nullptr, const float* next_scale = nullptr, const float* next_shift = nullptr,
-                          const void* xn = nullptr, int Lp = 0, int num_cu = 256);
+                          const void* xn = nullptr, int Lp = 0, int num_cu = 256, bool sym = false);
+// (sym, DT_F16 only: `filt` is the [128][128] slot-major table of the symmetric form — rawnet2.hip, rn_sinc_kernel<.., SYM>)
 // (dt: DT_F32 / DT_BF16 / DT_F16 — the storage type of the activations)
 // (y_s32 / pre_s32, fp32 only: that output in the S32 split layout — the operand of the split convolution kernels — instead of fp32)
 hipError_t launch_rn_bn_act(const void* x, void* y, int dt, const float* scale, const float* shift, int64_t rows, int C,

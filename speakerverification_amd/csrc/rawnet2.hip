@@ -235,7 +235,14 @@ template <> struct SincCfg<float> {
 };
 
 // filters: bf16: [128][256] bf16 (k contiguous); fp32: [128][252] fp32.
-template <typename T>
+// SYM (round 6, fp16 handles): the sinc band-pass filters are symmetric about their centre tap (RawNet_baseline.py:339-357 builds the right
+// half as the flip of the left), so  y[s] = sum_{m = 0..125} h[125 + m] (x[c + m] + x[c - m]),  c = s + 125  (the centre weight halved):
+// K = 126 instead of 251 — HALF the MFMAs and half the filter registers.  The operand fragment of (position s, slots k' .. k' + 7) is formed
+// in registers from TWO fragment reads of the same sample-shifted copies: the forward window x[c - 2 + k' ..] and the backward window
+// x[c + 2 - k' - 7 ..], added with the second one's eight halves reversed (v_pk_add_f16 with swapped half selects: no extra instruction).
+// Slot k' stands for m = k' - 2; slots 0 and 1 carry zero weights, so that every read stays inside the tile's 464 samples.
+// filters: [128][128] fp16, slot-major.
+template <typename T, bool SYM = false>
 __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict__ wav, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const void* __restrict__ filt, const float* __restrict__ bn_scale,
@@ -266,14 +273,19 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
     // this wave's filter fragments stay in registers for the whole kernel (weights are the MFMA A operand).  16-bit path (round 4):
     // v_mfma_f32_16x16x32 — four blocks of 16 filters x eight k steps of 32 (the chip holds a higher clock under this instruction than under
     // 32x32x16: tools/mfma_rate.hip); a lane owns filters 4 q4 .. + 3 of a block for pooled frame r16 of a 16-frame group
-    bf16x8 wfb[BF ? 4 : 1][BF ? 8 : 1];
+    static_assert(!SYM || std::is_same<T, f16_t>::value, "the symmetric form adds operand halves with v_pk_add_f16");
+    constexpr int NKS = SYM ? 4 : 8;                   // k steps of 32 slots
+    // SYM: a wave owns ALL 128 filters (eight blocks of 16) for 16 pooled frames — its operand costs two fragment reads per k step, so it
+    // must feed eight MFMAs, not four (with four the kernel sat on the LDS read port: 386 us against 462 for the 251-tap form)
+    constexpr int NFB = SYM ? 8 : 4;
+    bf16x8 wfb[BF ? NFB : 1][BF ? NKS : 1];
     float wff[BF ? 1 : 126];
     if (BF) {
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-            const char* w = reinterpret_cast<const char*>(filt) + (int64_t)(nf * 64 + fb * 16 + r16) * 256 * 2 + q4 * 16;
+        for (int fb = 0; fb < NFB; ++fb) {
+            const char* w = reinterpret_cast<const char*>(filt) + (int64_t)((SYM ? 0 : nf * 64) + fb * 16 + r16) * (NKS * 32) * 2 + q4 * 16;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) wfb[fb][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 64);
+            for (int kk = 0; kk < NKS; ++kk) wfb[fb][kk] = *reinterpret_cast<const bf16x8*>(w + kk * 64);
         }
     } else {
         const float* w = reinterpret_cast<const float*>(filt) + (int64_t)(wave * 32 + fr) * 252 + fh;
@@ -371,11 +383,16 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         // 16-bit path: the wave's 32 pooled frames are two groups of 16, multiplied and finished ONE AFTER THE OTHER (12 accumulators of
         // 16 x 16 live at a time: with all 24 the kernel needs 270 registers and spills its filter fragments into the tile loop)
         const char* base[3] = {nullptr, nullptr, nullptr};
+        const char* bback[3] = {nullptr, nullptr, nullptr};       // SYM: the backward windows (descending with the k step)
         if (BF) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int s = 3 * (32 * gw + r16) + j;                           // conv position inside the tile (frame group 0; group 1: + 48)
-                base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + q4) * 16;
+                const int s = 3 * ((SYM ? 16 * wave : 32 * gw) + r16) + j;       // conv position inside the tile (frame group 0; group 1: + 48)
+                if (SYM) {
+                    // (slot k': forward sample s + 123 + k', backward sample s + 127 - k': formed per pool partner in the tile body below)
+                } else {
+                    base[j] = xbuf + (s & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (s & 7))) & 15) + (s >> 3) + q4) * 16;
+                }
             }
         } else {
 #pragma unroll
@@ -397,6 +414,77 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
         // |.| -> max over the 3 pool partners -> BN -> LeakyReLU(0.3); lane = pooled frame, 4 consecutive filters per accumulator
         int fr_e = BF ? r16 : fr, fh_e = BF ? q4 : fh;
         asm volatile("" : "+v"(fr_e), "+v"(fh_e));
+        if (SYM) {
+            // pool partner j outermost: eight accumulators (one per filter block) live at a time, folded into a running max of |.|.  The twelve
+            // (partner, k step) fragment pairs form ONE read-ahead chain: the next partner's first pair is requested under this partner's last
+            // MFMAs (its two window bases are formed there, from the lane coordinates: kept across the tile they cost the registers the filter
+            // fragments need)
+            f32x4 mx[8];
+            auto bases = [&](int j, const char*& fb_, const char*& bb_) {
+                int r16_j = r16, q4_j = q4;
+                asm volatile("" : "+v"(r16_j), "+v"(q4_j));
+                const int sj = 3 * (16 * wave + r16_j) + j, sf = sj + 123, sb = sj + 120;
+                fb_ = xbuf + (sf & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (sf & 7))) & 15) + (sf >> 3) + q4_j) * 16;
+                bb_ = xbuf + (sb & 7) * CF::COPY_BYTES + (((CF::COPY_SKEW >> (4 * (sb & 7))) & 15) + (sb >> 3) - q4_j) * 16;
+            };
+            const char *fbase, *bbase;
+            bases(0, fbase, bbase);
+            bf16x8 fwd[2], bwd[2];
+            fwd[0] = *reinterpret_cast<const bf16x8*>(fbase);
+            bwd[0] = *reinterpret_cast<const bf16x8*>(bbase);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 a8[8];
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb) a8[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cur = (4 * j + kk) & 1;
+                    if (kk + 1 < 4) {
+                        fwd[cur ^ 1] = *reinterpret_cast<const bf16x8*>(fbase + (kk + 1) * 64);
+                        bwd[cur ^ 1] = *reinterpret_cast<const bf16x8*>(bbase - (kk + 1) * 64);
+                    } else if (j + 1 < 3) {
+                        bases(j + 1, fbase, bbase);
+                        fwd[cur ^ 1] = *reinterpret_cast<const bf16x8*>(fbase);
+                        bwd[cur ^ 1] = *reinterpret_cast<const bf16x8*>(bbase);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f16x8 fw = __builtin_bit_cast(f16x8, fwd[cur]), bk = __builtin_bit_cast(f16x8, bwd[cur]);
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, fw + __builtin_shufflevector(bk, bk, 7, 6, 5, 4, 3, 2, 1, 0));      // e[u] = forward[u] + backward[7 - u]
+#pragma unroll
+                    for (int fb = 0; fb < 8; ++fb) a8[fb] = Half16<H>::mfma16(wfb[fb][kk], xf, a8[fb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int fb = 0; fb < 8; ++fb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx[fb][e] = j == 0 ? fabsf(a8[fb][e]) : fmaxf(mx[fb][e], fabsf(a8[fb][e]));
+            }
+            const int row = 16 * wave + fr_e;
+            const int tp = tp0 + row;
+#pragma unroll
+            for (int fb = 0; fb < 8; ++fb) {
+                const int f = fb * 16 + 4 * fh_e;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(bnl + f);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(bnl + 128 + f);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float y = fmaf(mx[fb][e], sc[e], sh[e]); v[e] = y > 0.0f ? y : 0.3f * y; }
+                if (tp < T1) {
+                    typedef H h16x4 __attribute__((ext_vector_type(4)));
+                    const h16x4 pk = {static_cast<H>(v[0]), static_cast<H>(v[1]), static_cast<H>(v[2]), static_cast<H>(v[3])};
+                    const int c8 = f >> 2;
+                    *reinterpret_cast<h16x4*>(otile + row * 256 + ((c8 ^ (row & 31)) << 3)) = pk;
+                    if (pre) {
+                        const f32x4 nsc = *reinterpret_cast<const f32x4*>(nscale + f), nsh = *reinterpret_cast<const f32x4*>(nshift + f);
+                        h16x4 pp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float t = fmaf(static_cast<float>(pk[e]), nsc[e], nsh[e]); pp[e] = static_cast<H>(t > 0.0f ? t : 0.3f * t); }
+                        *reinterpret_cast<h16x4*>(pre + ((int64_t)b * T1 + tp) * 128 + f) = pp;
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             // 16-bit path: g = 16-frame group of this wave's 32 pooled frames, q = filter block; fp32 path: g = position group, q = 8-filter group
@@ -410,15 +498,25 @@ __global__ __launch_bounds__(256, 2) void rn_sinc_kernel(const float* __restrict
                 // 24 fragment reads are issued two ahead of their MFMAs through a ring of three, fenced (the compiler otherwise hoists them
                 // in bulk); frame group 1 starts 48 conv positions = 6 chunks of the SAME copy further on (+ 96 bytes)
                 auto xread = [&](int idx) { return *reinterpret_cast<const bf16x8*>(base[idx % 3] + g * 96 + (idx / 3) * 64); };
-                bf16x8 ring[3];
+                auto bread = [&](int idx) { return *reinterpret_cast<const bf16x8*>(bback[idx % 3] + g * 96 - (idx / 3) * 64); };
+                bf16x8 ring[3], rback[SYM ? 3 : 1];
                 ring[0] = xread(0);
                 ring[1] = xread(1);
+                if (SYM) { rback[0] = bread(0); rback[1] = bread(1); }
 #pragma unroll
-                for (int idx = 0; idx < 24; ++idx) {
-                    if (idx + 2 < 24) ring[(idx + 2) % 3] = xread(idx + 2);
+                for (int idx = 0; idx < 3 * NKS; ++idx) {
+                    if (idx + 2 < 3 * NKS) {
+                        ring[(idx + 2) % 3] = xread(idx + 2);
+                        if (SYM) rback[(idx + 2) % 3] = bread(idx + 2);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
+                    bf16x8 xf = ring[idx % 3];
+                    if (SYM) {          // e[u] = forward[u] + backward[7 - u]
+                        const f16x8 fw = __builtin_bit_cast(f16x8, ring[idx % 3]), bk = __builtin_bit_cast(f16x8, rback[idx % 3]);
+                        xf = __builtin_bit_cast(bf16x8, fw + __builtin_shufflevector(bk, bk, 7, 6, 5, 4, 3, 2, 1, 0));
+                    }
 #pragma unroll
-                    for (int fb = 0; fb < 4; ++fb) acc16[fb][idx % 3] = Half16<H>::mfma16(wfb[fb][idx / 3], ring[idx % 3], acc16[fb][idx % 3]);
+                    for (int fb = 0; fb < 4; ++fb) acc16[fb][idx % 3] = Half16<H>::mfma16(wfb[fb][idx / 3], xf, acc16[fb][idx % 3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1011,8 +1109,9 @@ hipError_t launch_rn_ln_stats(const float* wav, int B, int L, float* stats, hipS
 
 hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gamma, const float* beta, const void* filt,
                           const float* bn_scale, const float* bn_shift, void* out, int dt, int B, int L, int T1,
-                          hipStream_t stream, void* pre, const float* next_scale, const float* next_shift, const void* xn, int Lp, int num_cu) {
+                          hipStream_t stream, void* pre, const float* next_scale, const float* next_shift, const void* xn, int Lp, int num_cu, bool sym) {
     const bool bf16 = dt != DT_F32;
+    if (sym && dt != DT_F16) return hipErrorInvalidValue;             // (`filt` is then the [128][128] slot-major table of the symmetric form)
     if (B <= 0) return hipErrorInvalidValue;
     if (T1 != (L - 250) / 3 || L < 251 + 3 || (pre && (!next_scale || !next_shift))) return hipErrorInvalidValue;
     if (bf16 && (!xn || Lp < L + RN_XN_TAIL || Lp % 64 != 0)) return hipErrorInvalidValue;          // the bf16 kernel stages from the normalised copy
@@ -1020,7 +1119,11 @@ hipError_t launch_rn_sinc(const float* wav, const float* stats, const float* gam
     if (items >= (1ll << 31)) return hipErrorInvalidValue;
     const int slots = 2 * (num_cu > 0 ? num_cu : 256);               // two workgroups per CU (256 VGPRs per lane, 47 KiB of LDS each)
     dim3 grid((unsigned)(items < slots ? items : slots)), block(256);
-    if (dt == DT_F16)
+    if (dt == DT_F16 && sym)
+        hipLaunchKernelGGL((rn_sinc_kernel<f16_t, true>), grid, block, SincCfg<f16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
+                           bn_shift, reinterpret_cast<f16_t*>(out), reinterpret_cast<f16_t*>(pre), next_scale, next_shift, L, T1, B,
+                           reinterpret_cast<const uint16_t*>(xn), Lp);
+    else if (dt == DT_F16)
         hipLaunchKernelGGL(rn_sinc_kernel<f16_t>, grid, block, SincCfg<f16_t>::LDS, stream, wav, stats, gamma, beta, filt, bn_scale,
                            bn_shift, reinterpret_cast<f16_t*>(out), reinterpret_cast<f16_t*>(pre), next_scale, next_shift, L, T1, B,
                            reinterpret_cast<const uint16_t*>(xn), Lp);

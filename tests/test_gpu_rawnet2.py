@@ -558,3 +558,42 @@ def test_an_utterance_embeds_alike_on_both_sides_of_the_batch_size_switches(comp
     d = float(np.abs(e64 - e65[:64]).max()) / scale
     print(f"rawnet2 {compute}: B = 64 against B = 65, max difference {d:.2e} of the embedding scale")
     assert d <= bar
+
+
+def test_symmetric_sinc_form_matches_the_251_tap_kernel():
+    """Round 6: fp16 handles run the sinc front-end on the filters' symmetry — y[s] = sum_m h[125 + m] (x[c + m] + x[c - m]), K = 126 instead
+    of 251, the operand formed in registers from a forward and a (half-reversed) backward fragment read, one extra fp16 rounding per sum —
+    (rn_sinc_kernel<f16, SYM>; option rn_sinc_full keeps the 251-tap kernel).  Front-end output (stage rn_x) and embeddings of the two forms
+    on the same handle; both against the exact-fp32 handle at the fp16 bars; the symmetric table exists only if every baked filter IS
+    symmetric bit for bit (api.hip, bake_sinc)."""
+    B, L = 5, 32000
+    sd = synth.synth_state_dict(synth.rawnet2_param_spec(nOut=320), seed=3)
+    wav = synth.synth_waveforms(B, L, seed=9)
+    eng = Engine(model="rawnet2", compute="f16", embed_dim=320, max_batch=B, samples=L)
+    eng.load_state_dict(sd)
+    eng.finalize()
+    out, x0 = {}, {}
+    for mode in (0, 1):
+        eng.set_option("rn_sinc_full", mode)
+        eng.set_option("rn_stop", 0)                                   # stop behind the front-end: stage rn_x = its output
+        eng.embed_wave(wav)
+        x0[mode] = eng.get_stage("rn_x").copy()
+        eng.set_option("rn_stop", -1)
+        out[mode] = eng.embed_wave(wav).copy()
+    eng.set_option("rn_sinc_full", 0)
+    assert np.array_equal(eng.embed_wave(wav), out[0])                 # run to run: bitwise
+    eng.close()
+    d = np.abs(x0[0] - x0[1])
+    print(f"front-end, symmetric vs 251-tap: max |d| {d.max():.3e} of values up to {np.abs(x0[1]).max():.2f}; {float((d > 0).mean()):.3f} of the elements differ")
+    assert float(d.max()) <= 2e-2 * float(np.abs(x0[1]).max())
+    ref = Engine(model="rawnet2", compute="f32", embed_dim=320, max_batch=B, samples=L)
+    ref.load_state_dict(sd)
+    ref.finalize()
+    r = ref.embed_wave(wav)
+    ref.close()
+    for mode in (0, 1):
+        a = out[mode]
+        cos = np.sum(a * r, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(r, axis=1))
+        err = float(np.abs(a - r).max() / np.abs(r).max())
+        print(f"{'251-tap' if mode else 'symmetric'} front-end: embeddings vs exact f32: cos >= {cos.min():.6f}, {err:.2e} of the scale")
+        assert cos.min() >= 0.999 and err <= 3e-2
