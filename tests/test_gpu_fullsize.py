@@ -288,3 +288,40 @@ def test_f32x3_full_batch_of_short_utterances():
     scale = float(np.abs(a).max())
     assert float(np.abs(small - a[:4]).max()) <= 1e-4 * scale
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "speakers"])
+def test_asnorm_statistics_at_the_full_trial_list_size(kind):
+    """BASELINE configs[3] at its full size inside the test suite (the 1.2 M case ran only in bench.py): cohort statistics of
+    1.2 M x 192 embeddings against 5 994 cohort rows, top 200, ten chunks of the fused kernel — 96 sampled rows (the first and last of
+    every chunk among them) against the float64 statement; no row may need the slab path; a second call returns the same bits.  `speakers`:
+    embeddings around the cohort's own centroids (same-speaker cosine 0.5 - 0.8), as trained embeddings are."""
+    import torch
+    from speakerverification_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    N, K, top, D = 1_200_000, 5994, 200, 192
+    g = torch.Generator(device=dev).manual_seed(11)
+    def unit(*shape):
+        x = torch.randn(shape, generator=g, device=dev, dtype=torch.float32)
+        return x / x.norm(dim=-1, keepdim=True)
+    cohort = unit(K, D)
+    if kind == "gaussian":
+        E = unit(N, D)
+    else:
+        spk = torch.randint(0, K, (N,), generator=g, device=dev)
+        a = (0.5 + 0.3 * torch.rand((N, 1), generator=g, device=dev)).sqrt()
+        E = a * cohort[spk] + (1.0 - a * a).sqrt() * unit(N, D)
+        E = E / E.norm(dim=1, keepdim=True)
+    eng = Engine(model="none", max_batch=1)
+    mu, sd = eng.asnorm_stats(E, cohort, top)
+    assert eng.asnorm_last_fallback == 0 and eng.asnorm_last_refit == (0, 0)
+    edges = [c * 131072 + o for c in range(10) for o in (0, 131071) if c * 131072 + o < N]
+    rows = torch.tensor(sorted(set(edges + list(range(7, N, N // 70)) + [N - 1])), device=dev)
+    S = (E[rows].double() @ cohort.double().T).sort(dim=1, descending=True).values[:, :top]
+    emu = float((mu[rows].double() - S.mean(1)).abs().max())
+    esd = float(((sd[rows].double() - S.std(1, unbiased=False)).abs() / S.std(1, unbiased=False)).max())
+    print(f"{kind}: {rows.numel()} sampled rows of {N}: mu within {emu:.2e}, sigma within {esd:.2e} relative")
+    assert emu <= 2e-7 and esd <= 1e-5
+    mu2, sd2 = eng.asnorm_stats(E, cohort, top)
+    assert torch.equal(mu2, mu) and torch.equal(sd2, sd)
+    eng.close()
