@@ -8,8 +8,8 @@
 // 3-stage ring) the layer ran at 440 TFLOP/s at B = 256 (0.18 ms, 401 tiles = 1.57 rounds of 256 CUs) and — what hurt more — took 141 us
 // at the reference API's own batch size (B = 20: 32 workgroups, each walking 48 K steps alone on its CU: a fifth of a 0.71 ms call).
 // Here a tile is 128 frames x 128 channels on four waves (64 x 64 per wave, v_mfma_f32_16x16x32_bf16, weights as the A operand so a lane
-// owns 4 consecutive channels of a frame) with 64 KiB of LDS (two K tiles of X and W, 16 KiB each), so TWO workgroups share a CU: one's
-// wait for its next K tile (the loop is plain double buffering: wait, barrier, issue the next tile, multiply) runs under the other's
+// owns 4 consecutive channels of a frame) with 80 KiB of LDS (round 6: three K tiles of X, two of W, 16 KiB each), so TWO workgroups share a CU: one's
+// wait for its next K tile (wait, barrier, issue the tiles after next, multiply) runs under the other's
 // MFMAs, twice as many workgroups exist for a small batch, and the tail round of a big one is half as long.  Structure borrowed from
 // r2_step.hip (the F32X3 Res2Net step), which showed that this shape feeds the matrix pipe at 1.3 PFLOP/s of issue.
 // Epilogue: + ctx[row's utterance] -> ReLU -> BN affine -> tanh (1 - 2 / (1 + e^2x) on v_exp / v_rcp: the output is rounded to bf16)
@@ -27,8 +27,10 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 constexpr int NT_TILE = 128;                       // frames per tile = channels
 constexpr int NT_HT = NT_TILE * 128;               // one operand buffer of one K tile: 128 rows x 64 k bf16 (128 bytes)
-constexpr int NT_LDS = 4 * NT_HT;                  // {X, W} x two K tiles = 64 KiB (the 32 KiB output image reuses it)
+constexpr int NT_LDS = 5 * NT_HT;                  // three K tiles of X + two of W = 80 KiB: two workgroups fill a CU's 160 KiB (the 32 KiB output image reuses it)
 
+// (Round 6, measured and dropped: equal row ranges per workgroup — 512 workgroups of 208 rows walked as a pass of 128 and one of 80 instead of 804
+//  tiles on 512 slots.  160 us against 148 - 151: a pass costs its 48 K tiles of barriers whatever it streams.)
 __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;        // rows wm * 64 .. + 63, channels wn * 64 .. + 63
     const int r16 = lane & 15, q4 = lane >> 4;
     const int m0 = blockIdx.x * NT_TILE;
+    const int mend = p.M;
 
     // ---- operand DMA addressing: thread -> four (row, 16-byte slot) items of a 128 x 128-byte buffer; the swizzle
     //      (slot ^ (row >> 1 & 7)) goes on the source chunk (the DMA writes LDS lane-linear) ----
@@ -47,17 +50,22 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
         const int pidx = q * 256 + tid;
         const int row = pidx >> 3, slot = pidx & 7;
         const int c = slot ^ ((row >> 1) & 7);
-        const int m = min(m0 + row, p.M - 1);
+        const int m = min(m0 + row, mend - 1);
         xo[q] = (uint32_t)m * (uint32_t)(p.lda * 2) + (uint32_t)c * 16u;          // (M * lda * 2 < 2^32: host check)
         wo[q] = (uint32_t)row * (uint32_t)(p.Kp * 2) + (uint32_t)c * 16u;          // weight row = output channel `row`
     }
-    auto issue = [&](int kt, int buf) {
+    // X: a ring of three K tiles (slots 0 .. 2), W: two (slots 3, 4).  X is the HBM stream (read once, 632 MB per launch at B = 256); with one
+    // K tile of it in flight per workgroup (round 4/5: plain double buffering) a CU has 32 KiB outstanding and the chip 8 MB — 4.3 TB/s at
+    // the latency the stream sees; two tiles in flight double that.  W (768 KB, every workgroup reads all of it) comes from L2.
+    auto issue_x = [&](int kt, int slot) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Ab + xo[q] + kt * 128), (lds_void*)(smem + (buf * 2) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);      // (one N tile: X is read once)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Ab + xo[q] + kt * 128), (lds_void*)(smem + slot * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, CPOL_NT);      // (one N tile: X is read once)
+    };
+    auto issue_w = [&](int kt, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(Wb + wo[q] + kt * 128), (lds_void*)(smem + (buf * 2 + 1) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(Wb + wo[q] + kt * 128), (lds_void*)(smem + (3 + buf) * NT_HT + (q * 256 + wave * 64) * 16), 16, 0, 0);
     };
     auto lds_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -71,17 +79,24 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    issue(0, 0);
     const int nkt = p.Kp >> 6;
+    issue_x(0, 0);
+    issue_w(0, 0);
+    if (nkt > 1) issue_x(1, 1);
     const int xrow = (wm * 64 + r16) * 128, wrow = (wn * 64 + r16) * 128;
     const int xkey = ((wm * 64 + r16) >> 1) & 7, wkey = ((wn * 64 + r16) >> 1) & 7;      // (+ 16 i keeps (row >> 1) & 7)
+    int xslot = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();                              // K tile kt has landed for every wave; nobody still reads the other buffer
-        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-        const char* xb = smem + (buf * 2) * NT_HT + xrow;
-        const char* wb = smem + (buf * 2 + 1) * NT_HT + wrow;
+        // X(kt) and W(kt) have landed; X(kt + 1) — the four youngest requests — stays in flight
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                              // ... for every wave; nobody still reads W's other buffer or X's slot of tile kt - 1
+        if (kt + 1 < nkt) issue_w(kt + 1, buf ^ 1);
+        if (kt + 2 < nkt) issue_x(kt + 2, xslot == 0 ? 2 : xslot - 1);      // (kt + 2) % 3
+        const char* xb = smem + xslot * NT_HT + xrow;
+        const char* wb = smem + (3 + buf) * NT_HT + wrow;
+        xslot = xslot == 2 ? 0 : xslot + 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 wf[4], xf[4];
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ml = wm * 64 + i * 16 + r16;
-            const int m = min(m0 + ml, p.M - 1);
+            const int m = min(m0 + ml, mend - 1);
             f32x4 bu = {0.f, 0.f, 0.f, 0.f};
             if (p.bias_utt) bu = *reinterpret_cast<const f32x4*>(p.bias_utt + (int64_t)(m / p.T) * p.ld_bu + nl);
             float v[4];
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_n128_kernel(GemmParams p) {
         const int rr = row & 15;
         const u32x4 t = *reinterpret_cast<const u32x4*>(smem + row * ORB + (((2 * q) ^ (rr & 14)) << 3));
         const u32x4 d = (rr & 1) ? u32x4{t[2], t[3], t[0], t[1]} : t;
-        if (m0 + row < p.M) *reinterpret_cast<u32x4*>(Yb + ((int64_t)(m0 + row) * p.ldy + q * 8) * 2) = d;
+        if (m0 + row < mend) *reinterpret_cast<u32x4*>(Yb + ((int64_t)(m0 + row) * p.ldy + q * 8) * 2) = d;
     }
 }
 
