@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
             }
         }
     };
+    u32x4 dW[8];                                    // (PW4_ABL & 4 only)
     // all four half-tiles of K tile kt of the current source -> ring buffer `buf`
     auto issue_ktile = [&](int kt, int buf) {
         char* base = smem + buf * 4 * HT4 + wave * 4096;
@@ -98,6 +99,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
             for (int pc = 0; pc < 4; ++pc) {
                 uint32_t o = wo[hf][pc];
                 asm("" : "+v"(o));           // (not volatile: opaque to the optimiser — SGPR base + 32-bit VGPR offset addressing — but no scheduling boundary)
+                if (PW4_ABL & 4) {             // ablation: the W pieces as plain loads into registers nobody reads (results wrong; what an LDS-DMA costs beside a load)
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dW[hf * 4 + pc]) : "v"(o), "s"(uw) : "memory");      // (dW stays live until the K tile's vmcnt wait)
+                } else
                 if (!(PW4_ABL & 1)) __builtin_amdgcn_global_load_lds((gbl_void*)(uw + o), (lds_void*)(base + (2 + hf) * HT4 + pc * 1024), 16, 0, 0);
             }
 #pragma unroll
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw4_kernel(GemmParams p) {
             else if (CS == 1) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");                     \
             else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");                                  \
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        if (PW4_ABL & 4) asm volatile("" :: "v"(dW[0]), "v"(dW[1]), "v"(dW[2]), "v"(dW[3]), "v"(dW[4]), "v"(dW[5]), "v"(dW[6]), "v"(dW[7])); \
         if (!(PW4_ABL & 2)) __builtin_amdgcn_s_barrier();                                           \
         /* skew: wave w runs PW4_SKEW cycles behind wave w - 1 until the next barrier, so that the four waves' operand DMAs do not */ \
         /* reach the CU's one address path in the same cycle */                                     \
