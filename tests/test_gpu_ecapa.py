@@ -449,13 +449,14 @@ def test_res2net_time_slices_match_whole_utterances(C, T_samples, B):
             np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("C,L,B", [(1024, 32000, 5), (512, 32000, 20), (1024, 2560, 9), (256, 10320, 7)])
+@pytest.mark.parametrize("C,L,B", [(1024, 32000, 5), (512, 32000, 20), (1024, 2560, 9), (256, 10320, 7), (64, 8000, 6), (128, 12000, 3)])
 def test_n128_attention_gemm_matches_the_generic_route(C, L, B):
     """Round 4: asp.tdnn (N = 128, K = 3C, per-utterance bias, ReLU -> BN -> tanh; ECAPA_TDNN.py:245-250) runs on gemm_n128 (128 x 128
     tiles, four waves, two workgroups per CU) at every batch size; option n128_off keeps gemm_pw's 256 x 128 tile.  Same products in
     the same K order; the epilogues differ in how tanh is evaluated (1 - 2 / (1 + e^2x) on the fast units against tanhf), i.e. by at
     most a bf16 rounding of a few att elements: pooled statistics and embeddings agree far inside the bf16 path's own error.
-    Geometries: several tiles per utterance, short utterances (T = 33: four utterances inside one 128-row tile), a ragged last tile."""
+    Geometries: several tiles per utterance, short utterances (T = 33: four utterances inside one 128-row tile), a ragged last tile;
+    C = 64 / 128 (round 6): K = 192 / 384 — three and six K tiles, the short ends of the kernel's three-slot X ring."""
     sd = synth.synth_state_dict(synth.ecapa_param_spec(C=C), seed=5)
     wav = synth.synth_waveforms(B, L, seed=15)
     eng = Engine(model="ecapa", compute="bf16", channels=C, max_batch=B, samples=L)
